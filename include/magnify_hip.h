@@ -1,0 +1,234 @@
+/*
+ * magnify_hip.h -- C ABI of the MI355X (gfx950) marker-detection hot path.
+ *
+ * The reference (FordyceLab/magnify v0.12.5) is pure Python; its compiled work on
+ * this path comes from OpenCV, numba-JIT helpers and NumPy.
+ * There is no FFI in the reference: each entry point below replaces one of those
+ * native call sites (cited as file:line relative to the reference root) and is
+ * what a ctypes binding in the reference would call.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer owned by the caller (PyTorch-ROCm
+ *     tensors in this repo); the library never allocates or frees device memory;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*) and is
+ *     asynchronous with respect to the host;
+ *   - return value: 0 = ok, MG_EINVAL = bad argument, MG_ELAUNCH = HIP launch error;
+ *   - "plane" = one (channel, time) image of H x W pixels; kernels are batched over
+ *     planes (gridDim.z / gridDim.y) and read per-plane counters from device memory
+ *     so that no host round trip is needed between stages;
+ *   - thread-safe as long as streams and buffers are distinct.
+ */
+#ifndef MAGNIFY_HIP_H
+#define MAGNIFY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_OK 0
+#define MG_EINVAL (-1)
+#define MG_ELAUNCH (-2)
+
+/* element types of image/tile buffers */
+#define MG_U8 0
+#define MG_U16 1
+#define MG_F32 2
+#define MG_F64 3
+
+/* value stored in the angle map for "not an edge pixel" (angles are in [-pi, pi]) */
+#define MG_NO_EDGE 100.0f
+
+/* Canny map values (OpenCV's): 0 weak candidate, 1 not an edge, 2 strong edge */
+
+int mg_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Host-side tables (no GPU needed).  utils.py:433-465 circle_points,
+ * utils.py:398-430 filled_circle_points, utils.py:38 cv.circle(thickness=-1).
+ * ---------------------------------------------------------------------------------- */
+
+/* Perimeter offsets (row, col) in the reference's emission order.  Returns the number
+ * of points (writes at most cap of them; pass cap=0 to query). */
+int mg_circle_points(int r, int four_connected, int32_t* out_rc, int cap);
+/* Filled disk of filled_circle_points(r) as per-row half widths: out[dy + r] = max |dx|
+ * for dy in [-r, r].  r >= 2 (undefined below that in the reference).  Returns 2r+1. */
+int mg_disk_halfwidths(int r, int32_t* out);
+/* Filled disk of cv.circle(..., thickness=-1): out[|dy|] = max |dx|, |dy| in [0, r]. */
+int mg_cv_disk_halfwidths(int r, int32_t* out);
+/* Concatenated perimeter tables for radii min_r..max_r: offsets (row, col) int32,
+ * expected angle atan2(row, col) float64 (utils.py:234), starts[nr+1].  Returns the
+ * total number of points, or the required capacity if cap is too small. */
+int mg_perimeter_table(int min_r, int max_r, int32_t* out_rc, double* out_expected, int32_t* out_starts, int cap);
+
+/* ------------------------------------------------------------------------------------
+ * A2 flat-field (preprocess.py:83-87) and A1 stitch (stitch.py:22-39)
+ * ---------------------------------------------------------------------------------- */
+
+/* Pass 1: the two global maxima M1 = max(clip(x - dark, 0)) and M2 = max(clip(x - dark, 0) / flat)
+ * over ALL n_tiles * ty * tx elements (float64, NaN-propagating).
+ * d_max2 is double[2], pre-initialised by the caller to -inf.
+ * dark/flat: scalar when d_dark / d_flat is NULL, else a (ty, tx) image of type
+ * dark_dtype / flat_dtype (MG_F32 or MG_F64) broadcast over tiles. */
+int mg_flatfield_max(const void* d_tiles, int dtype, int64_t n_tiles, int ty, int tx,
+                     double dark, const void* d_dark, int dark_dtype,
+                     double flat, const void* d_flat, int flat_dtype,
+                     double* d_max2, void* stream);
+
+/* Pass 2, fused with the stitch crop/concat: out[p, R*hy, Cc*hx] in the input dtype,
+ * value = trunc(((clip(x - dark, 0) / flat) * M1) / M2) with M1, M2 read from d_max2.
+ * Tiles are laid out (plane, tile_row, tile_col, ty, tx); hy = ty - overlap etc.
+ * If apply_flatfield == 0 this is the pure stitch copy (any dtype, d_max2 unused).
+ * d_minmax (optional, double[n_planes][2] pre-initialised to {+inf, -inf}) receives the
+ * per-plane min/max of the values written (feeds to_uint8, utils.py:24-26). */
+int mg_flatfield_apply_stitch(const void* d_tiles, int dtype, int64_t n_planes, int n_tile_rows, int n_tile_cols,
+                              int ty, int tx, int overlap, int apply_flatfield,
+                              double dark, const void* d_dark, int dark_dtype,
+                              double flat, const void* d_flat, int flat_dtype,
+                              const double* d_max2, void* d_image, double* d_minmax, void* stream);
+
+/* Per-plane min/max (utils.py:24-25) of strided planes.  d_minmax double[n_planes][2],
+ * pre-initialised to {+inf, -inf}.  Strides are in elements. */
+int mg_plane_minmax(const void* d_src, int dtype, int n_planes, int64_t plane_stride, int h, int w,
+                    int64_t row_stride, double* d_minmax, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * A3-A6 edge stage of find_circles (utils.py:20-27, 115-142)
+ * ---------------------------------------------------------------------------------- */
+
+/* to_uint8 (global min/max rescale, truncating) fused with cv.GaussianBlur(5x5, sigma 0):
+ * d_blur[n_planes][h][w] u8.  d_u8 (optional, same shape) receives the un-blurred uint8
+ * image.  With dtype == MG_U8 and d_minmax == NULL the input is taken as already uint8. */
+int mg_to_uint8_blur(const void* d_src, int dtype, int n_planes, int64_t plane_stride, int h, int w,
+                     int64_t row_stride, const double* d_minmax, uint8_t* d_blur, uint8_t* d_u8, void* stream);
+
+/* Scharr gradients of the blurred image and a histogram of the integer squared
+ * magnitude m = dx^2 + dy^2 (the float32 gradient of utils.py:120 is sqrt(float(m)), a
+ * monotone function of m, so np.quantile's order statistics are recovered exactly):
+ * d_hist[n_planes][n_bins] += 1 at bin (m - d_base[plane]) >> shift when that is in
+ * [0, n_bins).  d_base NULL means base 0.  n_bins <= 8192. */
+int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w, const uint32_t* d_base, int shift,
+                   int n_bins, uint32_t* d_hist, void* stream);
+
+/* cv.Canny(dx, dy, L2gradient=True) non-maximum suppression + double threshold with the
+ * already prepared integer thresholds d_thresh[n_planes][2] = {low, high}; writes
+ * OpenCV's map values {0 weak, 1 none, 2 strong} to d_map[n_planes][h][w]. */
+int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_thresh, uint8_t* d_map,
+                 void* stream);
+
+/* One sweep of 8-connected hysteresis (tile-local fixed point + halo exchange through
+ * global memory).  d_changed[n_planes] is incremented for planes that changed; call until
+ * a sweep leaves it at zero. */
+int mg_canny_hysteresis(uint8_t* d_map, int n_planes, int h, int w, uint32_t* d_changed, void* stream);
+
+/* Finalise: map -> {0,1} edge map in place (utils.py:142), angle map (float32
+ * atan2(dy, dx) at edge pixels, MG_NO_EDGE elsewhere; utils.py:170) and the per-cell
+ * edge counts of grid_array (utils.py:351-357): d_cell_counts[n_planes][gr*gc] int32,
+ * pre-zeroed, gr = ceil(h / grid), gc = ceil(w / grid). */
+int mg_edges_finalize(uint8_t* d_map, const uint8_t* d_blur, int n_planes, int h, int w, int grid,
+                      float* d_angle, int32_t* d_cell_counts, void* stream);
+
+/* grid_array (utils.py:359-377): exclusive scan of the cell counts (d_cell_starts, and
+ * d_num_edges[n_planes]) and the cell-major / row-major-inside-cell coordinate list
+ * d_coords[n_planes][coord_cap][2] (row, col) int32. */
+int mg_edge_grid(const uint8_t* d_edges, int n_planes, int h, int w, int grid, const int32_t* d_cell_counts,
+                 int32_t* d_cell_starts, int32_t* d_num_edges, int32_t* d_coords, int64_t coord_cap, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * A8-A11 RANSAC circle candidates, scoring, greedy NMS (utils.py:145-199, 225-344)
+ * ---------------------------------------------------------------------------------- */
+
+/* candidate_circles (utils.py:295-344) with the build's counter-based RNG (the reference
+ * is unseeded): iteration i of plane p draws three 32-bit uniforms from
+ * splitmix64(seed[p] + (3 i + k + 1) * golden) >> 32, p0 = coords[u0 * E >> 32],
+ * p1, p2 = p0's cell list[u * count >> 32].  Then steps 4 of filter_circles
+ * (utils.py:157-166): radius window, round-half-even, off-image rejection.  Survivors set
+ * their bit in d_bitmap[n_planes][bitmap_words] (layout: ((r - min_r) * HH + row + max_r) * WW
+ * + col + max_r, HH = h + 2 max_r, WW = w + 2 max_r), which de-duplicates them.
+ * d_raw (optional, float32 [n_planes][num_iter][3]) receives the unfiltered circles. */
+int mg_candidate_circles(const int32_t* d_coords, int64_t coord_cap, const int32_t* d_cell_starts,
+                         const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w,
+                         int grid, const uint64_t* d_seeds, int64_t num_iter, int min_r, int max_r,
+                         uint32_t* d_bitmap, int64_t bitmap_words, float* d_raw, void* stream);
+
+/* Ordered compaction of the bitmap into the unique circle list, sorted by (r, row, col):
+ * d_circles[n_planes][circle_cap][3] int32, d_num_circles[n_planes].  Clears the bitmap
+ * words it consumes (the bitmap is all-zero again afterwards).  d_block_counts is scratch
+ * of n_planes * ceil(bitmap_words / 1024) uint32. */
+int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, int n_planes, int h, int w, int min_r,
+                         int max_r, uint32_t* d_block_counts, int32_t* d_circles, int64_t circle_cap,
+                         int32_t* d_num_circles, void* stream);
+
+/* mean_grad / len(perimeter) (utils.py:183-188, 225-251): float64 sequential sum in
+ * perimeter order, stored float32, divided by the perimeter length in float32.  Circles
+ * with score >= min_roundness (float32 compare, utils.py:191) are appended (unordered) to
+ * d_alive[n_planes][circle_cap] (indices into d_circles), d_num_alive[n_planes] pre-zeroed;
+ * d_max_rc[n_planes][2] (pre-set to INT32_MIN) receives max row / max col of the alive
+ * circles (the claim-grid extent of utils.py:268-270). */
+int mg_score_circles(const float* d_angle, int n_planes, int h, int w, const int32_t* d_circles,
+                     int64_t circle_cap, const int32_t* d_num_circles, int min_r, int max_r,
+                     const int32_t* d_per_rc, const double* d_per_expected, const int32_t* d_per_starts,
+                     float min_roundness, float* d_scores, int32_t* d_alive, int32_t* d_num_alive,
+                     int32_t* d_max_rc, void* stream);
+
+/* One round of the parallel-but-equivalent greedy suppression of filter_neighbors
+ * (utils.py:254-292).  Priority = (score desc, index in d_circles asc) -- the build's
+ * canonical tie order.  d_grid[n_planes][grid_cap] uint64 claim grid pre-set to all-ones;
+ * d_state[n_planes][circle_cap] uint8 (0 undecided, 1 kept, 2 dropped) pre-zeroed for
+ * alive circles; d_undecided[n_planes] is overwritten with the number still undecided.
+ * Ring = 4-connected perimeter of radius min_dist (d_ring_rc, ring_len); indices wrap
+ * modulo the claim grid extent like negative numba indices do. */
+int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
+                 const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist,
+                 const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
+                 int32_t* d_undecided, void* stream);
+
+/* Gather the kept circles in priority order (utils.py:195-199 output order):
+ * d_out[n_planes][out_cap][3] int32 (row, col, r), d_out_scores, d_num_out[n_planes].
+ * keep_all != 0 skips the state test (min_dist == 0: no suppression, utils.py:197). */
+int mg_collect_circles(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
+                       const int32_t* d_num_alive, const uint8_t* d_state, int keep_all, int n_planes,
+                       int32_t* d_out, float* d_out_scores, int64_t out_cap, int32_t* d_num_out,
+                       int32_t* d_scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * A12-A15, A18 labels, ROI gather, fg/bg masks, masked reductions
+ * (utils.py:380-395, 60-80; find.py:561-602; README.md:21-22, identify.py:76-80)
+ * ---------------------------------------------------------------------------------- */
+
+/* circle_labels as a coverage count: d_labels[n_planes][h][w] int32 pre-set to -1;
+ * beads d_beads[n_planes][bead_cap][3] (row, col, r), d_num_beads[n_planes];
+ * d_halfwidths[(max_r+1)][2*max_r+1] from mg_disk_halfwidths (row r of the table). */
+int mg_circle_labels(const int32_t* d_beads, int64_t bead_cap, const int32_t* d_num_beads, int n_planes, int h,
+                     int w, const int32_t* d_halfwidths, int max_r, int32_t* d_labels, void* stream);
+
+/* ROI gather + masks + reductions for one assay.  image (C, T, h, w) of dtype (u8/u16/f32);
+ * beads (m, 3) with labels from time 0; window = bounding_box(col, row, L, w, h).
+ * Outputs: roi (m, C, T, L, L) same dtype; fg, bg (m, L, L) uint8 {0,1};
+ * sums double[m][C][T][2] = {sum over fg, sum over bg} (exact for integer dtypes below 2^53),
+ * counts int32[m][2] = {|fg|, |bg|}.  Any output pointer may be NULL. */
+int mg_roi_gather_reduce(const void* d_image, int dtype, int n_c, int n_t, int h, int w, const int32_t* d_beads,
+                         int m, int roi_len, const int32_t* d_labels, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
+                         double* d_sums, int32_t* d_counts, void* stream);
+
+/* Batched form: marker g belongs to assay d_marker_assay[g] (image base + assay * assay_stride
+ * elements, labels base + assay * h * w) and owns label value d_marker_local[g].  Both index
+ * arrays may be NULL (single assay, local index = g).  d_beads is (m, 3) for all markers. */
+int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h, int w,
+                                 const int32_t* d_beads, const int32_t* d_marker_assay,
+                                 const int32_t* d_marker_local, int m, int roi_len, const int32_t* d_labels,
+                                 void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts,
+                                 void* stream);
+
+/* Masked median (numpy nanmedian semantics: mean of the two middle values) of an already
+ * gathered roi (m, C, T, L, L) under mask (m, L, L): d_median double[m][C][T], NaN if the
+ * mask is empty.  u16 only (radix select on the 16-bit value). */
+int mg_roi_masked_median_u16(const uint16_t* d_roi, const uint8_t* d_mask, int m, int n_c, int n_t, int roi_len,
+                             double* d_median, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGNIFY_HIP_H */

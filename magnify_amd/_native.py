@@ -1,0 +1,129 @@
+"""ctypes binding of the C-ABI hot-path library (``include/magnify_hip.h``).
+
+The library is built in-tree by ``magnify_amd/csrc/Makefile`` (``__graft_entry__.build()``)
+into ``magnify_amd/_lib/libmagnify_hip.so``.  There is NO CPU fallback: if the library is
+missing every product entry point raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libmagnify_hip.so")
+
+MG_U8, MG_U16, MG_F32, MG_F64 = 0, 1, 2, 3
+MG_NO_EDGE = 100.0
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_d = C.c_double
+_f = C.c_float
+
+# name -> argtypes, exactly the prototypes of include/magnify_hip.h
+PROTOTYPES = {
+    "mg_version": [],
+    "mg_circle_points": [_i, _i, _p, _i],
+    "mg_disk_halfwidths": [_i, _p],
+    "mg_cv_disk_halfwidths": [_i, _p],
+    "mg_perimeter_table": [_i, _i, _p, _p, _p, _i],
+    "mg_flatfield_max": [_p, _i, _l, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p],
+    "mg_flatfield_apply_stitch": [_p, _i, _l, _i, _i, _i, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p, _p, _p],
+    "mg_plane_minmax": [_p, _i, _i, _l, _i, _i, _l, _p, _p],
+    "mg_to_uint8_blur": [_p, _i, _i, _l, _i, _i, _l, _p, _p, _p, _p],
+    "mg_scharr_hist": [_p, _i, _i, _i, _p, _i, _i, _p, _p],
+    "mg_canny_nms": [_p, _i, _i, _i, _p, _p, _p],
+    "mg_canny_hysteresis": [_p, _i, _i, _i, _p, _p],
+    "mg_edges_finalize": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
+    "mg_edge_grid": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p],
+    "mg_candidate_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _p, _p],
+    "mg_bitmap_to_circles": [_p, _l, _i, _i, _i, _i, _i, _p, _p, _l, _p, _p],
+    "mg_score_circles": [_p, _i, _i, _i, _p, _l, _p, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p],
+    "mg_nms_round": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _p],
+    "mg_collect_circles": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p],
+    "mg_circle_labels": [_p, _l, _p, _i, _i, _i, _p, _i, _p, _p],
+    "mg_roi_gather_reduce": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "mg_roi_gather_reduce_batched": [_p, _i, _l, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "mg_roi_masked_median_u16": [_p, _p, _i, _i, _i, _i, _p, _p],
+}
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C magnify_amd/csrc).  magnify_amd has no CPU fallback."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc == -1:
+        raise ValueError(f"{what}: invalid argument (MG_EINVAL)")
+    raise RuntimeError(f"{what}: HIP launch failure (code {rc})")
+
+
+def dtype_code(dtype) -> int:
+    """MG_* code of a numpy/torch dtype (by name)."""
+    name = str(dtype).replace("torch.", "")
+    try:
+        return {"uint8": MG_U8, "uint16": MG_U16, "float32": MG_F32, "float64": MG_F64}[name]
+    except KeyError:
+        raise TypeError(f"unsupported image dtype {dtype}; supported: uint8, uint16, float32, float64") from None
+
+
+# ---- host tables ---------------------------------------------------------------------------
+
+
+def circle_points(r: int, four_connected: bool = False) -> np.ndarray:
+    n = lib().mg_circle_points(int(r), int(bool(four_connected)), None, 0)
+    if n < 0:
+        raise ValueError("radius must be non-negative")
+    out = np.empty((n, 2), dtype=np.int32)
+    lib().mg_circle_points(int(r), int(bool(four_connected)), out.ctypes.data, n)
+    return out
+
+
+def disk_halfwidths(r: int) -> np.ndarray:
+    out = np.empty(2 * r + 1, dtype=np.int32)
+    if lib().mg_disk_halfwidths(int(r), out.ctypes.data) < 0:
+        raise ValueError("filled disk is undefined for r < 2 (reference utils.py:398-430)")
+    return out
+
+
+def cv_disk_halfwidths(r: int) -> np.ndarray:
+    out = np.empty(r + 1, dtype=np.int32)
+    if lib().mg_cv_disk_halfwidths(int(r), out.ctypes.data) < 0:
+        raise ValueError("radius must be non-negative")
+    return out
+
+
+def perimeter_table(min_r: int, max_r: int):
+    starts = np.empty(max_r - min_r + 2, dtype=np.int32)
+    total = lib().mg_perimeter_table(int(min_r), int(max_r), None, None, starts.ctypes.data, 0)
+    if total < 0:
+        raise ValueError("bad radius range")
+    rc = np.empty((total, 2), dtype=np.int32)
+    expected = np.empty(total, dtype=np.float64)
+    lib().mg_perimeter_table(int(min_r), int(max_r), rc.ctypes.data, expected.ctypes.data, starts.ctypes.data, total)
+    return rc, expected, starts

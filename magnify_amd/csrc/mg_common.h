@@ -1,0 +1,126 @@
+// Shared device/host helpers for the gfx950 marker-detection kernels.
+// Built with -ffp-contract=off: float64 sequences must round exactly like NumPy's.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/magnify_hip.h"
+
+#define MG_WAVE 64
+
+#define MG_CHECK_LAUNCH()                          \
+  do {                                             \
+    hipError_t e_ = hipGetLastError();             \
+    if (e_ != hipSuccess) return MG_ELAUNCH;       \
+  } while (0)
+
+static inline hipStream_t mg_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+__host__ __device__ static inline int mg_elem_size(int dtype) {
+  return dtype == MG_U8 ? 1 : dtype == MG_U16 ? 2 : dtype == MG_F32 ? 4 : 8;
+}
+
+// cv::borderInterpolate(p, n, BORDER_REFLECT_101)
+__device__ __forceinline__ int mg_reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+  return p;
+}
+
+// Load element idx of a scalar-or-image operand as float64.
+__device__ __forceinline__ double mg_load_f64(const void* p, int dtype, int64_t idx) {
+  switch (dtype) {
+    case MG_U8: return (double)((const uint8_t*)p)[idx];
+    case MG_U16: return (double)((const uint16_t*)p)[idx];
+    case MG_F32: return (double)((const float*)p)[idx];
+    default: return ((const double*)p)[idx];
+  }
+}
+
+// NaN-propagating max / min, as np.max / np.min.
+__device__ __forceinline__ double mg_nanmax(double a, double b) { return (a != a) ? a : (b != b) ? b : (a > b ? a : b); }
+__device__ __forceinline__ double mg_nanmin(double a, double b) { return (a != a) ? a : (b != b) ? b : (a < b ? a : b); }
+
+__device__ __forceinline__ double mg_wave_nanmax(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = mg_nanmax(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ double mg_wave_nanmin(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = mg_nanmin(v, __shfl_xor(v, off));
+  return v;
+}
+
+__device__ __forceinline__ void mg_atomic_nanmax(double* addr, double v) {
+  unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
+  unsigned long long old = *a;
+  while (true) {
+    double cur = __longlong_as_double((long long)old);
+    if (cur != cur) return;                // already NaN
+    if (v == v && !(v > cur)) return;      // not larger (and not NaN)
+    unsigned long long seen = atomicCAS(a, old, (unsigned long long)__double_as_longlong(v));
+    if (seen == old) return;
+    old = seen;
+  }
+}
+__device__ __forceinline__ void mg_atomic_nanmin(double* addr, double v) {
+  unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
+  unsigned long long old = *a;
+  while (true) {
+    double cur = __longlong_as_double((long long)old);
+    if (cur != cur) return;
+    if (v == v && !(v < cur)) return;
+    unsigned long long seen = atomicCAS(a, old, (unsigned long long)__double_as_longlong(v));
+    if (seen == old) return;
+    old = seen;
+  }
+}
+
+__device__ __forceinline__ int mg_wave_sum_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ long long mg_wave_sum_i64(long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double mg_wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// Exclusive prefix sum over the threads of a block (blockDim.x <= 1024, multiple of 64).
+// Returns this thread's exclusive prefix; *total receives the block sum in every thread.
+__device__ __forceinline__ int mg_block_exscan(int v, int* total) {
+  __shared__ int s_wave[16];
+  __shared__ int s_total;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    const int w = lane < nw ? s_wave[lane] : 0;
+    int wi = w;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const int t = __shfl_up(wi, off);
+      if (lane >= off) wi += t;
+    }
+    if (lane < nw) s_wave[lane] = wi - w;
+    if (lane == nw - 1) s_total = wi;
+  }
+  __syncthreads();
+  const int res = incl - v + s_wave[wave];
+  *total = s_total;
+  __syncthreads();
+  return res;
+}

@@ -1,0 +1,266 @@
+// A12-A15, A18: ownership labels (utils.py:380-395), ROI windows (utils.py:60-80), fg/bg masks
+// and ROI gather (find.py:561-602), masked reductions (README.md:21-22, identify.py:76-80).
+//
+// Roofline: HBM.  Per marker: L*L*(4 label read + 2 mask write) + C*T*L*L*(2 read + 2 write)
+// bytes (u16); the reductions ride along in registers (wavefront shuffles), 0 extra bytes.
+#include <math.h>
+
+#include "mg_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---- circle_labels as a coverage count -------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_circle_labels(const int32_t* __restrict__ d_beads, int64_t bead_cap,
+                                                      const int32_t* __restrict__ d_num_beads, int h, int w,
+                                                      const int32_t* __restrict__ d_halfwidths, int max_r,
+                                                      int32_t* __restrict__ d_labels) {
+  const int plane = blockIdx.y;
+  const int i = blockIdx.x;
+  if (i >= d_num_beads[plane]) return;
+  const int32_t* b = d_beads + ((int64_t)plane * bead_cap + i) * 3;
+  const int row = b[0], col = b[1], r = b[2];
+  if (r < 2 || r > max_r) return;  // undefined in the reference (utils.py:398-430 indexes out of bounds)
+  const int32_t* hw = d_halfwidths + (int64_t)r * (2 * max_r + 1);
+  int32_t* lab = d_labels + (int64_t)plane * h * w;
+  const int side = 2 * r + 1;
+  for (int p = threadIdx.x; p < side * side; p += NT) {
+    const int dy = p / side - r, dx = p % side - r;
+    if (abs(dx) > hw[dy + r]) continue;
+    const int y = row + dy, x = col + dx;
+    if (y < 0 || y >= h || x < 0 || x >= w) continue;
+    int32_t* cell = &lab[(int64_t)y * w + x];
+    const int old = atomicCAS(cell, -1, i);
+    if (old != -1 && old != i) *cell = -2;  // a second owner: contested
+  }
+}
+
+// ---- ROI gather + masks + sums ------------------------------------------------------------------
+__device__ __forceinline__ void window(int c, int len, int size, int& lo) {
+  // utils.py:64-79 with an integer centre
+  int a = c - len / 2, b = c + (len - len / 2);
+  if (a < 0) {
+    b -= a;
+    a = 0;
+  }
+  if (b > size) a -= b - size;
+  lo = a;
+}
+
+template <typename T, typename ACC>
+__global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64_t assay_stride, int n_c, int n_t, int h,
+                                            int w, const int32_t* __restrict__ d_beads,
+                                            const int32_t* __restrict__ d_marker_assay,
+                                            const int32_t* __restrict__ d_marker_local, int len,
+                                            const int32_t* __restrict__ d_labels, T* __restrict__ d_roi,
+                                            uint8_t* __restrict__ d_fg, uint8_t* __restrict__ d_bg,
+                                            double* __restrict__ d_sums, int32_t* __restrict__ d_counts) {
+  extern __shared__ uint8_t flags[];
+  __shared__ ACC s_red[2][NT / 64];
+  __shared__ int s_cnt[2][NT / 64];
+  const int g = blockIdx.x;
+  const int assay = d_marker_assay ? d_marker_assay[g] : 0;
+  const int local = d_marker_local ? d_marker_local[g] : g;
+  const int cy = d_beads[3 * (int64_t)g], cx = d_beads[3 * (int64_t)g + 1];
+  int top, left;
+  window(cy, len, h, top);
+  window(cx, len, w, left);
+  const int n = len * len;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // masks from the label map (find.py:580-584)
+  const int32_t* lab = d_labels ? d_labels + (int64_t)assay * h * w : nullptr;
+  int cf = 0, cb = 0;
+  for (int p = threadIdx.x; p < n; p += NT) {
+    const int ry = p / len, rx = p - ry * len;
+    uint8_t f = 0, b = 0;
+    if (lab) {
+      const int v = lab[(int64_t)(top + ry) * w + (left + rx)];
+      f = v == local;
+      b = v == -1;
+    }
+    flags[p] = f | (b << 1);
+    if (d_fg) d_fg[(int64_t)g * n + p] = f;
+    if (d_bg) d_bg[(int64_t)g * n + p] = b;
+    cf += f;
+    cb += b;
+  }
+  cf = mg_wave_sum_i32(cf);
+  cb = mg_wave_sum_i32(cb);
+  if (lane == 0) {
+    s_cnt[0][wave] = cf;
+    s_cnt[1][wave] = cb;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && d_counts) {
+    d_counts[2 * (int64_t)g] = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+    d_counts[2 * (int64_t)g + 1] = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+  }
+  // gather every (channel, time) window (find.py:589-602) and reduce under the masks
+  const T* img = d_image + (int64_t)assay * assay_stride;
+  for (int ct = 0; ct < n_c * n_t; ++ct) {
+    const T* plane = img + (int64_t)ct * h * w;
+    T* out = d_roi ? d_roi + ((int64_t)g * n_c * n_t + ct) * n : nullptr;
+    ACC sf = 0, sb = 0;
+    for (int p = threadIdx.x; p < n; p += NT) {
+      const int ry = p / len, rx = p - ry * len;
+      const T v = plane[(int64_t)(top + ry) * w + (left + rx)];
+      if (out) out[p] = v;
+      const uint8_t fl = flags[p];
+      if (fl & 1) sf += (ACC)v;
+      if (fl & 2) sb += (ACC)v;
+    }
+    if (d_sums) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        sf += __shfl_xor(sf, off);
+        sb += __shfl_xor(sb, off);
+      }
+      __syncthreads();
+      if (lane == 0) {
+        s_red[0][wave] = sf;
+        s_red[1][wave] = sb;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double* o = d_sums + ((int64_t)g * n_c * n_t + ct) * 2;
+        o[0] = (double)(s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3]);
+        o[1] = (double)(s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]);
+      }
+    }
+  }
+}
+
+// ---- masked median (u16): two-level radix select in LDS --------------------------------------------
+__device__ int select_kth_u16(const uint16_t* __restrict__ v, const uint8_t* __restrict__ mask, int n, int k,
+                              uint32_t* hist) {
+  // returns the k-th smallest (0-based) masked value
+  __shared__ int s_bin, s_rank;
+  int prefix_val = 0;
+  int rank = k;
+  for (int level = 0; level < 2; ++level) {
+    for (int i = threadIdx.x; i < 256; i += NT) hist[i] = 0;
+    __syncthreads();
+    for (int p = threadIdx.x; p < n; p += NT) {
+      if (!mask[p]) continue;
+      const int x = v[p];
+      if (level == 0) {
+        atomicAdd(&hist[x >> 8], 1u);
+      } else if ((x >> 8) == prefix_val) {
+        atomicAdd(&hist[x & 255], 1u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0, b = 0;
+      for (; b < 256; ++b) {
+        if (acc + (int)hist[b] > rank) break;
+        acc += hist[b];
+      }
+      s_bin = b;
+      s_rank = rank - acc;
+    }
+    __syncthreads();
+    if (level == 0) prefix_val = s_bin;
+    else prefix_val = (prefix_val << 8) | s_bin;
+    rank = s_rank;
+    __syncthreads();
+  }
+  return prefix_val;
+}
+
+__global__ __launch_bounds__(NT) void k_masked_median_u16(const uint16_t* __restrict__ d_roi,
+                                                          const uint8_t* __restrict__ d_mask, int n_ct, int n,
+                                                          double* __restrict__ d_median) {
+  __shared__ uint32_t hist[256];
+  __shared__ int s_count;
+  const int g = blockIdx.x, ct = blockIdx.y;
+  const uint16_t* v = d_roi + ((int64_t)g * n_ct + ct) * n;
+  const uint8_t* mask = d_mask + (int64_t)g * n;
+  int c = 0;
+  for (int p = threadIdx.x; p < n; p += NT) c += mask[p] != 0;
+  int total;
+  mg_block_exscan(c, &total);
+  if (threadIdx.x == 0) s_count = total;
+  __syncthreads();
+  const int cnt = s_count;
+  double* out = d_median + (int64_t)g * n_ct + ct;
+  if (cnt == 0) {
+    if (threadIdx.x == 0) *out = __longlong_as_double(0x7FF8000000000000ll);
+    return;
+  }
+  const int lo = select_kth_u16(v, mask, n, (cnt - 1) / 2, hist);
+  int hi = lo;
+  if ((cnt & 1) == 0) hi = select_kth_u16(v, mask, n, cnt / 2, hist);
+  if (threadIdx.x == 0) *out = ((double)lo + (double)hi) / 2.0;
+}
+
+template <typename T, typename ACC>
+int launch_roi(const void* d_image, int64_t assay_stride, int n_c, int n_t, int h, int w, const int32_t* d_beads,
+               const int32_t* d_marker_assay, const int32_t* d_marker_local, int m, int len, const int32_t* d_labels,
+               void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, hipStream_t s) {
+  hipLaunchKernelGGL((k_roi<T, ACC>), dim3(m), dim3(NT), (size_t)len * len, s, (const T*)d_image, assay_stride, n_c,
+                     n_t, h, w, d_beads, d_marker_assay, d_marker_local, len, d_labels, (T*)d_roi, d_fg, d_bg, d_sums,
+                     d_counts);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+}  // namespace
+
+extern "C" int mg_circle_labels(const int32_t* d_beads, int64_t bead_cap, const int32_t* d_num_beads, int n_planes,
+                                int h, int w, const int32_t* d_halfwidths, int max_r, int32_t* d_labels,
+                                void* stream) {
+  if (!d_beads || !d_num_beads || !d_halfwidths || !d_labels || n_planes < 0 || n_planes > 65535 || bead_cap < 0 ||
+      max_r < 0)
+    return MG_EINVAL;
+  if (n_planes == 0 || bead_cap == 0) return MG_OK;
+  hipLaunchKernelGGL(k_circle_labels, dim3((unsigned)bead_cap, n_planes), dim3(NT), 0, mg_stream(stream), d_beads,
+                     bead_cap, d_num_beads, h, w, d_halfwidths, max_r, d_labels);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t,
+                                            int h, int w, const int32_t* d_beads, const int32_t* d_marker_assay,
+                                            const int32_t* d_marker_local, int m, int roi_len,
+                                            const int32_t* d_labels, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
+                                            double* d_sums, int32_t* d_counts, void* stream) {
+  if (!d_image || !d_beads || m < 0 || roi_len <= 0 || n_c <= 0 || n_t <= 0) return MG_EINVAL;
+  if (roi_len > h || roi_len > w || (int64_t)roi_len * roi_len > 60000) return MG_EINVAL;
+  if (m == 0) return MG_OK;
+  hipStream_t s = mg_stream(stream);
+  switch (dtype) {
+    case MG_U8:
+      return launch_roi<uint8_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
+                                            d_marker_local, m, roi_len, d_labels, d_roi, d_fg, d_bg, d_sums, d_counts, s);
+    case MG_U16:
+      return launch_roi<uint16_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
+                                             d_marker_local, m, roi_len, d_labels, d_roi, d_fg, d_bg, d_sums, d_counts, s);
+    case MG_F32:
+      return launch_roi<float, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
+                                       m, roi_len, d_labels, d_roi, d_fg, d_bg, d_sums, d_counts, s);
+    case MG_F64:
+      return launch_roi<double, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
+                                        m, roi_len, d_labels, d_roi, d_fg, d_bg, d_sums, d_counts, s);
+  }
+  return MG_EINVAL;
+}
+
+extern "C" int mg_roi_gather_reduce(const void* d_image, int dtype, int n_c, int n_t, int h, int w,
+                                    const int32_t* d_beads, int m, int roi_len, const int32_t* d_labels, void* d_roi,
+                                    uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream) {
+  return mg_roi_gather_reduce_batched(d_image, dtype, 0, n_c, n_t, h, w, d_beads, nullptr, nullptr, m, roi_len,
+                                      d_labels, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
+}
+
+extern "C" int mg_roi_masked_median_u16(const uint16_t* d_roi, const uint8_t* d_mask, int m, int n_c, int n_t,
+                                        int roi_len, double* d_median, void* stream) {
+  if (!d_roi || !d_mask || !d_median || m < 0 || n_c <= 0 || n_t <= 0 || roi_len <= 0) return MG_EINVAL;
+  if (n_c * n_t > 65535) return MG_EINVAL;
+  if (m == 0) return MG_OK;
+  hipLaunchKernelGGL(k_masked_median_u16, dim3(m, n_c * n_t), dim3(NT), 0, mg_stream(stream), d_roi, d_mask,
+                     n_c * n_t, roi_len * roi_len, d_median);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}

@@ -1,0 +1,476 @@
+"""Device-side orchestration of the hot path on PyTorch-ROCm tensors.
+
+PyTorch is plumbing only (device memory, streams); every numeric step is a hand-written HIP
+kernel reached through the C ABI (``include/magnify_hip.h``).  Host code here mirrors the control
+flow of the reference's ``utils.find_circles`` (src/magnify/utils.py:102-222),
+``flatfield_correct`` (preprocess.py:62-88), ``Stitcher`` (stitch.py:12-46) and the ROI part of
+``BeadFinder.__call__`` (find.py:561-602), batched over planes.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+GRID_LENGTH = 20  # find.py:215, 348, 482
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("magnify_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+    nat.lib()
+
+
+# --------------------------------------------------------------------------------------
+# A2 + A1: flat-field correction fused with stitching
+# --------------------------------------------------------------------------------------
+
+
+def _df_operand(value, ty, tx, device):
+    """Scalar -> (float, None, 0); image -> (0.0, device tensor, dtype code)."""
+    if np.isscalar(value) or (isinstance(value, np.ndarray) and value.ndim == 0):
+        return float(value), None, 0
+    arr = np.asarray(value) if not isinstance(value, torch.Tensor) else value
+    if isinstance(arr, np.ndarray):
+        if arr.shape != (ty, tx):
+            raise ValueError(f"flat/dark field image must have the tile shape {(ty, tx)}, got {arr.shape}")
+        arr = arr.astype(np.float32 if arr.dtype == np.float32 else np.float64)
+        arr = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+    else:
+        if tuple(arr.shape) != (ty, tx):
+            raise ValueError(f"flat/dark field image must have the tile shape {(ty, tx)}")
+        arr = arr.to(device=device, dtype=torch.float32 if arr.dtype == torch.float32 else torch.float64).contiguous()
+    return 0.0, arr, nat.dtype_code(arr.dtype)
+
+
+def flatfield_max(tiles: torch.Tensor, flatfield=1.0, darkfield=0.0) -> torch.Tensor:
+    """Pass 1 of flatfield_correct: the two global maxima as a float64[2] device tensor."""
+    require_gpu()
+    ty, tx = tiles.shape[-2:]
+    tiles = tiles.contiguous()
+    dk, dkt, dkc = _df_operand(darkfield, ty, tx, tiles.device)
+    fl, flt, flc = _df_operand(flatfield, ty, tx, tiles.device)
+    max2 = torch.full((2,), -math.inf, dtype=torch.float64, device=tiles.device)
+    n_tiles = tiles.numel() // (ty * tx)
+    nat.check(nat.lib().mg_flatfield_max(tiles.data_ptr(), nat.dtype_code(tiles.dtype), n_tiles, ty, tx, dk, _ptr(dkt),
+                                         dkc, fl, _ptr(flt), flc, max2.data_ptr(), _stream()), "mg_flatfield_max")
+    return max2
+
+
+def flatfield_stitch(tiles: torch.Tensor, overlap: int, flatfield=1.0, darkfield=0.0, apply_flatfield=True,
+                     max2: torch.Tensor | None = None, want_minmax=True):
+    """tiles (C, T, R, Cc, ty, tx) -> image (C, T, R*hy, Cc*hx) and per-plane min/max (C*T, 2).
+
+    ``max2`` lets a multi-GPU caller supply all-reduced maxima."""
+    require_gpu()
+    if overlap < 0:
+        raise ValueError("Overlap must be non-negative.")
+    c, t, nr, nc, ty, tx = tiles.shape
+    if overlap >= ty or overlap >= tx:
+        raise ValueError(f"Overlap ({overlap}) must be smaller than tile size ({ty}x{tx}).")
+    tiles = tiles.contiguous()
+    clip, rem = overlap // 2, overlap % 2
+    hy, hx = ty - 2 * clip - rem, tx - 2 * clip - rem
+    dk, dkt, dkc = _df_operand(darkfield, ty, tx, tiles.device)
+    fl, flt, flc = _df_operand(flatfield, ty, tx, tiles.device)
+    if apply_flatfield and max2 is None:
+        max2 = flatfield_max(tiles, flatfield, darkfield)
+    image = torch.empty((c, t, nr * hy, nc * hx), dtype=tiles.dtype, device=tiles.device)
+    minmax = None
+    if want_minmax:
+        minmax = torch.empty((c * t, 2), dtype=torch.float64, device=tiles.device)
+        minmax[:, 0] = math.inf
+        minmax[:, 1] = -math.inf
+    nat.check(nat.lib().mg_flatfield_apply_stitch(tiles.data_ptr(), nat.dtype_code(tiles.dtype), c * t, nr, nc, ty, tx,
+                                                  overlap, int(bool(apply_flatfield)), dk, _ptr(dkt), dkc, fl,
+                                                  _ptr(flt), flc, _ptr(max2), image.data_ptr(), _ptr(minmax),
+                                                  _stream()), "mg_flatfield_apply_stitch")
+    return image, minmax
+
+
+def plane_minmax(planes: torch.Tensor) -> torch.Tensor:
+    """Per-plane (min, max) of a (P, H, W) view with uniform plane stride."""
+    require_gpu()
+    p, h, w = planes.shape
+    assert planes.stride(2) == 1 or w <= 1
+    out = torch.empty((p, 2), dtype=torch.float64, device=planes.device)
+    out[:, 0] = math.inf
+    out[:, 1] = -math.inf
+    nat.check(nat.lib().mg_plane_minmax(planes.data_ptr(), nat.dtype_code(planes.dtype), p, planes.stride(0), h, w,
+                                        planes.stride(1), out.data_ptr(), _stream()), "mg_plane_minmax")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# np.quantile on the float32 gradient magnitude, from the integer histogram
+# --------------------------------------------------------------------------------------
+
+
+def _grad_of(m: int) -> np.float32:
+    # utils.py:120: sqrt(dx**2 + dy**2) in float32; the float32 sum of two exact squares is the
+    # correctly rounded float32 of the integer m
+    return np.sqrt(np.float32(m))
+
+
+def quantile_indexes(n: int, q: float):
+    """Indexes and weight that numpy (2.x) uses for np.quantile(float32_array, q),
+    method 'linear': a Python-float q is cast to the array dtype, so the virtual index is
+    float32 arithmetic (numpy/lib/_function_base_impl.py: quantile, _compute_virtual_index,
+    _get_indexes, _get_gamma)."""
+    qf = np.float32(q)
+    vi = n * qf + (1 + qf * (1 - 1 - 1)) - 1  # float32 throughout
+    prev = np.floor(vi)
+    nxt = prev + 1
+    if vi >= n - 1:
+        prev_i = nxt_i = n - 1
+    elif vi < 0:
+        prev_i = nxt_i = 0
+    else:
+        prev_i, nxt_i = int(prev), int(nxt)
+    gamma = np.float32(vi - prev)
+    return prev_i, nxt_i, gamma
+
+
+def lerp_f32(a: np.float32, b: np.float32, t: np.float32) -> np.float32:
+    """numpy's _lerp in float32."""
+    diff = np.float32(b - a)
+    if t >= 0.5:
+        return np.float32(b - diff * np.float32(1 - t))
+    return np.float32(a + diff * t)
+
+
+def canny_int_thresholds(lo: float, hi: float):
+    """Threshold preparation of cv::Canny(dx, dy, t1, t2, L2gradient=true) (call site utils.py:128-134)."""
+    lo, hi = float(lo), float(hi)
+    if lo > hi:
+        lo, hi = hi, lo
+    lo, hi = min(32767.0, lo), min(32767.0, hi)
+    if lo > 0:
+        lo *= lo
+    if hi > 0:
+        hi *= hi
+    return int(math.floor(lo)), int(math.floor(hi))
+
+
+COARSE_SHIFT = 13
+COARSE_BINS = 4096  # covers m < 2**25 (max 2 * 4080**2 = 33 292 800)
+FINE_BINS = 1 << COARSE_SHIFT
+
+
+# --------------------------------------------------------------------------------------
+# find_circles, batched over planes
+# --------------------------------------------------------------------------------------
+
+
+class CircleFinder:
+    """``utils.find_circles`` (utils.py:102-222) for a batch of equally sized planes.
+
+    Workspace tensors are allocated once per (P, H, W, radii, num_iter) and reused.
+    After ``find`` the intermediate device tensors (``blur``, ``edges``, ``angle``,
+    ``coords`` ...) stay available for inspection by the parity tests.
+    """
+
+    def __init__(self, n_planes, h, w, min_radius, max_radius, num_iter, device="cuda", grid_length=GRID_LENGTH):
+        require_gpu()
+        if min_radius > max_radius:
+            raise ValueError("min_radius must be <= max_radius")
+        self.P, self.h, self.w = int(n_planes), int(h), int(w)
+        self.min_r, self.max_r, self.num_iter = int(min_radius), int(max_radius), int(num_iter)
+        self.grid = int(grid_length)
+        self.dev = torch.device(device)
+        P, dev = self.P, self.dev
+        self.gr, self.gc = math.ceil(h / self.grid), math.ceil(w / self.grid)
+        self.n_cells = self.gr * self.gc
+        i32, u8 = torch.int32, torch.uint8
+        self.blur = torch.empty((P, h, w), dtype=u8, device=dev)
+        self.edges = torch.empty((P, h, w), dtype=u8, device=dev)  # Canny map, then {0,1} edges
+        self.angle = torch.empty((P, h, w), dtype=torch.float32, device=dev)
+        self.hist = torch.zeros((P, FINE_BINS), dtype=i32, device=dev)
+        self.hist_base = torch.zeros((P,), dtype=i32, device=dev)
+        self.thresh = torch.zeros((P, 2), dtype=i32, device=dev)
+        self.changed = torch.zeros((P,), dtype=i32, device=dev)
+        self.cell_counts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
+        self.cell_starts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
+        self.num_edges = torch.zeros((P,), dtype=i32, device=dev)
+        self.coords = None
+        nr = self.max_r - self.min_r + 1
+        bits = nr * (h + 2 * self.max_r) * (w + 2 * self.max_r)
+        self.bitmap_words = (bits + 31) // 32
+        self.bitmap = torch.zeros((P, self.bitmap_words), dtype=i32, device=dev)
+        self.block_counts = torch.zeros((P, (self.bitmap_words + 1023) // 1024), dtype=i32, device=dev)
+        self.cap = max(1, min(self.num_iter, bits))
+        self.circles = torch.empty((P, self.cap, 3), dtype=i32, device=dev)
+        self.num_circles = torch.zeros((P,), dtype=i32, device=dev)
+        self.scores = torch.empty((P, self.cap), dtype=torch.float32, device=dev)
+        self.alive = torch.empty((P, self.cap), dtype=i32, device=dev)
+        self.num_alive = torch.zeros((P,), dtype=i32, device=dev)
+        self.max_rc = torch.zeros((P, 2), dtype=i32, device=dev)
+        self.state = torch.zeros((P, self.cap), dtype=u8, device=dev)
+        self.undecided = torch.zeros((P,), dtype=i32, device=dev)
+        per_rc, per_exp, per_starts = nat.perimeter_table(self.min_r, self.max_r)
+        self.per_rc = torch.from_numpy(per_rc).to(dev)
+        self.per_exp = torch.from_numpy(per_exp).to(dev)
+        self.per_starts = torch.from_numpy(per_starts).to(dev)
+        self.nms_grid = None
+        self.seeds = torch.zeros((P,), dtype=torch.int64, device=dev)
+        self.raw = None
+        self.stats = {}
+
+    # -- stage 1: to_uint8 + blur + Scharr/quantiles + Canny + hysteresis + edge grid --------
+    def edge_stage(self, planes: torch.Tensor, minmax, low_q: float, high_q: float, keep_u8=False,
+                   passthrough_u8=False):
+        L, P, h, w, s = nat.lib(), self.P, self.h, self.w, _stream()
+        assert tuple(planes.shape) == (P, h, w)
+        if planes.stride(2) != 1:
+            planes = planes.contiguous()
+        code = nat.dtype_code(planes.dtype)
+        if passthrough_u8:
+            if code != nat.MG_U8:
+                raise TypeError("passthrough_u8 needs uint8 planes")
+            minmax = None
+        elif minmax is None:
+            minmax = plane_minmax(planes)
+        self.u8 = torch.empty((P, h, w), dtype=torch.uint8, device=self.dev) if keep_u8 else None
+        nat.check(L.mg_to_uint8_blur(planes.data_ptr(), code, P, planes.stride(0), h, w, planes.stride(1),
+                                     _ptr(minmax), self.blur.data_ptr(), _ptr(self.u8), s), "mg_to_uint8_blur")
+        # coarse histogram of m = dx^2 + dy^2
+        self.hist.zero_()
+        nat.check(L.mg_scharr_hist(self.blur.data_ptr(), P, h, w, 0, COARSE_SHIFT, COARSE_BINS, self.hist.data_ptr(), s),
+                  "mg_scharr_hist")
+        # NB: rows of self.hist are FINE_BINS wide; the coarse pass used the first COARSE_BINS of a
+        # COARSE_BINS-strided view, so read it back through the same flat layout.
+        flat = self.hist.view(-1)[: P * COARSE_BINS].view(P, COARSE_BINS)
+        ccum = torch.cumsum(flat.to(torch.int64), dim=1).cpu().numpy()
+        n = h * w
+        want = []  # per plane: the order-statistic ranks needed
+        for q in (low_q, high_q):
+            a, b, _ = quantile_indexes(n, q)
+            want += [a, b]
+        ranks = sorted(set(want))
+        # coarse bin of every needed rank, per plane
+        bins = np.stack([np.array([np.searchsorted(ccum[p], r, side="right") for r in ranks]) for p in range(P)])
+        order_stat = np.zeros((P, len(ranks)), dtype=np.int64)
+        todo = [sorted(set(bins[p].tolist())) for p in range(P)]
+        n_pass = max(len(t) for t in todo)
+        for k in range(n_pass):
+            base_bins = np.array([t[min(k, len(t) - 1)] for t in todo], dtype=np.int64)
+            self.hist_base.copy_(torch.from_numpy((base_bins << COARSE_SHIFT).astype(np.int32)))
+            self.hist.zero_()
+            nat.check(L.mg_scharr_hist(self.blur.data_ptr(), P, h, w, self.hist_base.data_ptr(), 0, FINE_BINS,
+                                       self.hist.data_ptr(), s), "mg_scharr_hist")
+            fcum = torch.cumsum(self.hist.to(torch.int64), dim=1).cpu().numpy()
+            for p in range(P):
+                b = base_bins[p]
+                below = ccum[p, b - 1] if b > 0 else 0
+                for j, r in enumerate(ranks):
+                    if bins[p, j] == b:
+                        order_stat[p, j] = (b << COARSE_SHIFT) + np.searchsorted(fcum[p], r - below, side="right")
+        thresh = np.zeros((P, 2), dtype=np.int32)
+        self.quantiles = np.zeros((P, 2), dtype=np.float32)
+        for p in range(P):
+            vals = []
+            for q in (low_q, high_q):
+                a, b, gamma = quantile_indexes(n, q)
+                ga = _grad_of(int(order_stat[p, ranks.index(a)]))
+                gb = _grad_of(int(order_stat[p, ranks.index(b)]))
+                vals.append(lerp_f32(ga, gb, gamma))
+            self.quantiles[p] = vals
+            thresh[p] = canny_int_thresholds(vals[0], vals[1])
+        self.thresh.copy_(torch.from_numpy(thresh))
+        nat.check(L.mg_canny_nms(self.blur.data_ptr(), P, h, w, self.thresh.data_ptr(), self.edges.data_ptr(), s),
+                  "mg_canny_nms")
+        sweeps = 0
+        while True:
+            self.changed.zero_()
+            nat.check(L.mg_canny_hysteresis(self.edges.data_ptr(), P, h, w, self.changed.data_ptr(), s),
+                      "mg_canny_hysteresis")
+            sweeps += 1
+            if int(self.changed.sum().item()) == 0:
+                break
+        self.stats["hysteresis_sweeps"] = sweeps
+        self.cell_counts.zero_()
+        nat.check(L.mg_edges_finalize(self.edges.data_ptr(), self.blur.data_ptr(), P, h, w, self.grid,
+                                      self.angle.data_ptr(), self.cell_counts.data_ptr(), s), "mg_edges_finalize")
+        n_edges = self.cell_counts.sum(dim=1).cpu().numpy()
+        self.coord_cap = max(1, int(n_edges.max()))
+        self.coords = torch.empty((P, self.coord_cap, 2), dtype=torch.int32, device=self.dev)
+        nat.check(L.mg_edge_grid(self.edges.data_ptr(), P, h, w, self.grid, self.cell_counts.data_ptr(),
+                                 self.cell_starts.data_ptr(), self.num_edges.data_ptr(), self.coords.data_ptr(),
+                                 self.coord_cap, s), "mg_edge_grid")
+        self.n_edges_host = n_edges
+        return n_edges
+
+    # -- stage 2: candidates -> unique integer circles -> scores ------------------------------
+    def circle_stage(self, seeds, min_roundness: float, keep_raw=False):
+        L, P, h, w, s = nat.lib(), self.P, self.h, self.w, _stream()
+        seeds = np.asarray(seeds, dtype=np.uint64).reshape(P)
+        self.seeds.copy_(torch.from_numpy(seeds.view(np.int64)))
+        self.raw = torch.empty((P, self.num_iter, 3), dtype=torch.float32, device=self.dev) if keep_raw else None
+        nat.check(L.mg_candidate_circles(self.coords.data_ptr(), self.coord_cap, self.cell_starts.data_ptr(),
+                                         self.cell_counts.data_ptr(), self.num_edges.data_ptr(), P, h, w, self.grid,
+                                         self.seeds.data_ptr(), self.num_iter, self.min_r, self.max_r,
+                                         self.bitmap.data_ptr(), self.bitmap_words, _ptr(self.raw), s),
+                  "mg_candidate_circles")
+        nat.check(L.mg_bitmap_to_circles(self.bitmap.data_ptr(), self.bitmap_words, P, h, w, self.min_r, self.max_r,
+                                         self.block_counts.data_ptr(), self.circles.data_ptr(), self.cap,
+                                         self.num_circles.data_ptr(), s), "mg_bitmap_to_circles")
+        self.num_alive.zero_()
+        self.max_rc.fill_(-(2**31))
+        nat.check(L.mg_score_circles(self.angle.data_ptr(), P, h, w, self.circles.data_ptr(), self.cap,
+                                     self.num_circles.data_ptr(), self.min_r, self.max_r, self.per_rc.data_ptr(),
+                                     self.per_exp.data_ptr(), self.per_starts.data_ptr(), float(min_roundness),
+                                     self.scores.data_ptr(), self.alive.data_ptr(), self.num_alive.data_ptr(),
+                                     self.max_rc.data_ptr(), s), "mg_score_circles")
+
+    # -- stage 3: greedy suppression + ordered output -------------------------------------------
+    def nms_stage(self, min_dist: int):
+        L, P, s = nat.lib(), self.P, _stream()
+        n_alive = self.num_alive.cpu().numpy()
+        out_cap = max(1, int(n_alive.max()))
+        rounds = 0
+        if min_dist > 0 and n_alive.max() > 0:
+            pad = 2 * min_dist + 1
+            grid_cap = (self.h + self.max_r + 2 * pad) * (self.w + self.max_r + 2 * pad)
+            if self.nms_grid is None or self.nms_grid.shape[1] < grid_cap:
+                self.nms_grid = torch.empty((P, grid_cap), dtype=torch.int64, device=self.dev)
+            self.nms_grid.fill_(-1)
+            self.state.zero_()
+            ring = torch.from_numpy(nat.circle_points(min_dist, True)).to(self.dev)
+            while True:
+                nat.check(L.mg_nms_round(self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
+                                         self.alive.data_ptr(), self.num_alive.data_ptr(), self.max_rc.data_ptr(), P,
+                                         min_dist, ring.data_ptr(), ring.shape[0], self.nms_grid.data_ptr(),
+                                         self.nms_grid.shape[1], self.state.data_ptr(), self.undecided.data_ptr(), s),
+                          "mg_nms_round")
+                rounds += 1
+                if int(self.undecided.sum().item()) == 0:
+                    break
+                if rounds > 10000:
+                    raise RuntimeError("greedy suppression did not converge")
+        self.stats["nms_rounds"] = rounds
+        out = torch.empty((P, out_cap, 3), dtype=torch.int32, device=self.dev)
+        out_scores = torch.empty((P, out_cap), dtype=torch.float32, device=self.dev)
+        scratch = torch.empty((P, out_cap), dtype=torch.int32, device=self.dev)
+        num_out = torch.zeros((P,), dtype=torch.int32, device=self.dev)
+        nat.check(L.mg_collect_circles(self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
+                                       self.num_alive.data_ptr(), self.state.data_ptr(), int(min_dist <= 0), P,
+                                       out.data_ptr(), out_scores.data_ptr(), out_cap, num_out.data_ptr(),
+                                       scratch.data_ptr(), s), "mg_collect_circles")
+        return out, out_scores, num_out
+
+    def find(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw=False, keep_u8=False,
+             passthrough_u8=False):
+        """Returns per-plane lists (circles int32 (M,3) [row, col, r], scores float32 (M,)) on the
+        host plus the device tensors (out, out_scores, num_out)."""
+        n_edges = self.edge_stage(planes, minmax, low_q, high_q, keep_u8=keep_u8, passthrough_u8=passthrough_u8)
+        self.circle_stage(seeds, min_roundness, keep_raw=keep_raw)
+        out, out_scores, num_out = self.nms_stage(min_dist)
+        counts = num_out.cpu().numpy()
+        out_h, sc_h = out.cpu().numpy(), out_scores.cpu().numpy()
+        res = [(out_h[p, : counts[p]].copy(), sc_h[p, : counts[p]].copy()) for p in range(self.P)]
+        self.stats["n_edges"] = n_edges
+        return res, (out, out_scores, num_out)
+
+
+# --------------------------------------------------------------------------------------
+# A12-A15, A18: labels, ROI gather, masks, reductions
+# --------------------------------------------------------------------------------------
+
+_HALF_CACHE = {}
+
+
+def _halfwidth_table(max_r: int, device):
+    key = (max_r, str(device))
+    if key not in _HALF_CACHE:
+        tab = np.full((max_r + 1, 2 * max_r + 1), -1, dtype=np.int32)
+        for r in range(2, max_r + 1):
+            tab[r, : 2 * r + 1] = nat.disk_halfwidths(r)
+        _HALF_CACHE[key] = torch.from_numpy(tab).to(device)
+    return _HALF_CACHE[key]
+
+
+def circle_labels(beads_per_assay, h, w, device="cuda"):
+    """utils.circle_labels (utils.py:380-395) for a list of (M_a, 3) int bead arrays.
+    Returns labels (A, h, w) int32 on the device."""
+    require_gpu()
+    a = len(beads_per_assay)
+    cap = max(1, max((len(b) for b in beads_per_assay), default=1))
+    host = np.zeros((a, cap, 3), dtype=np.int32)
+    counts = np.zeros(a, dtype=np.int32)
+    max_r = 2
+    for k, b in enumerate(beads_per_assay):
+        b = np.asarray(b).reshape(-1, 3)
+        host[k, : len(b)] = b
+        counts[k] = len(b)
+        if len(b):
+            max_r = max(max_r, int(b[:, 2].max()))
+    labels = torch.full((a, h, w), -1, dtype=torch.int32, device=device)
+    d_beads = torch.from_numpy(host).to(device)
+    d_counts = torch.from_numpy(counts).to(device)
+    tab = _halfwidth_table(max_r, device)
+    nat.check(nat.lib().mg_circle_labels(d_beads.data_ptr(), cap, d_counts.data_ptr(), a, h, w, tab.data_ptr(), max_r,
+                                         labels.data_ptr(), _stream()), "mg_circle_labels")
+    return labels
+
+
+def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, labels: torch.Tensor | None,
+                      want_roi=True, want_masks=True, want_sums=True):
+    """images (A, C, T, h, w); centers_per_assay: list of (M_a, >=2) int arrays [row, col, ...].
+
+    Returns dict: roi (M, C, T, L, L), fg/bg (M, L, L) uint8, sums (M, C, T, 2) float64
+    [fg sum, bg sum], counts (M, 2) int32, offsets (A+1,) numpy."""
+    require_gpu()
+    a, c, t, h, w = images.shape
+    images = images.contiguous()
+    dev = images.device
+    sizes = [len(b) for b in centers_per_assay]
+    m = int(sum(sizes))
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    res = {"offsets": offsets}
+    L = int(roi_len)
+    res["roi"] = torch.empty((m, c, t, L, L), dtype=images.dtype, device=dev) if want_roi else None
+    res["fg"] = torch.empty((m, L, L), dtype=torch.uint8, device=dev) if want_masks else None
+    res["bg"] = torch.empty((m, L, L), dtype=torch.uint8, device=dev) if want_masks else None
+    res["sums"] = torch.empty((m, c, t, 2), dtype=torch.float64, device=dev) if want_sums else None
+    res["counts"] = torch.empty((m, 2), dtype=torch.int32, device=dev) if want_sums else None
+    if m == 0:
+        return res
+    beads = np.zeros((m, 3), dtype=np.int32)
+    assay = np.zeros(m, dtype=np.int32)
+    local = np.zeros(m, dtype=np.int32)
+    for k, b in enumerate(centers_per_assay):
+        b = np.asarray(b)
+        lo, hi = offsets[k], offsets[k + 1]
+        if hi > lo:
+            beads[lo:hi, :2] = b[:, :2]
+            assay[lo:hi] = k
+            local[lo:hi] = np.arange(hi - lo)
+    d_beads = torch.from_numpy(beads).to(dev)
+    d_assay = torch.from_numpy(assay).to(dev)
+    d_local = torch.from_numpy(local).to(dev)
+    nat.check(nat.lib().mg_roi_gather_reduce_batched(
+        images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w, d_beads.data_ptr(),
+        d_assay.data_ptr(), d_local.data_ptr(), m, L, _ptr(labels), _ptr(res["roi"]), _ptr(res["fg"]),
+        _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream()), "mg_roi_gather_reduce_batched")
+    return res
+
+
+def masked_median_u16(roi: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """nanmedian of roi (M, C, T, L, L) uint16 under mask (M, L, L) -> (M, C, T) float64."""
+    require_gpu()
+    m, c, t, L, _ = roi.shape
+    out = torch.empty((m, c, t), dtype=torch.float64, device=roi.device)
+    nat.check(nat.lib().mg_roi_masked_median_u16(roi.contiguous().data_ptr(), mask.contiguous().data_ptr(), m, c, t, L,
+                                                 out.data_ptr(), _stream()), "mg_roi_masked_median_u16")
+    return out

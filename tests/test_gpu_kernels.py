@@ -1,0 +1,368 @@
+"""Stage-wise parity of the HIP kernels (through the C ABI) against the CPU oracle.
+
+Bit-exact for every integer/byte/index stage.  Floating point: the float32 gradient angle is
+compared within 2 ulp (the reference's np.arctan2(float32) is platform-dependent in its last
+bits), scores within 1 float32 ulp when fed identical angles (perimeter angle table: libm vs
+NumPy-SIMD atan2 differ in the last float64 bit).
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_numeric as rn
+from oracle import ref_opencv as rcv
+from oracle import ref_pipeline as rp
+from synth import draw_beads, noisy_bead_image, vignette
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def hp():
+    from magnify_amd import hotpath
+
+    hotpath.require_gpu()  # fails loudly if the HIP library or the GPU is missing
+    return hotpath
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def ulp_diff_f32(a, b):
+    ia = a.view(np.int32).astype(np.int64)
+    ib = b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+# ---------------------------------------------------------------------------------------------
+# A1 / A2
+# ---------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("overlap", [0, 5, 8])
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32, np.float64, np.uint8])
+def test_stitch_copy(hp, overlap, dtype):
+    rng = np.random.default_rng(1)
+    shape = (2, 3, 2, 3, 40, 48)
+    tiles = (rng.random(shape) * 200).astype(dtype)
+    img, _ = hp.flatfield_stitch(dev(tiles), overlap, apply_flatfield=False, want_minmax=False)
+    np.testing.assert_array_equal(img.cpu().numpy(), rp.stitch(tiles, overlap))
+
+
+def test_stitch_reference_assertions(hp):
+    # tests/test_stitch.py:9-26 (basic), :28-45 (single tile), :78-96 (zero overlap)
+    rng = np.random.default_rng(2)
+    t = rng.random((1, 1, 2, 3, 40, 40))
+    img = hp.flatfield_stitch(dev(t), 5, apply_flatfield=False, want_minmax=False)[0].cpu().numpy()
+    assert img.shape[-2:] == (2 * 35, 3 * 35)
+    np.testing.assert_array_equal(img[0, 0, 35:70, 35:70], t[0, 0, 1, 1, 2:37, 2:37])
+    t = rng.random((1, 1, 1, 1, 30, 30))
+    img = hp.flatfield_stitch(dev(t), 5, apply_flatfield=False, want_minmax=False)[0].cpu().numpy()
+    np.testing.assert_array_equal(img[0, 0], t[0, 0, 0, 0, 2:27, 2:27])
+    t = rng.random((1, 1, 1, 2, 20, 20))
+    img = hp.flatfield_stitch(dev(t), 0, apply_flatfield=False, want_minmax=False)[0].cpu().numpy()
+    np.testing.assert_array_equal(img[0, 0, :, :20], t[0, 0, 0, 0])
+    np.testing.assert_array_equal(img[0, 0, :, 20:], t[0, 0, 0, 1])
+    with pytest.raises(ValueError):
+        hp.flatfield_stitch(dev(t), -5)
+    with pytest.raises(ValueError):
+        hp.flatfield_stitch(dev(rng.random((1, 1, 2, 2, 50, 50))), 100)
+
+
+@pytest.mark.parametrize("case", ["scalar", "image", "image64", "default"])
+def test_flatfield_u16(hp, case):
+    rng = np.random.default_rng(3)
+    tiles = rng.integers(90, 4000, size=(2, 2, 2, 2, 64, 72), dtype=np.uint16)
+    if case == "scalar":
+        flat, dark = 0.8, 100.0
+    elif case == "image":
+        flat, dark = vignette((64, 72)), 100.0
+    elif case == "image64":
+        flat, dark = vignette((64, 72), dtype=np.float64), rng.integers(80, 120, size=(64, 72)).astype(np.uint16)
+    else:
+        flat, dark = 1.0, 0.0
+    for overlap in (0, 7):
+        img, minmax = hp.flatfield_stitch(dev(tiles), overlap, flat, dark)
+        want = rp.stitch(rp.flatfield_correct(tiles, flat, dark), overlap)
+        got = img.cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+        mm = minmax.cpu().numpy().reshape(2, 2, 2)
+        np.testing.assert_array_equal(mm[..., 0], want.min(axis=(-1, -2)))
+        np.testing.assert_array_equal(mm[..., 1], want.max(axis=(-1, -2)))
+
+
+def test_flatfield_f32_and_ragged(hp):
+    rng = np.random.default_rng(4)
+    tiles = rng.normal(1000, 200, size=(1, 2, 1, 1, 33, 47)).astype(np.float32)
+    img, _ = hp.flatfield_stitch(dev(tiles), 0, vignette((33, 47)), 50.0)
+    np.testing.assert_array_equal(img.cpu().numpy(), rp.stitch(rp.flatfield_correct(tiles, vignette((33, 47)), 50.0), 0))
+    t16 = rng.integers(0, 65536, size=(1, 1, 1, 1, 31, 45), dtype=np.uint16)  # odd sizes: unaligned rows
+    img, _ = hp.flatfield_stitch(dev(t16), 3, 0.9, 10.0)
+    np.testing.assert_array_equal(img.cpu().numpy(), rp.stitch(rp.flatfield_correct(t16, 0.9, 10.0), 3))
+
+
+# ---------------------------------------------------------------------------------------------
+# A3 / A4: to_uint8 + blur
+# ---------------------------------------------------------------------------------------------
+
+
+def _blur_case(hp, planes, passthrough=False):
+    p, h, w = planes.shape
+    cf = hp.CircleFinder(p, h, w, 5, 8, 10)
+    d = dev(planes)
+    mm = None if passthrough else hp.plane_minmax(d)
+    cf.u8 = torch.empty((p, h, w), dtype=torch.uint8, device="cuda")
+    from magnify_amd import _native as nat
+
+    nat.check(nat.lib().mg_to_uint8_blur(d.data_ptr(), nat.dtype_code(d.dtype), p, d.stride(0), h, w, d.stride(1),
+                                         0 if mm is None else mm.data_ptr(), cf.blur.data_ptr(), cf.u8.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "blur")
+    return cf.u8.cpu().numpy(), cf.blur.cpu().numpy()
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32, np.float64, np.uint8])
+@pytest.mark.parametrize("shape", [(3, 97, 113), (1, 200, 300), (2, 3, 5), (1, 1, 7), (1, 33, 1), (1, 2, 2)])
+def test_to_uint8_blur(hp, dtype, shape):
+    rng = np.random.default_rng(5)
+    if np.issubdtype(dtype, np.integer):
+        planes = rng.integers(0, np.iinfo(dtype).max // 3, size=shape).astype(dtype)
+    else:
+        planes = rng.normal(500, 100, size=shape).astype(dtype)
+    u8, blur = _blur_case(hp, planes)
+    for k in range(shape[0]):
+        want = rn.to_uint8(planes[k])
+        np.testing.assert_array_equal(u8[k], want)
+        np.testing.assert_array_equal(blur[k], rcv.gaussian_blur5(want))
+
+
+def test_to_uint8_golden_and_constant(hp, golden):
+    g = golden("to_uint8")
+    for key in ("a16", "a16n", "af32", "af64", "const"):
+        u8, _ = _blur_case(hp, g[key][None])
+        np.testing.assert_array_equal(u8[0], g[key + "_out"])
+    planes = np.random.default_rng(6).integers(0, 256, size=(2, 40, 50), dtype=np.uint8)
+    u8, blur = _blur_case(hp, planes, passthrough=True)
+    np.testing.assert_array_equal(u8, planes)
+    np.testing.assert_array_equal(blur[1], rcv.gaussian_blur5(planes[1]))
+
+
+# ---------------------------------------------------------------------------------------------
+# A5-A7: edges
+# ---------------------------------------------------------------------------------------------
+
+
+def _edge_images():
+    imgs = [noisy_bead_image(7, (300, 420), 12, r_lo=6, r_hi=14)[0],
+            draw_beads((300, 420), [[60, 60], [150, 200], [250, 380], [5, 300]], 20),
+            noisy_bead_image(8, (300, 420), 6, poisson=400.0, read_noise=30.0)[0]]
+    return np.stack(imgs)
+
+
+@pytest.mark.parametrize("quantiles", [(0.1, 0.9), (0.5, 0.99), (0.9, 0.1)])
+def test_edge_stage(hp, quantiles):
+    planes = _edge_images()
+    p, h, w = planes.shape
+    cf = hp.CircleFinder(p, h, w, 5, 14, 1000)
+    n_edges = cf.edge_stage(dev(planes), None, *quantiles)
+    edges = cf.edges.cpu().numpy()
+    angle = cf.angle.cpu().numpy()
+    counts, starts = cf.cell_counts.cpu().numpy(), cf.cell_starts.cpu().numpy()
+    coords = cf.coords.cpu().numpy()
+    for k in range(p):
+        u8 = rn.to_uint8(planes[k])
+        blur, dx, dy, want_edges, (lo, hi) = rp.edge_stage(u8, *quantiles)
+        np.testing.assert_array_equal(cf.blur[k].cpu().numpy(), blur)
+        assert (np.float32(lo), np.float32(hi)) == tuple(cf.quantiles[k])
+        assert tuple(cf.thresh[k].cpu().numpy()) == rcv.canny_thresholds(lo, hi)
+        np.testing.assert_array_equal(edges[k], want_edges)
+        assert n_edges[k] == want_edges.sum()
+        # angle map: sentinel off-edge; on edges the correctly rounded float32 arctan2, which is
+        # within 2 ulp of NumPy's SIMD float32 arctan2 (itself not correctly rounded: e.g.
+        # arctan2(-1, 1) comes out 1 ulp above float32(-pi/4) on AVX-512 hosts)
+        on = want_edges > 0
+        assert (angle[k][~on] == np.float32(100.0)).all()
+        want_angle = np.arctan2(dy, dx)
+        assert ulp_diff_f32(angle[k][on], want_angle[on]).max() <= 2
+        exact64 = np.arctan2(dy.astype(np.float64), dx.astype(np.float64)).astype(np.float32)
+        assert (angle[k][on] == exact64[on]).mean() > 0.9999
+        gcoords, gstarts, gcounts = rn.grid_array(want_edges, 20)
+        np.testing.assert_array_equal(counts[k].reshape(gcounts.shape), gcounts)
+        np.testing.assert_array_equal(starts[k].reshape(gstarts.shape), gstarts)
+        np.testing.assert_array_equal(coords[k, : len(gcoords)], gcoords)
+
+
+def test_edge_stage_empty_and_tiny(hp):
+    planes = np.zeros((2, 64, 64), dtype=np.uint16)
+    planes[1, 30:34, 30:34] = 500
+    cf = hp.CircleFinder(2, 64, 64, 5, 8, 100)
+    n_edges = cf.edge_stage(dev(planes), None, 0.1, 0.9)
+    for k in range(2):
+        _, _, _, want, _ = rp.edge_stage(rn.to_uint8(planes[k]), 0.1, 0.9)
+        np.testing.assert_array_equal(cf.edges[k].cpu().numpy(), want)
+    assert n_edges[0] == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# A8-A11: candidates, unique circles, scores, suppression
+# ---------------------------------------------------------------------------------------------
+
+
+def test_candidates_scores_nms(hp):
+    planes = _edge_images()
+    p, h, w = planes.shape
+    min_r, max_r, num_iter, min_dist = 5, 14, 20000, 5
+    cf = hp.CircleFinder(p, h, w, min_r, max_r, num_iter)
+    seeds = [11, 12, 13]
+    res, _ = cf.find(dev(planes), None, 0.1, 0.9, 0.3, min_dist, seeds, keep_raw=True)
+    raw = cf.raw.cpu().numpy()
+    circles = cf.circles.cpu().numpy()
+    n_circles = cf.num_circles.cpu().numpy()
+    scores = cf.scores.cpu().numpy()
+    angle = cf.angle.cpu().numpy()
+    assert cf.bitmap.count_nonzero().item() == 0  # the compaction leaves the bitmap clean
+    for k in range(p):
+        u8 = rn.to_uint8(planes[k])
+        _, dx, dy, edges, _ = rp.edge_stage(u8, 0.1, 0.9)
+        picks = rn.draw_picks(seeds[k], num_iter, edges, 20)
+        cand = rn.candidate_circles_from_picks(edges, 20, *picks)
+        np.testing.assert_array_equal(raw[k].view(np.uint32), cand.view(np.uint32))  # bit-exact incl. NaN/inf
+        # step 4 + de-duplication + (r, row, col) order
+        with np.errstate(invalid="ignore"):
+            c = cand[(cand[:, 2] >= min_r) & (cand[:, 2] <= max_r)]
+            c = np.round(c).astype(np.int32)
+        c = c[(c[:, 0] + c[:, 2] >= 0) & (c[:, 1] + c[:, 2] >= 0) & (c[:, 0] - c[:, 2] < h) & (c[:, 1] - c[:, 2] < w)]
+        c = np.unique(c, axis=0)
+        c = c[np.lexsort((c[:, 1], c[:, 0], c[:, 2]))]
+        assert n_circles[k] == len(c)
+        np.testing.assert_array_equal(circles[k, : len(c)], c)
+        # scores, given the GPU's own angle map as the oracle's grad_angles
+        ang = np.where(edges > 0, angle[k], 0).astype(np.float32)
+        pad = 2 * max_r
+        pa, pe = np.pad(ang, pad), np.pad(edges, pad)
+        want_scores = np.empty(len(c), dtype=np.float32)
+        for r in range(min_r, max_r + 1):
+            sel = c[:, 2] == r
+            per = rn.circle_points(r)
+            want_scores[sel] = rn.mean_grad(pa, pe, c[sel, :2] + pad, per) / len(per)
+        got = scores[k, : len(c)]
+        assert ulp_diff_f32(got, want_scores).max() <= 1
+        assert (got == want_scores).mean() > 0.999
+        # suppression, given the GPU's scores
+        good = got >= np.float32(0.3)
+        cc, ss = c[good], got[good]
+        perm = rn.canonical_order(cc, ss)
+        cc, ss = cc[perm], ss[perm]
+        keep = rn.filter_neighbors(cc, min_dist)
+        np.testing.assert_array_equal(res[k][0], cc[keep])
+        np.testing.assert_array_equal(res[k][1], ss[keep])
+        assert len(res[k][0]) >= (4 if k < 2 else 1)
+        # and the whole thing against the oracle's find_circles (same RNG stream, GPU angles)
+        oc, osc = rp.find_circles(u8, 0.1, 0.9, 20, num_iter, min_r, max_r, 0.3, min_dist, seed=seeds[k],
+                                  grad_angles=ang)
+        np.testing.assert_array_equal(res[k][0], oc)
+        assert ulp_diff_f32(res[k][1], osc).max() <= 1
+
+
+def test_nms_golden_and_wrap(hp, golden):
+    """filter_neighbors golden cases (reference output, incl. negative-index wrap) through the
+    GPU suppression: feed circles with strictly decreasing scores."""
+    from magnify_amd import _native as nat
+
+    g = golden("filter_neighbors")
+    for case in range(4):
+        c = g[f"circles_{case}"].astype(np.int32)
+        min_dist = int(g[f"min_dist_{case}"])
+        n = len(c)
+        cf = hp.CircleFinder(1, 400, 400, 5, 25, n)
+        cf.circles[0, :n] = dev(c)
+        cf.num_circles[0] = n
+        cf.scores[0, :n] = dev(np.linspace(1.0, 0.5, n).astype(np.float32))
+        cf.alive[0, :n] = dev(np.random.default_rng(case).permutation(n).astype(np.int32))
+        cf.num_alive[0] = n
+        cf.max_rc[0] = dev(np.array([c[:, 0].max(), c[:, 1].max()], dtype=np.int32))
+        out, out_scores, num_out = cf.nms_stage(min_dist)
+        m = int(num_out[0].item())
+        want = c[g[f"valid_{case}"]]
+        assert m == len(want)
+        np.testing.assert_array_equal(out[0, :m].cpu().numpy(), want)
+
+
+def test_find_circles_empty(hp):
+    planes = np.zeros((1, 128, 128), dtype=np.uint16)
+    cf = hp.CircleFinder(1, 128, 128, 8, 12, 1000)
+    res, _ = cf.find(dev(planes), None, 0.1, 0.9, 0.3, 8, [5])
+    assert res[0][0].shape == (0, 3)
+
+
+def test_find_circles_no_suppression(hp):
+    """min_dist == 0 (per-chamber refinement, find.py:352): all scored circles, priority order."""
+    img = draw_beads((72, 72), [[36, 36]], 20)
+    cf = hp.CircleFinder(1, 72, 72, 4, 15, 400)
+    res, _ = cf.find(dev(img[None]), None, 0.1, 0.99, 0.2, 0, [9])
+    u8 = rn.to_uint8(img)
+    ang = np.where(cf.edges[0].cpu().numpy() > 0, cf.angle[0].cpu().numpy(), 0).astype(np.float32)
+    oc, osc = rp.find_circles(u8, 0.1, 0.99, 20, 400, 4, 15, 0.2, 0, seed=9, grad_angles=ang)
+    np.testing.assert_array_equal(res[0][0], oc)
+    assert len(oc) > 0 and abs(int(oc[0][0]) - 36) <= 1 and abs(int(oc[0][2]) - 10) <= 1
+
+
+# ---------------------------------------------------------------------------------------------
+# A12-A15, A18: labels, ROI, reductions
+# ---------------------------------------------------------------------------------------------
+
+
+def test_circle_labels(hp, golden):
+    g = golden("circle_labels")
+    h, w = (int(v) for v in g["shape"])
+    beads = g["beads"]
+    ok = beads[:, 2] >= 2
+    lab = hp.circle_labels([beads[ok]], h, w)[0].cpu().numpy()
+    np.testing.assert_array_equal(lab, rn.circle_labels(beads[ok], h, w))
+    if ok.all():
+        np.testing.assert_array_equal(lab, g["labels"])
+    # two assays at once, one empty
+    labs = hp.circle_labels([beads[ok][:5], np.empty((0, 3), int)], h, w).cpu().numpy()
+    np.testing.assert_array_equal(labs[0], rn.circle_labels(beads[ok][:5], h, w))
+    assert (labs[1] == -1).all()
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_roi_gather_reduce(hp, dtype):
+    rng = np.random.default_rng(21)
+    c, t, h, w, L = 3, 2, 160, 200, 40
+    image = rng.integers(0, 4000, size=(c, t, h, w)).astype(dtype)
+    beads = np.array([[20, 20, 8], [5, 190, 6], [150, 100, 10], [80, 80, 9], [84, 92, 9], [159, 0, 5]])
+    labels = hp.circle_labels([beads], h, w)
+    res = hp.roi_gather_reduce(dev(image)[None], [beads], L, labels)
+    lab = rn.circle_labels(beads, h, w)
+    m = len(beads)
+    roi = np.zeros((m, c, t, L, L), dtype=dtype)
+    fg = np.zeros((m, t, L, L), dtype=bool)
+    bg = np.zeros_like(fg)
+    for i, (row, col, _) in enumerate(beads):
+        top, bottom, left, right = rn.bounding_box(int(col), int(row), L, w, h)
+        roi[i] = image[:, :, top:bottom, left:right]
+        fg[i] = (lab[top:bottom, left:right] == i)[None]
+        bg[i] = (lab[top:bottom, left:right] == -1)[None]
+    np.testing.assert_array_equal(res["roi"].cpu().numpy(), roi)
+    np.testing.assert_array_equal(res["fg"].cpu().numpy().astype(bool), fg[:, 0])
+    np.testing.assert_array_equal(res["bg"].cpu().numpy().astype(bool), bg[:, 0])
+    red = rp.roi_reduce(roi, fg, bg)
+    counts = res["counts"].cpu().numpy()
+    np.testing.assert_array_equal(counts[:, 0], red["fg_count"][:, 0])
+    np.testing.assert_array_equal(counts[:, 1], red["bg_count"][:, 0])
+    sums = res["sums"].cpu().numpy()
+    if dtype == np.uint16:
+        np.testing.assert_array_equal(sums[..., 0], red["fg_sum"])  # exact integer sums
+        np.testing.assert_array_equal(sums[..., 1], red["bg_sum"])
+        med = hp.masked_median_u16(res["roi"], res["fg"]).cpu().numpy()
+        np.testing.assert_array_equal(med, red["fg_median"])
+        med = hp.masked_median_u16(res["roi"], res["bg"]).cpu().numpy()
+        np.testing.assert_array_equal(med, red["bg_median"])
+    else:
+        np.testing.assert_allclose(sums[..., 0], red["fg_sum"], rtol=1e-12)  # float64 sums, other order
+        np.testing.assert_allclose(sums[..., 1], red["bg_sum"], rtol=1e-12)
