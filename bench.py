@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the marker-detection hot path on MI355X.
+
+One "step" = one pass of flat-field + stitch -> bead detection -> fg/bg segmentation -> per-ROI
+reduction over one synthetic (T x C x H x W) uint16 stack that is already resident in HBM.
+Workload at N=1: BASELINE.json's 64 x 4 x 4096 x 4096 stack (C4), per-timepoint detection (mode P),
+search channel 0, the reference's default 5 000 000 RANSAC iterations per searched plane.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own block of
+timepoints of the same size (weak scaling), runs the chain locally and all-gathers the final marker
+table over RCCL.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def algorithmic_bytes(stage, p):
+    """Algorithmic HBM bytes of ONE launch of a stage (DESIGN.md 'Kernels'); p = workload numbers."""
+    n, planes, c = p["h"] * p["w"], p["search_planes"], p["n_c"]
+    table = {
+        "mg_flatfield_max": 2 * c * n,                      # one assay (C planes) per launch: read u16
+        "mg_flatfield_apply_stitch": 4 * c * n,             # read u16 + write u16
+        "mg_to_uint8_blur": 3 * planes * n,                 # read u16, write blurred u8
+        "mg_scharr_hist": 1 * planes * n,                   # read u8
+        "mg_canny_nms": 2 * planes * n,                     # read u8, write map u8
+        "mg_canny_hysteresis": 2 * planes * n,              # read + write map (per sweep)
+        "mg_edges_finalize": 6 * planes * n,                # map r/w + float32 angle map write
+        "mg_edge_grid": 1 * planes * n + 8 * p["edges"],    # read edges, write coords
+        "mg_candidate_circles": 28 * planes * p["num_iter"],  # 3 coordinate reads (8 B) + bitmap word
+        "mg_bitmap_to_circles": 2 * 4 * p["bitmap_words"] * planes + 12 * p["unique"],
+        "mg_score_circles": p["unique"] * (12 + 4 * p["mean_perimeter"] + 4),
+        "mg_nms_round": p["alive"] * p["ring_len"] * 16,
+        "mg_collect_circles": p["alive"] * 4 + p["markers"] * 16,
+        "mg_circle_labels": p["markers"] * p["mean_disk"] * 8,
+        "mg_roi_gather_reduce_batched": p["markers"] * p["L"] ** 2 * (4 * c + 6),
+        "mg_plane_minmax": 2 * planes * n,
+    }
+    return table.get(stage)
+
+
+def cpu_baseline(args, flat_np):
+    """The oracle (a CPU restatement of the reference path, kind 'port') timed on this host on a
+    bounded sample of the same workload: ONE timepoint of C channels at (cpu_size x cpu_size) with
+    the RANSAC budget scaled to the same iterations per pixel."""
+    import numpy as np
+
+    from oracle import ref_numeric as rn
+    from oracle import ref_pipeline as rp
+    from synth import noisy_bead_image
+
+    s = args.cpu_size
+    n_beads = int(round(120 * s * s / 1e6))
+    planes = np.stack([noisy_bead_image(9000 + c, (s, s), n_beads)[0] for c in range(args.channels)])
+    tiles = planes[:, None, None, None]
+    num_iter = max(1000, int(args.num_iter * (s * s) / (args.size * args.size)))
+    flat = flat_np[:s, :s]
+    t0 = time.perf_counter()
+    image = rp.stitch(rp.flatfield_correct(tiles, flat, 100.0), 0)
+    out = rp.find_beads(image, 10, 50, num_iter=num_iter, search_channels=[0], seed=1)
+    red = rp.roi_reduce(out["roi"], out["fg"], out["bg"])
+    dt = time.perf_counter() - t0
+    mp = args.channels * s * s / 1e6
+    return {"value": mp / dt, "unit": "MP/s", "cores": 1, "kind": "port",
+            "sample": f"1 timepoint x {args.channels} ch x {s}x{s} uint16, num_iter={num_iter}, "
+                      f"{len(out['beads'])} markers, {dt:.1f} s (NumPy oracle, single thread)",
+            "markers_per_s": len(out["beads"]) / dt, "_check": float(red["fg_count"].sum())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--timepoints", type=int, default=64, help="timepoints per GPU")
+    ap.add_argument("--channels", type=int, default=4)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--num-iter", type=int, default=5_000_000)
+    ap.add_argument("--plane-batch", type=int, default=0, help="searched planes per kernel batch (0 = all)")
+    ap.add_argument("--cpu-size", type=int, default=1024)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from magnify_amd import distributed as mgd
+    from magnify_amd import hotpath as hp
+    from magnify_amd.stack import StackProcessor, synthetic_stack
+    from synth import vignette
+
+    rank, world, local = mgd.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    hp.require_gpu()
+    dev = torch.device("cuda", local)
+    T, C, S = args.timepoints, args.channels, args.size
+
+    stack, truth = synthetic_stack(T, C, S, S, seed=4000 + 100 * rank, device=dev)
+    flat_np = vignette((S, S))
+    flat = torch.from_numpy(flat_np).to(dev)
+    proc = StackProcessor(T, C, S, S, num_iter=args.num_iter, min_bead_diameter=10, max_bead_diameter=50,
+                          search_channels=(0,), mode="P", plane_batch=args.plane_batch or None, device=dev)
+
+    def step(seed):
+        out = proc(stack, flat, 100.0, seed=seed)
+        table = mgd.marker_table(out, rank * T, C, dev)
+        table = mgd.gather_marker_table(table)
+        return out, table
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out, table = step(i)
+    timer = hp.StageTimer()
+    barrier()
+    hp.set_timer(timer)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out, table = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    hp.set_timer(None)
+    stages = timer.summary()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    markers_local = int(sum(len(b) for b in out["beads"]))
+    markers_total = int(table.shape[0])
+    mp_total = world * T * C * S * S / 1e6
+    ms_per_step = dt / args.steps * 1e3
+
+    if rank == 0:
+        # workload numbers for the algorithmic-byte table (last step, rank 0)
+        f = proc.finder
+        unique = int(f.num_circles.sum().item())
+        alive = int(f.num_alive.sum().item())
+        per_starts = f.per_starts.cpu().numpy()
+        radii = f.circles[:, :, 2]
+        mean_perimeter = float(np.mean(np.diff(per_starts)))
+        p = {"h": S, "w": S, "n_c": C, "search_planes": f.P, "num_iter": args.num_iter,
+             "edges": int(f.n_edges_host.sum()), "bitmap_words": f.bitmap_words, "unique": unique, "alive": alive,
+             "mean_perimeter": mean_perimeter, "ring_len": len(hp.nat.circle_points(proc.min_r, True)),
+             "markers": markers_local, "mean_disk": 600, "L": proc.L}
+        total_ms = sum(v[0] for v in stages.values())
+        breakdown = {k: {"ms_total": round(v[0], 3), "launches": v[1], "ms_avg": round(v[0] / v[1], 4)}
+                     for k, v in sorted(stages.items(), key=lambda kv: -kv[1][0])}
+        dom, (dom_ms, dom_n) = max(stages.items(), key=lambda kv: kv[1][0])
+        ab = algorithmic_bytes(dom, p)
+        avg_s = dom_ms / dom_n / 1e3
+        achieved = ab / avg_s / 1e9 if ab else None
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                    "algorithmic_bytes_per_launch": ab, "avg_launch_ms": dom_ms / dom_n,
+                    "share_of_kernel_time": dom_ms / total_ms}
+        # the streaming part alone (everything that is not RANSAC scoring / suppression)
+        stream_stages = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_to_uint8_blur", "mg_scharr_hist",
+                         "mg_canny_nms", "mg_canny_hysteresis", "mg_edges_finalize", "mg_edge_grid",
+                         "mg_roi_gather_reduce_batched"]
+        stream_ms = sum(stages[s][0] for s in stream_stages if s in stages) / args.steps
+        n_all, n_s = T * C * S * S, f.P * S * S
+        stream_bytes = 6 * n_all + 12 * n_s + markers_local * proc.L**2 * (4 * C + 6)
+        result = {
+            "metric": "megapixels/sec through flatfield+segment+ROI-reduce; markers/sec",
+            "value": mp_total / (dt / args.steps), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": f"C4: {T} timepoints x {C} ch x {S}x{S} uint16 per GPU, mode P (per-timepoint "
+                                   f"detection), search channel 0, num_iter={args.num_iter}, vignette flat-field, "
+                                   f"dark=100, roi_length={proc.L}",
+                       "timepoints_per_gpu": T, "parallelism": f"time-shard x{world}"},
+            "markers_per_s": markers_total / (dt / args.steps), "markers": markers_total,
+            "roofline": roofline,
+            "streaming_part": {"ms_per_step": stream_ms, "algorithmic_bytes": stream_bytes,
+                               "achieved_GBs": stream_bytes / (stream_ms / 1e3) / 1e9 if stream_ms else None,
+                               "frac_of_peak": stream_bytes / (stream_ms / 1e3) / 1e9 / HBM_PEAK_GBS if stream_ms else None},
+            "stages": breakdown,
+            "stats": {"unique_circles": unique, "alive_circles": alive, "edges": p["edges"],
+                      "hysteresis_sweeps": f.stats.get("hysteresis_sweeps"), "nms_rounds": f.stats.get("nms_rounds"),
+                      "kernel_ms_per_step": total_ms / args.steps},
+        }
+        if not args.no_cpu and world == 1:
+            cb = cpu_baseline(args, flat_np)
+            cb.pop("_check", None)
+            result["cpu_baseline"] = cb
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, the time (assay) axis is split in
+contiguous blocks, each rank runs the whole per-plane chain locally, and the only exchange is a
+variable-length all-gather of the final marker table (plus, in single-assay mode "R", a max
+all-reduce of the two flat-field maxima).  Backend "nccl" is RCCL over xGMI on ROCm; the same code
+runs on "gloo" for the CPU tests.  The reference has no distributed code.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); no-op for 1 rank."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def shard_range(n_units: int, rank: int, world: int):
+    """Contiguous block of units (timepoints / assays) owned by ``rank``."""
+    base, extra = divmod(n_units, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def allreduce_max_(t: torch.Tensor):
+    """In-place max all-reduce (flat-field maxima in single-assay mode, preprocess.py:84,86)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+def gather_marker_table(table: torch.Tensor) -> torch.Tensor:
+    """All-gather of per-rank marker tables (M_rank, F) -> (sum M_rank, F), rank order.
+
+    Variable length: counts are gathered first, then one padded all-gather."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return table
+    world = dist.get_world_size()
+    count = torch.tensor([table.shape[0]], dtype=torch.int64, device=table.device)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    padded = torch.zeros((cap, table.shape[1]), dtype=table.dtype, device=table.device)
+    padded[: table.shape[0]] = table
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+
+def marker_table(out: dict, assay_offset: int, n_channels: int, device) -> torch.Tensor:
+    """Pack a StackProcessor result into rows
+    [assay, row, col, r, fg_count, bg_count, fg_sum[C], bg_sum[C]] (float64; exact for these ints)."""
+    import numpy as np
+
+    beads = out["beads"]
+    m = int(sum(len(b) for b in beads))
+    width = 6 + 2 * n_channels
+    if m == 0:
+        return torch.zeros((0, width), dtype=torch.float64, device=device)
+    head = np.concatenate([np.column_stack([np.full(len(b), assay_offset + a), b]) for a, b in enumerate(beads) if len(b)])
+    tab = torch.empty((m, width), dtype=torch.float64, device=device)
+    tab[:, :4] = torch.from_numpy(head.astype(np.float64)).to(device)
+    tab[:, 4:6] = out["counts"].to(torch.float64)
+    sums = out["sums"][:, :, 0, :]  # (M, C, 2) at the assay's (only) time index
+    tab[:, 6 : 6 + n_channels] = sums[:, :, 0]
+    tab[:, 6 + n_channels :] = sums[:, :, 1]
+    return tab

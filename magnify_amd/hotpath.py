@@ -26,6 +26,67 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class StageTimer:
+    """Per-stage HIP-event timing on the stream the kernels are launched on (torch's current
+    stream): ``with timer.stage("name"):`` around C-ABI calls; ``timer.summary()`` after a sync."""
+
+    def __init__(self):
+        self.events = []
+
+    class _Ctx:
+        def __init__(self, timer, name):
+            self.timer, self.name = timer, name
+
+        def __enter__(self):
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+
+        def __exit__(self, *exc):
+            self.end.record()
+            self.timer.events.append((self.name, self.start, self.end))
+
+    def stage(self, name):
+        return StageTimer._Ctx(self, name)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.events:
+            tot, cnt = out.get(name, (0.0, 0))
+            out[name] = (tot + a.elapsed_time(b), cnt + 1)
+        return out
+
+
+class _NoTimer:
+    class _Ctx:
+        def __enter__(self):
+            return None
+
+        def __exit__(self, *exc):
+            return False
+
+    _ctx = _Ctx()
+
+    def stage(self, name):
+        return self._ctx
+
+
+TIMER = _NoTimer()
+
+
+def set_timer(timer):
+    """Install a StageTimer (or None) used by every hot-path call."""
+    global TIMER
+    TIMER = timer if timer is not None else _NoTimer()
+
+
+def _call(name, *args, stage=None):
+    """One C-ABI call: timed (if a StageTimer is installed) and status-checked."""
+    with TIMER.stage(stage or name):
+        nat.check(getattr(nat.lib(), name)(*args), name)
+
+
 def require_gpu():
     if not torch.cuda.is_available():
         raise RuntimeError("magnify_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
@@ -63,13 +124,14 @@ def flatfield_max(tiles: torch.Tensor, flatfield=1.0, darkfield=0.0) -> torch.Te
     fl, flt, flc = _df_operand(flatfield, ty, tx, tiles.device)
     max2 = torch.full((2,), -math.inf, dtype=torch.float64, device=tiles.device)
     n_tiles = tiles.numel() // (ty * tx)
-    nat.check(nat.lib().mg_flatfield_max(tiles.data_ptr(), nat.dtype_code(tiles.dtype), n_tiles, ty, tx, dk, _ptr(dkt),
-                                         dkc, fl, _ptr(flt), flc, max2.data_ptr(), _stream()), "mg_flatfield_max")
+    _call("mg_flatfield_max", tiles.data_ptr(), nat.dtype_code(tiles.dtype), n_tiles, ty, tx, dk, _ptr(dkt),
+                                         dkc, fl, _ptr(flt), flc, max2.data_ptr(), _stream())
     return max2
 
 
 def flatfield_stitch(tiles: torch.Tensor, overlap: int, flatfield=1.0, darkfield=0.0, apply_flatfield=True,
-                     max2: torch.Tensor | None = None, want_minmax=True):
+                     max2: torch.Tensor | None = None, want_minmax=True, out: torch.Tensor | None = None,
+                     minmax_out: torch.Tensor | None = None):
     """tiles (C, T, R, Cc, ty, tx) -> image (C, T, R*hy, Cc*hx) and per-plane min/max (C*T, 2).
 
     ``max2`` lets a multi-GPU caller supply all-reduced maxima."""
@@ -86,16 +148,24 @@ def flatfield_stitch(tiles: torch.Tensor, overlap: int, flatfield=1.0, darkfield
     fl, flt, flc = _df_operand(flatfield, ty, tx, tiles.device)
     if apply_flatfield and max2 is None:
         max2 = flatfield_max(tiles, flatfield, darkfield)
-    image = torch.empty((c, t, nr * hy, nc * hx), dtype=tiles.dtype, device=tiles.device)
+    if out is None:
+        image = torch.empty((c, t, nr * hy, nc * hx), dtype=tiles.dtype, device=tiles.device)
+    else:
+        image = out
+        assert image.is_contiguous() and image.numel() == c * t * nr * hy * nc * hx and image.dtype == tiles.dtype
     minmax = None
     if want_minmax:
-        minmax = torch.empty((c * t, 2), dtype=torch.float64, device=tiles.device)
-        minmax[:, 0] = math.inf
-        minmax[:, 1] = -math.inf
-    nat.check(nat.lib().mg_flatfield_apply_stitch(tiles.data_ptr(), nat.dtype_code(tiles.dtype), c * t, nr, nc, ty, tx,
+        if minmax_out is None:
+            minmax = torch.empty((c * t, 2), dtype=torch.float64, device=tiles.device)
+        else:
+            minmax = minmax_out
+            assert minmax.is_contiguous() and minmax.numel() == c * t * 2 and minmax.dtype == torch.float64
+        minmax.view(-1, 2)[:, 0] = math.inf
+        minmax.view(-1, 2)[:, 1] = -math.inf
+    _call("mg_flatfield_apply_stitch", tiles.data_ptr(), nat.dtype_code(tiles.dtype), c * t, nr, nc, ty, tx,
                                                   overlap, int(bool(apply_flatfield)), dk, _ptr(dkt), dkc, fl,
                                                   _ptr(flt), flc, _ptr(max2), image.data_ptr(), _ptr(minmax),
-                                                  _stream()), "mg_flatfield_apply_stitch")
+                                                  _stream())
     return image, minmax
 
 
@@ -107,8 +177,8 @@ def plane_minmax(planes: torch.Tensor) -> torch.Tensor:
     out = torch.empty((p, 2), dtype=torch.float64, device=planes.device)
     out[:, 0] = math.inf
     out[:, 1] = -math.inf
-    nat.check(nat.lib().mg_plane_minmax(planes.data_ptr(), nat.dtype_code(planes.dtype), p, planes.stride(0), h, w,
-                                        planes.stride(1), out.data_ptr(), _stream()), "mg_plane_minmax")
+    _call("mg_plane_minmax", planes.data_ptr(), nat.dtype_code(planes.dtype), p, planes.stride(0), h, w,
+                                        planes.stride(1), out.data_ptr(), _stream())
     return out
 
 
@@ -242,12 +312,11 @@ class CircleFinder:
         elif minmax is None:
             minmax = plane_minmax(planes)
         self.u8 = torch.empty((P, h, w), dtype=torch.uint8, device=self.dev) if keep_u8 else None
-        nat.check(L.mg_to_uint8_blur(planes.data_ptr(), code, P, planes.stride(0), h, w, planes.stride(1),
-                                     _ptr(minmax), self.blur.data_ptr(), _ptr(self.u8), s), "mg_to_uint8_blur")
+        _call("mg_to_uint8_blur", planes.data_ptr(), code, P, planes.stride(0), h, w, planes.stride(1),
+                                     _ptr(minmax), self.blur.data_ptr(), _ptr(self.u8), s)
         # coarse histogram of m = dx^2 + dy^2
         self.hist.zero_()
-        nat.check(L.mg_scharr_hist(self.blur.data_ptr(), P, h, w, 0, COARSE_SHIFT, COARSE_BINS, self.hist.data_ptr(), s),
-                  "mg_scharr_hist")
+        _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 0, COARSE_SHIFT, COARSE_BINS, self.hist.data_ptr(), s)
         # NB: rows of self.hist are FINE_BINS wide; the coarse pass used the first COARSE_BINS of a
         # COARSE_BINS-strided view, so read it back through the same flat layout.
         flat = self.hist.view(-1)[: P * COARSE_BINS].view(P, COARSE_BINS)
@@ -267,8 +336,8 @@ class CircleFinder:
             base_bins = np.array([t[min(k, len(t) - 1)] for t in todo], dtype=np.int64)
             self.hist_base.copy_(torch.from_numpy((base_bins << COARSE_SHIFT).astype(np.int32)))
             self.hist.zero_()
-            nat.check(L.mg_scharr_hist(self.blur.data_ptr(), P, h, w, self.hist_base.data_ptr(), 0, FINE_BINS,
-                                       self.hist.data_ptr(), s), "mg_scharr_hist")
+            _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, self.hist_base.data_ptr(), 0, FINE_BINS,
+                                       self.hist.data_ptr(), s)
             fcum = torch.cumsum(self.hist.to(torch.int64), dim=1).cpu().numpy()
             for p in range(P):
                 b = base_bins[p]
@@ -288,26 +357,24 @@ class CircleFinder:
             self.quantiles[p] = vals
             thresh[p] = canny_int_thresholds(vals[0], vals[1])
         self.thresh.copy_(torch.from_numpy(thresh))
-        nat.check(L.mg_canny_nms(self.blur.data_ptr(), P, h, w, self.thresh.data_ptr(), self.edges.data_ptr(), s),
-                  "mg_canny_nms")
+        _call("mg_canny_nms", self.blur.data_ptr(), P, h, w, self.thresh.data_ptr(), self.edges.data_ptr(), s)
         sweeps = 0
         while True:
             self.changed.zero_()
-            nat.check(L.mg_canny_hysteresis(self.edges.data_ptr(), P, h, w, self.changed.data_ptr(), s),
-                      "mg_canny_hysteresis")
+            _call("mg_canny_hysteresis", self.edges.data_ptr(), P, h, w, self.changed.data_ptr(), s)
             sweeps += 1
             if int(self.changed.sum().item()) == 0:
                 break
         self.stats["hysteresis_sweeps"] = sweeps
         self.cell_counts.zero_()
-        nat.check(L.mg_edges_finalize(self.edges.data_ptr(), self.blur.data_ptr(), P, h, w, self.grid,
-                                      self.angle.data_ptr(), self.cell_counts.data_ptr(), s), "mg_edges_finalize")
+        _call("mg_edges_finalize", self.edges.data_ptr(), self.blur.data_ptr(), P, h, w, self.grid,
+                                      self.angle.data_ptr(), self.cell_counts.data_ptr(), s)
         n_edges = self.cell_counts.sum(dim=1).cpu().numpy()
         self.coord_cap = max(1, int(n_edges.max()))
         self.coords = torch.empty((P, self.coord_cap, 2), dtype=torch.int32, device=self.dev)
-        nat.check(L.mg_edge_grid(self.edges.data_ptr(), P, h, w, self.grid, self.cell_counts.data_ptr(),
+        _call("mg_edge_grid", self.edges.data_ptr(), P, h, w, self.grid, self.cell_counts.data_ptr(),
                                  self.cell_starts.data_ptr(), self.num_edges.data_ptr(), self.coords.data_ptr(),
-                                 self.coord_cap, s), "mg_edge_grid")
+                                 self.coord_cap, s)
         self.n_edges_host = n_edges
         return n_edges
 
@@ -317,21 +384,20 @@ class CircleFinder:
         seeds = np.asarray(seeds, dtype=np.uint64).reshape(P)
         self.seeds.copy_(torch.from_numpy(seeds.view(np.int64)))
         self.raw = torch.empty((P, self.num_iter, 3), dtype=torch.float32, device=self.dev) if keep_raw else None
-        nat.check(L.mg_candidate_circles(self.coords.data_ptr(), self.coord_cap, self.cell_starts.data_ptr(),
+        _call("mg_candidate_circles", self.coords.data_ptr(), self.coord_cap, self.cell_starts.data_ptr(),
                                          self.cell_counts.data_ptr(), self.num_edges.data_ptr(), P, h, w, self.grid,
                                          self.seeds.data_ptr(), self.num_iter, self.min_r, self.max_r,
-                                         self.bitmap.data_ptr(), self.bitmap_words, _ptr(self.raw), s),
-                  "mg_candidate_circles")
-        nat.check(L.mg_bitmap_to_circles(self.bitmap.data_ptr(), self.bitmap_words, P, h, w, self.min_r, self.max_r,
+                                         self.bitmap.data_ptr(), self.bitmap_words, _ptr(self.raw), s)
+        _call("mg_bitmap_to_circles", self.bitmap.data_ptr(), self.bitmap_words, P, h, w, self.min_r, self.max_r,
                                          self.block_counts.data_ptr(), self.circles.data_ptr(), self.cap,
-                                         self.num_circles.data_ptr(), s), "mg_bitmap_to_circles")
+                                         self.num_circles.data_ptr(), s)
         self.num_alive.zero_()
         self.max_rc.fill_(-(2**31))
-        nat.check(L.mg_score_circles(self.angle.data_ptr(), P, h, w, self.circles.data_ptr(), self.cap,
+        _call("mg_score_circles", self.angle.data_ptr(), P, h, w, self.circles.data_ptr(), self.cap,
                                      self.num_circles.data_ptr(), self.min_r, self.max_r, self.per_rc.data_ptr(),
                                      self.per_exp.data_ptr(), self.per_starts.data_ptr(), float(min_roundness),
                                      self.scores.data_ptr(), self.alive.data_ptr(), self.num_alive.data_ptr(),
-                                     self.max_rc.data_ptr(), s), "mg_score_circles")
+                                     self.max_rc.data_ptr(), s)
 
     # -- stage 3: greedy suppression + ordered output -------------------------------------------
     def nms_stage(self, min_dist: int):
@@ -348,11 +414,10 @@ class CircleFinder:
             self.state.zero_()
             ring = torch.from_numpy(nat.circle_points(min_dist, True)).to(self.dev)
             while True:
-                nat.check(L.mg_nms_round(self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
+                _call("mg_nms_round", self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
                                          self.alive.data_ptr(), self.num_alive.data_ptr(), self.max_rc.data_ptr(), P,
                                          min_dist, ring.data_ptr(), ring.shape[0], self.nms_grid.data_ptr(),
-                                         self.nms_grid.shape[1], self.state.data_ptr(), self.undecided.data_ptr(), s),
-                          "mg_nms_round")
+                                         self.nms_grid.shape[1], self.state.data_ptr(), self.undecided.data_ptr(), s)
                 rounds += 1
                 if int(self.undecided.sum().item()) == 0:
                     break
@@ -363,10 +428,10 @@ class CircleFinder:
         out_scores = torch.empty((P, out_cap), dtype=torch.float32, device=self.dev)
         scratch = torch.empty((P, out_cap), dtype=torch.int32, device=self.dev)
         num_out = torch.zeros((P,), dtype=torch.int32, device=self.dev)
-        nat.check(L.mg_collect_circles(self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
+        _call("mg_collect_circles", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
                                        self.num_alive.data_ptr(), self.state.data_ptr(), int(min_dist <= 0), P,
                                        out.data_ptr(), out_scores.data_ptr(), out_cap, num_out.data_ptr(),
-                                       scratch.data_ptr(), s), "mg_collect_circles")
+                                       scratch.data_ptr(), s)
         return out, out_scores, num_out
 
     def find(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw=False, keep_u8=False,
@@ -419,8 +484,8 @@ def circle_labels(beads_per_assay, h, w, device="cuda"):
     d_beads = torch.from_numpy(host).to(device)
     d_counts = torch.from_numpy(counts).to(device)
     tab = _halfwidth_table(max_r, device)
-    nat.check(nat.lib().mg_circle_labels(d_beads.data_ptr(), cap, d_counts.data_ptr(), a, h, w, tab.data_ptr(), max_r,
-                                         labels.data_ptr(), _stream()), "mg_circle_labels")
+    _call("mg_circle_labels", d_beads.data_ptr(), cap, d_counts.data_ptr(), a, h, w, tab.data_ptr(), max_r,
+                                         labels.data_ptr(), _stream())
     return labels
 
 
@@ -459,10 +524,10 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
     d_beads = torch.from_numpy(beads).to(dev)
     d_assay = torch.from_numpy(assay).to(dev)
     d_local = torch.from_numpy(local).to(dev)
-    nat.check(nat.lib().mg_roi_gather_reduce_batched(
+    _call("mg_roi_gather_reduce_batched", 
         images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w, d_beads.data_ptr(),
         d_assay.data_ptr(), d_local.data_ptr(), m, L, _ptr(labels), _ptr(res["roi"]), _ptr(res["fg"]),
-        _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream()), "mg_roi_gather_reduce_batched")
+        _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
     return res
 
 
@@ -471,6 +536,6 @@ def masked_median_u16(roi: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     require_gpu()
     m, c, t, L, _ = roi.shape
     out = torch.empty((m, c, t), dtype=torch.float64, device=roi.device)
-    nat.check(nat.lib().mg_roi_masked_median_u16(roi.contiguous().data_ptr(), mask.contiguous().data_ptr(), m, c, t, L,
-                                                 out.data_ptr(), _stream()), "mg_roi_masked_median_u16")
+    _call("mg_roi_masked_median_u16", roi.contiguous().data_ptr(), mask.contiguous().data_ptr(), m, c, t, L,
+                                                 out.data_ptr(), _stream())
     return out

@@ -1,0 +1,158 @@
+"""Whole-stack driver of the hot path: flat-field + stitch -> bead detection -> fg/bg
+segmentation -> ROI reduction for a (time x channel x H x W) stack resident in HBM.
+
+Detection modes:
+  * mode "P" (headline): every time slice is an independent assay, which is what the reference
+    does for a list input (pipeline.py:18-24): per-slice flat-field maxima, per-slice detection.
+  * mode "R": the reference's single-assay semantics (find.py:477, 543-550): global maxima,
+    detection on time 0 only, geometry replicated over time.
+
+The time axis is the unit of sharding across GPUs (``magnify_amd.distributed``).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import hotpath as hp
+
+
+class StackProcessor:
+    """Reusable workspaces for stacks of a fixed shape (T, C, H, W)."""
+
+    def __init__(self, n_t, n_c, h, w, dtype=torch.uint16, min_bead_diameter=10, max_bead_diameter=50,
+                 low_edge_quantile=0.1, high_edge_quantile=0.9, num_iter=5_000_000, min_roundness=0.3,
+                 roi_length=None, search_channels=(0,), mode="P", plane_batch=None, device="cuda"):
+        hp.require_gpu()
+        if min_bead_diameter > max_bead_diameter:
+            raise ValueError("min_bead_diameter must be <= max_bead_diameter.")
+        self.T, self.C, self.h, self.w = n_t, n_c, h, w
+        self.min_r = math.floor(min_bead_diameter / 2)  # find.py:461-467
+        self.max_r = math.ceil(max_bead_diameter / 2)
+        self.L = roi_length if roi_length is not None else 2 * max_bead_diameter
+        self.low_q, self.high_q = low_edge_quantile, high_edge_quantile
+        self.num_iter, self.min_roundness = num_iter, min_roundness
+        self.search_channels = list(search_channels)
+        self.mode = mode
+        self.dev = torch.device(device)
+        self.n_assays = n_t if mode == "P" else 1
+        self.batch = min(self.n_assays, plane_batch or self.n_assays)
+        self.finder = hp.CircleFinder(self.batch, h, w, self.min_r, self.max_r, num_iter, device=device)
+        self.image = torch.empty((n_t, n_c, h, w), dtype=dtype, device=self.dev)
+        self.minmax = torch.empty((n_t, n_c, 2), dtype=torch.float64, device=self.dev)
+
+    def flatfield(self, stack: torch.Tensor, flatfield=1.0, darkfield=0.0, max2=None):
+        """stack (T, C, H, W) -> self.image (T, C, H, W), self.minmax (T, C, 2)."""
+        T, C, h, w = self.T, self.C, self.h, self.w
+        if self.mode == "P":
+            for t in range(T):
+                hp.flatfield_stitch(stack[t].view(C, 1, 1, 1, h, w), 0, flatfield, darkfield, out=self.image[t],
+                                    minmax_out=self.minmax[t])
+        else:
+            # single assay: the maxima span the whole stack (preprocess.py:84,86)
+            tiles = stack.view(T * C, 1, 1, 1, h, w)
+            hp.flatfield_stitch(tiles, 0, flatfield, darkfield, out=self.image, minmax_out=self.minmax, max2=max2)
+        return self.image
+
+    def detect(self, seed=0):
+        """Bead tables per assay: list of (M_a, 3) int32 [row, col, r] (find.py:475-501)."""
+        T, h, w = self.T, self.h, self.w
+        assays = list(range(self.n_assays))
+        beads = [np.empty((0, 3), dtype=np.int32) for _ in assays]
+        for k, ch in enumerate(self.search_channels):
+            done = 0
+            while done < len(assays):
+                # contiguous window of `batch` assays (the last window overlaps the previous one
+                # instead of being ragged; already finished assays are skipped on output)
+                lo = min(done, len(assays) - self.batch)
+                ids = assays[lo : lo + self.batch]
+                planes = self.image[lo : lo + self.batch, ch]  # strided view, no copy
+                mm = self.minmax[lo : lo + self.batch, ch].contiguous()
+                seeds = [(seed + 1000003 * a + 7919 * k) & 0xFFFFFFFFFFFFFFFF for a in ids]
+                res, _ = self.finder.find(planes, mm, self.low_q, self.high_q, self.min_roundness, self.min_r, seeds)
+                for j, a in enumerate(ids):
+                    if a >= done:
+                        beads[a] = np.concatenate([beads[a], dedup_against(beads[a], res[j][0], 2 * self.min_r)])
+                done = lo + self.batch
+        return beads
+
+    def segment_reduce(self, beads, want_roi=True):
+        """Labels, fg/bg masks, ROI gather and masked sums for every marker."""
+        T, C, h, w = self.T, self.C, self.h, self.w
+        labels = hp.circle_labels(beads, h, w, device=self.dev)
+        if self.mode == "P":
+            images = self.image.view(T, C, 1, h, w)
+        else:
+            images = self.image.permute(1, 0, 2, 3).contiguous().view(1, C, T, h, w)
+        return hp.roi_gather_reduce(images, beads, self.L, labels, want_roi=want_roi)
+
+    def __call__(self, stack, flatfield=1.0, darkfield=0.0, seed=0, want_roi=True):
+        self.flatfield(stack, flatfield, darkfield)
+        beads = self.detect(seed)
+        out = self.segment_reduce(beads, want_roi=want_roi)
+        out["beads"] = beads
+        return out
+
+
+def dedup_against(seen: np.ndarray, new: np.ndarray, radius: float) -> np.ndarray:
+    """Cross-channel de-duplication (find.py:490-500): drop new beads that have an earlier bead
+    within ``radius`` (Euclidean, inclusive, as KDTree.query_ball_point)."""
+    if len(seen) == 0 or len(new) == 0:
+        return new
+    d2 = ((new[:, None, :2].astype(np.float64) - seen[None, :, :2].astype(np.float64)) ** 2).sum(-1)
+    return new[~(d2 <= float(radius) ** 2).any(axis=1)]
+
+
+# --------------------------------------------------------------------------------------
+# synthetic stacks, generated on the device
+# --------------------------------------------------------------------------------------
+
+
+def synthetic_stack(n_t, n_c, h, w, beads_per_mpx=120.0, seed=4000, r_lo=8, r_hi=20, jitter=2, device="cuda"):
+    """uint16 stack (T, C, H, W): background 100 + Poisson(20) + N(0, 3) read noise, filled-disk
+    beads (the reference's filled_circle_points pixel sets) of radius U{8..20}, per-channel value
+    U{500..4000}, non-overlapping, jittered by +-``jitter`` px per timepoint.
+    Returns (stack, truth) with truth (n_beads, 3) [row, col, r] of timepoint 0."""
+    from . import _native as nat
+
+    rng = np.random.default_rng(seed)
+    n_beads = int(round(beads_per_mpx * h * w / 1e6))
+    border = r_hi + jitter + 2
+    # Jittered-lattice placement: O(n) and non-overlapping by construction.
+    min_pitch = 2 * r_hi + 4 + 2 * jitter
+    pitch = max(min_pitch, int(math.sqrt((h - 2 * border) * (w - 2 * border) / max(n_beads, 1))))
+    while pitch > min_pitch and ((h - 2 * border) // pitch) * ((w - 2 * border) // pitch) < n_beads:
+        pitch -= 1
+    gy, gx = max((h - 2 * border) // pitch, 0), max((w - 2 * border) // pitch, 0)
+    n_beads = min(n_beads, gy * gx)
+    cells = rng.choice(gy * gx, size=n_beads, replace=False) if n_beads else np.zeros(0, dtype=np.int64)
+    slack = pitch - min_pitch + 1
+    rows = border + (cells // max(gx, 1)) * pitch + min_pitch // 2 + rng.integers(0, slack, n_beads)
+    cols = border + (cells % max(gx, 1)) * pitch + min_pitch // 2 + rng.integers(0, slack, n_beads)
+    radii = rng.integers(r_lo, r_hi + 1, n_beads)
+    truth = np.column_stack([rows, cols, radii]).astype(np.int64)
+    disks = {}
+    for r in range(r_lo, r_hi + 1):
+        hw = nat.disk_halfwidths(r)
+        pts = [(dy, dx) for dy in range(-r, r + 1) for dx in range(-hw[dy + r], hw[dy + r] + 1)]
+        disks[r] = np.asarray(pts, dtype=np.int64)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    stack = torch.empty((n_t, n_c, h, w), dtype=torch.uint16, device=device)
+    for t in range(n_t):
+        jit = rng.integers(-jitter, jitter + 1, size=(n_beads, 2)) if t > 0 else np.zeros((n_beads, 2), dtype=np.int64)
+        flat_idx = np.concatenate([(rows[i] + jit[i, 0] + disks[radii[i]][:, 0]) * w + cols[i] + jit[i, 1] + disks[radii[i]][:, 1]
+                                   for i in range(n_beads)]) if n_beads else np.zeros(0, dtype=np.int64)
+        owner = np.repeat(np.arange(n_beads), [len(disks[r]) for r in radii]) if n_beads else np.zeros(0, dtype=np.int64)
+        d_idx = torch.from_numpy(flat_idx).to(device)
+        for c in range(n_c):
+            values = rng.integers(500, 4001, n_beads).astype(np.float32)
+            plane = 100.0 + torch.poisson(torch.full((h * w,), 20.0, device=device), generator=gen)
+            plane += torch.randn((h * w,), device=device, generator=gen) * 3.0
+            if n_beads:
+                plane.index_add_(0, d_idx, torch.from_numpy(values[owner]).to(device))
+            plane = torch.clamp(torch.round(plane), 0, 32767).to(torch.int16)
+            stack[t, c] = plane.view(torch.uint16).view(h, w)
+    return stack, truth
