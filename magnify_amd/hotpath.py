@@ -196,10 +196,10 @@ def _grad_of(m: int) -> np.float32:
 def quantile_indexes(n: int, q: float):
     """Indexes and weight that numpy (2.x) uses for np.quantile(float32_array, q),
     method 'linear': a Python-float q is cast to the array dtype, so the virtual index is
-    float32 arithmetic (numpy/lib/_function_base_impl.py: quantile, _compute_virtual_index,
+    float32 arithmetic (numpy/lib/_function_base_impl.py: quantile, _QuantileMethods["linear"],
     _get_indexes, _get_gamma)."""
     qf = np.float32(q)
-    vi = n * qf + (1 + qf * (1 - 1 - 1)) - 1  # float32 throughout
+    vi = (n - 1) * qf  # float32: lambda n, quantiles: (n - 1) * quantiles
     prev = np.floor(vi)
     nxt = prev + 1
     if vi >= n - 1:

@@ -1,0 +1,142 @@
+"""standardize_format and flatfield_correct (reference: src/magnify/preprocess.py:11-41, 62-88),
+plus the trivial view components that keep their registry names (rotate is a no-op in the
+reference as well, preprocess.py:54-59)."""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import hotpath, registry, xr_lite
+from .xr_lite import DataArray, Dataset
+
+DESIRED_ORDER = ["channel", "time", "tile_row", "tile_col", "tile_y", "tile_x"]
+SUPPORTED = ("uint8", "uint16", "float32", "float64")
+
+
+def to_device(data):
+    """NumPy / torch array -> contiguous device tensor of a supported dtype."""
+    if isinstance(data, torch.Tensor):
+        t = data
+    else:
+        arr = np.asarray(data)
+        if arr.dtype.name not in SUPPORTED:
+            if arr.dtype.kind in "iub":
+                arr = arr.astype(np.float64)  # exact below 2**53
+            else:
+                raise TypeError(f"unsupported image dtype {arr.dtype}")
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+    if str(t.dtype).replace("torch.", "") not in SUPPORTED:
+        raise TypeError(f"unsupported image dtype {t.dtype}")
+    hotpath.require_gpu()
+    return t.cuda().contiguous()
+
+
+@registry.component("standardize_format")
+def standardize_format(xp):
+    xp = xr_lite.from_any(xp)
+    if isinstance(xp, DataArray):
+        ds = Dataset(attrs=xp.attrs)
+        for k, c in xp.coords.items():
+            ds.coords[k] = c
+        ds["tile"] = xp
+        xp = ds
+    for old in ["x", "y", "row", "col"]:
+        if old in xp.tile.dims:
+            xp = xp.rename({old: "tile_" + old})
+    xp.attrs["__original_tile_dims__"] = list(xp.tile.dims)
+    tile = xp.data_vars["tile"]
+    extra = [d for d in tile.dims if d not in DESIRED_ORDER]
+    if extra:
+        # stack every additional dimension (and an existing time axis) into one time axis
+        # (preprocess.py:24-32)
+        if "time" in tile.dims:
+            xp = xp.rename(time="__time__")
+            tile = xp.data_vars["tile"]
+            extra.append("__time__")
+        tile = tile.transpose(*extra, ...)
+        sizes = [tile.sizes[d] for d in extra]
+        data = tile.data.reshape((int(np.prod(sizes)),) + tuple(tile.shape[len(extra):]))
+        xp.attrs["__mg_stacked_time__"] = (list(extra), sizes)
+        for d in extra:
+            xp.coords.pop(d, None)
+        xp.data_vars["tile"] = DataArray(data, ("time",) + tile.dims[len(extra):], name="tile")
+    tile = xp.data_vars["tile"]
+    for dim in DESIRED_ORDER:
+        if dim not in tile.dims:
+            tile = tile.expand_dims(dim)
+    xp.data_vars["tile"] = DataArray(tile.transpose(*DESIRED_ORDER).raw, DESIRED_ORDER, name="tile")
+    return xp
+
+
+@registry.component("rename_labels")
+def rename_labels(xp, **coords):
+    for name, new in coords.items():
+        if isinstance(new, dict):
+            new = [new.get(v, v) for v in xp[name].values.tolist()]
+        xp = xp.assign_coords({name: new})
+    return xp
+
+
+@registry.component("rotate")
+def rotate(xp, rotation=0):
+    return xp  # no-op in the reference too (preprocess.py:54-59)
+
+
+class LazyFlatfield:
+    """The flat-field correction as a pending operation on the tile stack -- the counterpart of the
+    reference's lazy dask expression (preprocess.py:83-87), which is only executed when ``stitch``
+    caches the image (stitch.py:45).  ``stitch`` fuses it with the crop/concat in one kernel;
+    any other access materialises it with the same kernel (overlap 0 per tile)."""
+
+    def __init__(self, tiles: torch.Tensor, flatfield, darkfield):
+        self.tiles, self.flatfield, self.darkfield = tiles, flatfield, darkfield
+        self.shape, self.dtype = tuple(tiles.shape), tiles.dtype
+        self.max2 = hotpath.flatfield_max(tiles, flatfield, darkfield)  # pass 1: the two global maxima
+
+    def materialize(self):
+        c, t, nr, nc, ty, tx = self.shape
+        flat = self.tiles.reshape(c * t * nr * nc, 1, 1, 1, ty, tx)
+        out, _ = hotpath.flatfield_stitch(flat, 0, self.flatfield, self.darkfield, max2=self.max2, want_minmax=False)
+        return out.reshape(self.shape)
+
+
+def _field(value):
+    if isinstance(value, (str, os.PathLike)):
+        raise NotImplementedError("flat/dark field files are read with tifffile in the reference "
+                                  "(preprocess.py:64-81); pass the image as an array")
+    if isinstance(value, (DataArray,)):
+        value = value.values
+    return value
+
+
+@registry.component("flatfield_correct")
+def flatfield_correct(xp, flatfield=1.0, darkfield=0.0):
+    tiles = to_device(xp.data_vars["tile"].data)
+    xp.data_vars["tile"] = DataArray(LazyFlatfield(tiles, _field(flatfield), _field(darkfield)),
+                                     xp.data_vars["tile"].dims, name="tile")
+    return xp
+
+
+@registry.component("horizontal_flip")
+def horizontal_flip(xp):
+    name, dim = ("image", "im_x") if "image" in xp else ("tile", "tile_x")
+    v = xp.data_vars[name]
+    ax = v.dims.index(dim)
+    data = v.data
+    data = torch.flip(data, (ax,)) if isinstance(data, torch.Tensor) else np.flip(data, ax)
+    xp.data_vars[name] = DataArray(data, v.dims, name=name)
+    return xp
+
+
+@registry.component("vertical_flip")
+def vertical_flip(xp):
+    name, dim = ("image", "im_y") if "image" in xp else ("tile", "tile_y")
+    v = xp.data_vars[name]
+    ax = v.dims.index(dim)
+    data = v.data
+    data = torch.flip(data, (ax,)) if isinstance(data, torch.Tensor) else np.flip(data, ax)
+    xp.data_vars[name] = DataArray(data, v.dims, name=name)
+    return xp

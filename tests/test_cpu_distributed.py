@@ -1,0 +1,66 @@
+"""World-size-2 gloo test of the multi-GPU plumbing (time-axis sharding + variable-length marker
+table all-gather + flat-field max all-reduce), on CPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from magnify_amd import distributed as mgd
+
+    r, w, _ = mgd.init_from_env(backend="gloo")
+    lo, hi = mgd.shard_range(7, r, w)
+    # each rank "finds" a different number of markers per owned timepoint
+    beads = [np.column_stack([np.full(t + 1, 10 * t), np.arange(t + 1), np.full(t + 1, 5)]).astype(np.int32)
+             for t in range(lo, hi)]
+    m = sum(len(b) for b in beads)
+    out = {"beads": beads, "counts": torch.arange(2 * m, dtype=torch.int32).reshape(m, 2),
+           "sums": torch.arange(m * 3 * 2, dtype=torch.float64).reshape(m, 3, 1, 2)}
+    table = mgd.gather_marker_table(mgd.marker_table(out, lo, 3, torch.device("cpu")))
+    mx = mgd.allreduce_max_(torch.tensor([float(r), 10.0 - r], dtype=torch.float64))
+    ret[rank] = (table.numpy().copy(), mx.numpy().copy(), (lo, hi))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_marker_table_gather():
+    world = 2
+    port = _free_port()
+    manager = mp.get_context("spawn").Manager()
+    ret = manager.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    t0, m0, r0 = ret[0]
+    t1, m1, r1 = ret[1]
+    np.testing.assert_array_equal(t0, t1)  # every rank holds the same full table
+    assert r0 == (0, 4) and r1 == (4, 7)
+    assert t0.shape == (sum(t + 1 for t in range(7)), 6 + 2 * 3)
+    assert t0[:, 0].tolist() == sorted(t0[:, 0].tolist())  # rank order == time order
+    assert set(t0[:, 0].astype(int).tolist()) == set(range(7))
+    np.testing.assert_array_equal(m0, [1.0, 10.0])
+    np.testing.assert_array_equal(m0, m1)
+
+
+def test_shard_range_covers_everything():
+    from magnify_amd.distributed import shard_range
+
+    for n in (1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

@@ -1,0 +1,220 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, host tables match the
+oracle, the np.quantile restatement, the registry / Pipeline semantics of the reference
+(pipeline.py:31-87, registry.py:16-29), the container, and format round trips."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import magnify_amd as mg
+from magnify_amd import _native as nat
+from magnify_amd import hotpath as hp
+from oracle import ref_numeric as rn
+from oracle import ref_opencv as rcv
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "magnify_hip.h")).read()
+    declared = set(re.findall(r"^int (mg_\w+)\(", header, flags=re.M))
+    assert len(declared) >= 20
+    assert declared == set(nat.PROTOTYPES), declared ^ set(nat.PROTOTYPES)
+    lib = ctypes.CDLL(nat.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert nat.lib().mg_version() >= 1
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        hp.require_gpu()
+    with pytest.raises(RuntimeError):
+        mg.beads(mg.DataArray(np.zeros((64, 64), np.uint16), ("y", "x")), overlap=0, num_iter=10)
+
+
+def test_host_tables_match_oracle():
+    for r in (0, 1, 2, 5, 10, 25, 33, 60):
+        np.testing.assert_array_equal(nat.circle_points(r), rn.circle_points(r))
+        np.testing.assert_array_equal(nat.circle_points(r, True), rn.circle_points(r, True))
+    for r in range(2, 70):
+        hw = nat.disk_halfwidths(r)
+        pts = {tuple(p) for p in rn.filled_circle_points(r).tolist()}
+        assert pts == {(dy, dx) for dy in range(-r, r + 1) for dx in range(-hw[dy + r], hw[dy + r] + 1)}
+        np.testing.assert_array_equal(np.sort(mg.utils.filled_circle_points(r), axis=0),
+                                      np.sort(rn.filled_circle_points(r), axis=0))
+    for r in range(0, 40):
+        hw = nat.cv_disk_halfwidths(r)
+        mask = rcv.filled_circle_mask((2 * r + 1, 2 * r + 1), (r, r), r)
+        want = np.zeros_like(mask)
+        for ady in range(r + 1):
+            want[[r - ady, r + ady], r - hw[ady] : r + hw[ady] + 1] = True
+        np.testing.assert_array_equal(mask, want)
+    rc, expected, starts = nat.perimeter_table(5, 25)
+    assert starts[0] == 0 and starts[-1] == len(rc) == len(expected)
+    np.testing.assert_array_equal(rc[starts[5] : starts[6]], rn.circle_points(10))
+    # libm atan2 (product) vs NumPy's SIMD arctan2 (oracle): within 1 ulp of float64
+    ref = np.arctan2(rc[:, 0], rc[:, 1])
+    assert np.max(np.abs(expected - ref)) <= 4.5e-16
+    with pytest.raises(ValueError):
+        nat.disk_halfwidths(1)
+
+
+def test_bounding_box_golden(golden):
+    for x, y, length, w, h, *exp in golden("bounding_box")["cases"]:
+        assert mg.utils.bounding_box(int(x), int(y), int(length), int(w), int(h)) == tuple(int(v) for v in exp)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 1000, 300 * 420, 5_000_001, 20_000_003])
+def test_quantile_restatement_matches_numpy(n):
+    """hotpath.quantile_indexes / lerp_f32 reproduce np.quantile(float32 array, q) bit-for-bit,
+    including the float32 virtual index above 2**24 elements."""
+    rng = np.random.default_rng(n)
+    m = rng.integers(0, 5000, size=n) ** 2 + rng.integers(0, 5000, size=n) ** 2
+    g = np.sqrt(m.astype(np.float32))
+    srt = np.sort(m)
+    for q in (0.0, 0.1, 0.5, 0.9, 0.99, 0.9997, 1.0):
+        a, b, gamma = hp.quantile_indexes(n, q)
+        got = hp.lerp_f32(hp._grad_of(int(srt[a])), hp._grad_of(int(srt[b])), gamma)
+        want = np.quantile(g, q)
+        assert got.dtype == np.float32 and got == want, (n, q, got, want)
+
+
+def test_canny_threshold_prep():
+    for lo, hi in [(0.0, 0.0), (3.5, 10.2), (10.2, 3.5), (40000.0, 50000.0), (0.5, 181.0193)]:
+        assert hp.canny_int_thresholds(lo, hi) == rcv.canny_thresholds(lo, hi)
+
+
+# ---- registry / pipeline --------------------------------------------------------------------
+
+
+def test_registered_names_and_signatures():
+    names = set(mg.components.get_all())
+    assert {"standardize_format", "flatfield_correct", "stitch", "find_beads", "identify_buttons", "drop",
+            "restore_format", "rotate"} <= names
+    assert "read" in mg.readers.get_all()
+    import inspect
+
+    assert list(inspect.signature(mg.components.get("flatfield_correct")).parameters) == ["flatfield", "darkfield"]
+    sig = inspect.signature(mg.beads)
+    assert sig.parameters["min_bead_diameter"].default == 10 and sig.parameters["num_iter"].default == 5000000
+    assert inspect.signature(mg.beads_pipe).parameters["min_bead_diameter"].default == 5  # registry.py:572
+    assert inspect.signature(mg.microfluidic_chip).parameters["row_dist"].default == 375 / 1.61
+    with pytest.raises(ValueError):
+        mg.microfluidic_chip_pipe(chip_type="nope")
+
+
+def test_component_decorator_returns_function_and_registers_factory():
+    @mg.component("unit_test_scale")
+    def scale(xp, factor=2):
+        return ("scaled", xp, factor)
+
+    assert scale("a") == ("scaled", "a", 2)  # the original function comes back (registry.py:27)
+    factory = mg.components.get("unit_test_scale")
+    assert factory(factor=3)("b") == ("scaled", "b", 3)
+
+
+def test_pipeline_add_remove_semantics():
+    pipe = mg.Pipeline("read")
+    pipe.add_pipe("standardize_format")
+    pipe.add_pipe("drop", roi_only=False)
+
+    def custom(xp, k=1):
+        return xp
+
+    pipe.add_pipe(custom, after="standardize_format", k=2)
+    pipe.add_pipe("rotate", first=True)
+    pipe.add_pipe("restore_format", before="drop")
+    assert [n for n, _ in pipe.components] == ["rotate", "standardize_format", "custom", "restore_format", "drop"]
+    with pytest.raises(ValueError):
+        pipe.add_pipe("rotate")  # duplicate name
+    with pytest.raises(ValueError):
+        pipe.add_pipe("rotate", name="r2", first=True, last=True)
+    pipe.add_pipe("rotate", name="r2", after=0)
+    assert pipe.components[1][0] == "r2"
+    pipe.remove_pipe("r2")
+    with pytest.raises(ValueError):
+        pipe.remove_pipe("r2")
+    with pytest.raises(ValueError):
+        mg.Pipeline("read").remove_pipe("x")
+    with pytest.raises(KeyError):
+        pipe.add_pipe("no_such_component")
+
+
+def test_reader_passthrough_and_errors():
+    pipe = mg.Pipeline("read")
+    a = mg.DataArray(np.zeros((4, 4)), ("y", "x"))
+    assert pipe(a) is a
+    out = pipe([a, a])
+    assert isinstance(out, list) and len(out) == 2
+    with pytest.raises(FileNotFoundError):
+        pipe("/no/such/file.tif")
+
+
+@pytest.mark.parametrize("dims", [("y", "x"), ("channel", "y", "x"), ("time", "y", "x"), ("channel", "time", "y", "x"),
+                                  ("time", "channel", "y", "x"), ("row", "col", "y", "x")])
+def test_standardize_restore_round_trip(dims):
+    rng = np.random.default_rng(0)
+    shape = tuple(2 + i for i in range(len(dims) - 2)) + (6, 7)
+    data = rng.integers(0, 100, size=shape).astype(np.uint16)
+    xp = mg.preprocess.standardize_format(mg.DataArray(data, dims))
+    assert xp.tile.dims == ("channel", "time", "tile_row", "tile_col", "tile_y", "tile_x")
+    assert xp.attrs["__original_tile_dims__"] == ["tile_" + d if d in ("x", "y", "row", "col") else d for d in dims]
+    back = mg.postprocess.restore_format(xp)
+    assert "__original_tile_dims__" not in back.attrs
+    np.testing.assert_array_equal(back.tile.values, data)
+    assert back.tile.dims == tuple("tile_" + d if d in ("x", "y", "row", "col") else d for d in dims)
+
+
+def test_standardize_stacks_extra_dims_into_time():
+    data = np.arange(2 * 3 * 4 * 5).reshape(2, 3, 4, 5).astype(np.uint16)
+    xp = mg.preprocess.standardize_format(mg.DataArray(data, ("well", "time", "y", "x")))
+    assert xp.tile.sizes["time"] == 6 and xp.tile.sizes["channel"] == 1
+    back = mg.postprocess.restore_format(xp)
+    np.testing.assert_array_equal(back.tile.values, data)
+    assert back.tile.dims == ("well", "time", "tile_y", "tile_x")
+
+
+def test_identify_buttons_and_drop():
+    xp = mg.preprocess.standardize_format(mg.DataArray(np.zeros((3, 8, 8), np.uint16), ("time", "y", "x")))
+    xp = mg.identify.identify_buttons(xp, shape=(4, 5))
+    assert xp.tag.shape == (4, 5) and (xp.tag.values == "default").all()
+    assert xp.valid.shape == (4, 5, 3) and xp.valid.values.all()
+    with pytest.raises(ValueError):
+        mg.identify.identify_buttons(xp)
+    assert "tile" not in mg.postprocess.drop(xp).data_vars
+    assert "tile" in mg.postprocess.drop(xp, drop_tiles=False).data_vars
+
+
+def test_container_algebra():
+    rng = np.random.default_rng(1)
+    roi = mg.DataArray(rng.integers(0, 50, size=(3, 2, 4, 4)).astype(np.uint16), ("mark", "channel", "roi_y", "roi_x"))
+    fg = mg.DataArray(rng.random((3, 4, 4)) > 0.5, ("mark", "roi_y", "roi_x"))
+    ds = mg.Dataset({"roi": roi}, coords={"fg": fg, "channel": ["a", "b"]})
+    want = np.where(fg.values[:, None], roi.values, np.nan)
+    np.testing.assert_allclose(ds.roi.where(ds.fg).mean(dim=["roi_x", "roi_y"]).values, np.nanmean(want, axis=(-1, -2)))
+    np.testing.assert_allclose(ds.where(ds.fg).roi.median(dim=["roi_x", "roi_y"]).values,
+                               np.nanmedian(want, axis=(-1, -2)))
+    np.testing.assert_array_equal(ds.fg.sum(dim=["roi_x", "roi_y"]).values, fg.values.sum(axis=(-1, -2)))
+    np.testing.assert_array_equal(ds.roi.sel(channel="b").values, roi.values[:, 1])
+    np.testing.assert_array_equal(ds.roi.isel(mark=[0, 2]).values, roi.values[[0, 2]])
+    np.testing.assert_array_equal(ds.roi[1, 0, 1:3].values, roi.values[1, 0, 1:3])
+    assert ds.sizes == {"mark": 3, "channel": 2, "roi_y": 4, "roi_x": 4}
+
+
+def test_mark_stack_unstack():
+    x = mg.DataArray(np.arange(24).reshape(2, 3, 4), ("mark_row", "mark_col", "time"))
+    tag = mg.DataArray(np.array([["a", "b", "c"], ["d", "e", "f"]]), ("mark_row", "mark_col"))
+    ds = mg.Dataset(coords={"x": x, "tag": tag})
+    st = ds.stack_mark()
+    assert st.x.dims == ("mark", "time") and st.sizes["mark"] == 6
+    assert st.tag.values.tolist() == ["a", "b", "c", "d", "e", "f"]
+    back = st.unstack()
+    np.testing.assert_array_equal(back.x.values, x.values)
+    assert back.x.dims == ("mark_row", "mark_col", "time")

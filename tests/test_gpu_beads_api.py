@@ -1,0 +1,185 @@
+"""End-to-end (level-2) parity: the scenarios and tolerances of the reference's own bead and
+stitch tests (tests/test_beads.py, tests/test_stitch.py), driven through the drop-in API
+``mg.beads`` / ``Stitcher`` of this build.  Statistical tolerances, as in the reference, because
+the reference detector is unseeded."""
+import numpy as np
+import pytest
+
+from synth import draw_beads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import magnify_amd
+
+    magnify_amd.hotpath = __import__("magnify_amd.hotpath", fromlist=["x"])
+    magnify_amd.hotpath.require_gpu()
+    magnify_amd.seed(1234)
+    return magnify_amd
+
+
+def arr(mg, data, dims, **coords):
+    return mg.DataArray(data=data, dims=dims, coords=coords or None)
+
+
+def test_bead_single(mg):
+    # tests/test_beads.py:49-66
+    xp = mg.beads(data=arr(mg, draw_beads((1024, 1024), [512, 512]), ("y", "x")), min_bead_diameter=16,
+                  max_bead_diameter=24, overlap=0, num_iter=100)
+    assert isinstance(xp, mg.Dataset)
+    assert xp.roi.sizes["mark"] == 1
+    radius = 10
+    detected = np.sqrt(xp.fg.sum().values.item() / np.pi)
+    assert 0.95 * radius < detected < 1.05 * radius
+    assert 0.95 * 512 < xp.x.squeeze().values.item() < 1.05 * 512
+    assert 0.95 * 512 < xp.y.squeeze().values.item() < 1.05 * 512
+
+
+def test_beads_multiple(mg):
+    # tests/test_beads.py:69-98
+    pos = [[200, 200], [200, 800], [512, 512], [800, 200], [800, 800]]
+    xp = mg.beads(data=arr(mg, draw_beads((1024, 1024), pos), ("y", "x")), min_bead_diameter=16, max_bead_diameter=24,
+                  overlap=0, num_iter=10000)
+    assert xp.roi.sizes["mark"] == 5
+    radii = np.sqrt(xp.fg.sum(dim=["roi_x", "roi_y"]).values / np.pi)
+    assert np.all(radii > 9) and np.all(radii < 11)
+
+
+def test_beads_near_edges(mg):
+    # tests/test_beads.py:101-130
+    pos = [[50, 512], [974, 512], [512, 50], [512, 974]]
+    xp = mg.beads(data=arr(mg, draw_beads((1024, 1024), pos), ("y", "x")), min_bead_diameter=16, max_bead_diameter=24,
+                  overlap=0, num_iter=10000)
+    assert xp.roi.sizes["mark"] == 4
+    x, y = xp.x.squeeze().values, xp.y.squeeze().values
+    assert np.any(y < 100) and np.any(y > 900) and np.any(x < 100) and np.any(x > 900)
+
+
+def test_beads_close_stay_separate(mg):
+    # tests/test_beads.py:160-188: two beads 30 px apart are both found
+    pos = [[500, 500], [500, 530]]
+    xp = mg.beads(data=arr(mg, draw_beads((1024, 1024), pos), ("y", "x")), min_bead_diameter=16, max_bead_diameter=24,
+                  overlap=0, num_iter=10000)
+    assert xp.roi.sizes["mark"] == 2
+    xs = np.sort(xp.x.squeeze().values)
+    assert abs(xs[0] - 500) < 5 and abs(xs[1] - 530) < 5
+
+
+def test_beads_different_sizes(mg):
+    # tests/test_beads.py:191-216
+    pos = [[300, 300], [300, 700], [700, 500]]
+    diam = [16, 24, 32]
+    xp = mg.beads(data=arr(mg, draw_beads((1024, 1024), pos, np.array(diam)), ("y", "x")), min_bead_diameter=12,
+                  max_bead_diameter=40, overlap=0, num_iter=20000)
+    assert xp.roi.sizes["mark"] == 3
+    radii = np.sort(np.sqrt(xp.fg.sum(dim=["roi_x", "roi_y"]).values / np.pi))
+    for got, want in zip(radii, [8, 12, 16]):
+        assert 0.8 * want < got < 1.2 * want
+
+
+def test_beads_empty_image(mg):
+    # tests/test_beads.py:219-232
+    xp = mg.beads(data=arr(mg, np.zeros((512, 512), dtype=np.uint16), ("y", "x")), min_bead_diameter=16,
+                  max_bead_diameter=24, overlap=0, num_iter=1000)
+    assert xp.roi.sizes["mark"] == 0
+
+
+def test_beads_float32_input(mg):
+    # tests/test_beads.py:235-247
+    img = draw_beads((1024, 1024), [512, 512]).astype(np.float32)
+    xp = mg.beads(data=arr(mg, img, ("y", "x")), min_bead_diameter=16, max_bead_diameter=24, overlap=0, num_iter=1000)
+    assert xp.roi.sizes["mark"] == 1
+    assert xp.roi.dtype == np.float32
+
+
+def test_beads_output_structure(mg):
+    # tests/test_beads.py:250-274
+    xp = mg.beads(data=arr(mg, draw_beads((1024, 1024), [512, 512]), ("y", "x")), min_bead_diameter=16,
+                  max_bead_diameter=24, overlap=0, num_iter=1000)
+    for name in ("x", "y", "fg", "bg"):
+        assert name in xp.coords
+    assert "roi" in xp.data_vars
+    assert set(xp.roi.dims) == {"mark", "roi_x", "roi_y"}
+    assert "tile" not in xp.data_vars and "image" in xp.data_vars
+    assert xp.roi.shape[-2:] == (48, 48)  # roi_length = 2 * max_bead_diameter (find.py:467)
+    assert "__original_tile_dims__" not in xp.attrs
+
+
+def test_beads_multichannel_dedup_and_time(mg):
+    # tests/test_beads.py:394-430 (cross-channel de-duplication) + (channel, time, y, x) layout
+    a = draw_beads((512, 512), [[150, 150], [350, 350]])
+    b = draw_beads((512, 512), [[150, 150], [150, 350]])  # one bead shared with channel a
+    data = np.stack([np.stack([a, a]), np.stack([b, b])])  # (channel, time, y, x)
+    xp = mg.beads(data=arr(mg, data, ("channel", "time", "y", "x"), channel=["red", "green"]), min_bead_diameter=16,
+                  max_bead_diameter=24, overlap=0, num_iter=5000)
+    assert xp.roi.sizes["mark"] == 3
+    assert xp.roi.dims == ("mark", "channel", "time", "roi_y", "roi_x")
+    assert xp.fg.dims == ("mark", "time", "roi_y", "roi_x")
+    np.testing.assert_array_equal(xp.x.values[:, 0], xp.x.values[:, 1])  # geometry replicated over time
+    xq = mg.beads(data=arr(mg, data, ("channel", "time", "y", "x"), channel=["red", "green"]), min_bead_diameter=16,
+                  max_bead_diameter=24, overlap=0, num_iter=5000, search_channel="green")
+    assert xq.roi.sizes["mark"] == 2
+
+
+def test_beads_roi_contents_and_reductions(mg):
+    pos = [[200, 300], [400, 100]]
+    img = draw_beads((512, 512), pos, 20, [1000, 3000])
+    pipe = mg.beads_pipe(min_bead_diameter=16, max_bead_diameter=24, overlap=0, num_iter=5000)
+    pipe.remove_pipe("restore_format")
+    xp = pipe(arr(mg, img, ("y", "x")))
+    assert xp.roi.sizes["mark"] == 2
+    roi, fg, bg = xp.roi.values, xp.fg.values, xp.bg.values
+    for i in range(2):
+        x, y = int(xp.x.values[i, 0]), int(xp.y.values[i, 0])
+        top, bottom, left, right = mg.utils.bounding_box(x, y, 48, 512, 512)
+        np.testing.assert_array_equal(roi[i, 0, 0], img[top:bottom, left:right])
+        assert fg[i, 0].sum() > 250 and not (fg[i, 0] & bg[i, 0]).any()
+    s = mg.reduce.masked_sum(xp, "fg").values
+    np.testing.assert_array_equal(s[:, 0, 0], (roi[:, 0, 0] * fg[:, 0]).sum(axis=(-1, -2)))
+    mean = mg.reduce.masked_mean(xp, "fg").values[:, 0, 0]
+    assert set(np.round(mean).astype(int).tolist()) == {1000, 3000}
+    med = mg.reduce.masked_median(xp, "bg").values
+    assert (med == 0).all()
+    np.testing.assert_array_equal(mg.reduce.counts(xp, "fg").values[:, 0], fg[:, 0].sum(axis=(-1, -2)))
+    # user-side algebra through the container (README.md:21-22)
+    np.testing.assert_allclose(xp.roi.where(xp.fg).mean(dim=["roi_x", "roi_y"]).values[:, 0, 0], mean)
+
+
+def test_flatfield_in_pipeline_matches_oracle(mg):
+    from oracle import ref_pipeline as rp
+    from synth import noisy_bead_image, vignette
+
+    img, _ = noisy_bead_image(3, (256, 256), 5)
+    tiles = np.stack([img, img[::-1].copy()]).reshape(1, 1, 1, 2, 256, 256)
+    flat = vignette((256, 256))
+    pipe = mg.Pipeline("read")
+    pipe.add_pipe("standardize_format")
+    pipe.add_pipe("flatfield_correct", flatfield=flat, darkfield=100.0)
+    pipe.add_pipe("stitch", overlap=16)
+    xp = pipe(mg.DataArray(tiles, ("channel", "time", "tile_row", "tile_col", "tile_y", "tile_x")))
+    want = rp.stitch(rp.flatfield_correct(tiles, flat, 100.0), 16)
+    np.testing.assert_array_equal(xp.image.values, want)
+    # the lazily corrected tiles materialise to the same values
+    np.testing.assert_array_equal(xp.tile.values, rp.flatfield_correct(tiles, flat, 100.0))
+
+
+def test_stitcher_component(mg):
+    # tests/test_stitch.py through the component object
+    from magnify_amd.stitch import Stitcher
+
+    rng = np.random.default_rng(0)
+    dims = ["channel", "time", "tile_row", "tile_col", "tile_y", "tile_x"]
+    t = rng.random((2, 3, 2, 2, 25, 25))
+    ds = mg.Dataset({"tile": mg.DataArray(t, dims)}, coords={"channel": ["red", "green"], "time": [0, 1, 2]})
+    res = Stitcher(overlap=8)(ds)
+    assert "image" in res.data_vars and res.image.dims == ("channel", "time", "im_y", "im_x")
+    assert len(res.channel) == 2 and len(res.time) == 3
+    assert res.sizes["im_y"] == 2 * (25 - 8)
+    with pytest.raises(ValueError):
+        Stitcher(overlap=-5)
+    with pytest.raises(AttributeError):
+        Stitcher(overlap=10)(mg.Dataset({"other": mg.DataArray([1, 2, 3], ("x",))}))
+    with pytest.raises(ValueError):
+        Stitcher(overlap=100)(mg.Dataset({"tile": mg.DataArray(rng.random((1, 1, 2, 2, 50, 50)), dims)}))
