@@ -27,17 +27,17 @@ def algorithmic_bytes(stage, p):
     """Algorithmic HBM bytes of ONE launch of a stage (DESIGN.md 'Kernels'); p = workload numbers."""
     n, planes, c = p["h"] * p["w"], p["search_planes"], p["n_c"]
     table = {
-        "mg_flatfield_max": 2 * c * n,                      # one assay (C planes) per launch: read u16
-        "mg_flatfield_apply_stitch": 4 * c * n,             # read u16 + write u16
+        "mg_flatfield_max": 2 * c * n * p["n_t"],            # read u16, whole stack in one launch
+        "mg_flatfield_apply_stitch": 4 * c * n * p["n_t"],   # read u16 + write u16
         "mg_to_uint8_blur": 3 * planes * n,                 # read u16, write blurred u8
         "mg_scharr_hist": 1 * planes * n,                   # read u8
         "mg_canny_nms": 2 * planes * n,                     # read u8, write map u8
         "mg_canny_hysteresis": 2 * planes * n,              # read + write map (per sweep)
-        "mg_edges_finalize": 6 * planes * n,                # map r/w + float32 angle map write
-        "mg_edge_grid": 1 * planes * n + 8 * p["edges"],    # read edges, write coords
+        "mg_edges_finalize": (1 + 1 / 8) * planes * n,      # read map, write edge bitmap
+        "mg_edge_grid": planes * n / 8 + 8 * p["edges"],    # read bitmap (twice: count, fill), write coords
         "mg_candidate_circles": 28 * planes * p["num_iter"],  # 3 coordinate reads (8 B) + bitmap word
-        "mg_bitmap_to_circles": 2 * 4 * p["bitmap_words"] * planes + 12 * p["unique"],
-        "mg_score_circles": p["unique"] * (12 + 4 * p["mean_perimeter"] + 4),
+        "mg_bitmap_to_circles": 2 * 4 * p["bitmap_words"] * planes + 12 * p["unique"],  # bitmap read twice + list
+        "mg_score_circles": p["unique"] * (12 + p["mean_perimeter"] / 8 + 4),  # circle + perimeter edge bits + score
         "mg_nms_round": p["alive"] * p["ring_len"] * 16,
         "mg_collect_circles": p["alive"] * 4 + p["markers"] * 16,
         "mg_circle_labels": p["markers"] * p["mean_disk"] * 8,
@@ -78,8 +78,8 @@ def cpu_baseline(args, flat_np):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--timepoints", type=int, default=64, help="timepoints per GPU")
     ap.add_argument("--channels", type=int, default=4)
     ap.add_argument("--size", type=int, default=4096)
@@ -149,9 +149,8 @@ def main():
         unique = int(f.num_circles.sum().item())
         alive = int(f.num_alive.sum().item())
         per_starts = f.per_starts.cpu().numpy()
-        radii = f.circles[:, :, 2]
         mean_perimeter = float(np.mean(np.diff(per_starts)))
-        p = {"h": S, "w": S, "n_c": C, "search_planes": f.P, "num_iter": args.num_iter,
+        p = {"h": S, "w": S, "n_c": C, "n_t": T, "search_planes": f.P, "num_iter": args.num_iter,
              "edges": int(f.n_edges_host.sum()), "bitmap_words": f.bitmap_words, "unique": unique, "alive": alive,
              "mean_perimeter": mean_perimeter, "ring_len": len(hp.nat.circle_points(proc.min_r, True)),
              "markers": markers_local, "mean_disk": 600, "L": proc.L}

@@ -40,6 +40,8 @@ extern "C" {
 
 /* value stored in the angle map for "not an edge pixel" (angles are in [-pi, pi]) */
 #define MG_NO_EDGE 100.0f
+/* score written for circles that the exact prefilter proved to be below min_roundness */
+#define MG_SCORE_SKIPPED (-2.0f)
 
 /* Canny map values (OpenCV's): 0 weak candidate, 1 not an edge, 2 strong edge */
 
@@ -68,23 +70,24 @@ int mg_perimeter_table(int min_r, int max_r, int32_t* out_rc, double* out_expect
  * ---------------------------------------------------------------------------------- */
 
 /* Pass 1: the two global maxima M1 = max(clip(x - dark, 0)) and M2 = max(clip(x - dark, 0) / flat)
- * over ALL n_tiles * ty * tx elements (float64, NaN-propagating).
- * d_max2 is double[2], pre-initialised by the caller to -inf.
- * dark/flat: scalar when d_dark / d_flat is NULL, else a (ty, tx) image of type
- * dark_dtype / flat_dtype (MG_F32 or MG_F64) broadcast over tiles. */
-int mg_flatfield_max(const void* d_tiles, int dtype, int64_t n_tiles, int ty, int tx,
+ * (float64, NaN-propagating) of each of n_groups equal groups of tiles (n_groups = 1: the
+ * reference's single-assay semantics, the maxima span the whole array; n_groups = number of
+ * assays when every time slice is its own assay).  d_max2 is double[n_groups][2], pre-initialised
+ * by the caller to -inf.  dark/flat: scalar when d_dark / d_flat is NULL, else a (ty, tx) image
+ * of type dark_dtype / flat_dtype (MG_F32 or MG_F64) broadcast over tiles. */
+int mg_flatfield_max(const void* d_tiles, int dtype, int64_t n_tiles, int n_groups, int ty, int tx,
                      double dark, const void* d_dark, int dark_dtype,
                      double flat, const void* d_flat, int flat_dtype,
                      double* d_max2, void* stream);
 
 /* Pass 2, fused with the stitch crop/concat: out[p, R*hy, Cc*hx] in the input dtype,
- * value = trunc(((clip(x - dark, 0) / flat) * M1) / M2) with M1, M2 read from d_max2.
+ * value = trunc(((clip(x - dark, 0) / flat) * M1) / M2) with M1, M2 = d_max2[p / planes_per_group].
  * Tiles are laid out (plane, tile_row, tile_col, ty, tx); hy = ty - overlap etc.
  * If apply_flatfield == 0 this is the pure stitch copy (any dtype, d_max2 unused).
  * d_minmax (optional, double[n_planes][2] pre-initialised to {+inf, -inf}) receives the
  * per-plane min/max of the values written (feeds to_uint8, utils.py:24-26). */
 int mg_flatfield_apply_stitch(const void* d_tiles, int dtype, int64_t n_planes, int n_tile_rows, int n_tile_cols,
-                              int ty, int tx, int overlap, int apply_flatfield,
+                              int ty, int tx, int overlap, int apply_flatfield, int planes_per_group,
                               double dark, const void* d_dark, int dark_dtype,
                               double flat, const void* d_flat, int flat_dtype,
                               const double* d_max2, void* d_image, double* d_minmax, void* stream);
@@ -120,62 +123,90 @@ int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_
 
 /* One sweep of 8-connected hysteresis (tile-local fixed point + halo exchange through
  * global memory).  d_changed[n_planes] is incremented for planes that changed; call until
- * a sweep leaves it at zero. */
-int mg_canny_hysteresis(uint8_t* d_map, int n_planes, int h, int w, uint32_t* d_changed, void* stream);
+ * a sweep leaves it at zero.  Optional active-tile tracking: d_flags_in / d_flags_out are
+ * uint8[n_planes][tiles_y][tiles_x] (mg_hysteresis_tiles); a tile is skipped unless it or one of
+ * its 8 neighbours set its flag in the previous sweep; d_flags_out (pre-zeroed) receives this
+ * sweep's flags.  Pass d_flags_in = NULL for the first sweep. */
+int mg_canny_hysteresis(uint8_t* d_map, int n_planes, int h, int w, uint32_t* d_changed,
+                        const uint8_t* d_flags_in, uint8_t* d_flags_out, void* stream);
+int mg_hysteresis_tiles(int h, int w, int* tiles_x, int* tiles_y);
 
-/* Finalise: map -> {0,1} edge map in place (utils.py:142), angle map (float32
- * atan2(dy, dx) at edge pixels, MG_NO_EDGE elsewhere; utils.py:170) and the per-cell
- * edge counts of grid_array (utils.py:351-357): d_cell_counts[n_planes][gr*gc] int32,
- * pre-zeroed, gr = ceil(h / grid), gc = ceil(w / grid). */
-int mg_edges_finalize(uint8_t* d_map, const uint8_t* d_blur, int n_planes, int h, int w, int grid,
-                      float* d_angle, int32_t* d_cell_counts, void* stream);
+/* Finalise the Canny map (edge = value 2, utils.py:142) into the edge bitmap
+ * d_edge_bits[n_planes][words_per_plane] (bit i of word k <-> linear pixel 32 k + i;
+ * words_per_plane even, >= ceil(h w / 32)).  write_bytes != 0 also rewrites d_map in place as the
+ * {0,1} byte map; d_angle (optional) gets MG_NO_EDGE at non-edge pixels -- both only needed by
+ * tests/inspection (edge pixels of the angle map are written by mg_edge_angles). */
+int mg_edges_finalize(uint8_t* d_map, const uint8_t* d_blur, int n_planes, int h, int w, uint32_t* d_edge_bits,
+                      int64_t words_per_plane, int write_bytes, float* d_angle, void* stream);
 
-/* grid_array (utils.py:359-377): exclusive scan of the cell counts (d_cell_starts, and
- * d_num_edges[n_planes]) and the cell-major / row-major-inside-cell coordinate list
- * d_coords[n_planes][coord_cap][2] (row, col) int32. */
-int mg_edge_grid(const uint8_t* d_edges, int n_planes, int h, int w, int grid, const int32_t* d_cell_counts,
-                 int32_t* d_cell_starts, int32_t* d_num_edges, int32_t* d_coords, int64_t coord_cap, void* stream);
+/* grid_array (utils.py:347-377) from the bitmap, in two phases so that the caller can size the
+ * coordinate list: d_coords == NULL computes d_cell_counts / d_cell_starts [n_planes][gr*gc]
+ * (gr = ceil(h / grid), gc = ceil(w / grid)) and d_num_edges[n_planes]; with d_coords the
+ * cell-major / row-major-inside-cell list d_coords[n_planes][coord_cap][2] (row, col) is filled. */
+int mg_edge_grid(const uint32_t* d_edge_bits, int64_t words_per_plane, int n_planes, int h, int w, int grid,
+                 int32_t* d_cell_counts, int32_t* d_cell_starts, int32_t* d_num_edges, int32_t* d_coords,
+                 int64_t coord_cap, void* stream);
+
+/* float32 gradient angle arctan2(dy, dx) (utils.py:118-119, 170) at every edge pixel of the
+ * compact list, evaluated in float64 and rounded once: d_angle[n_planes][h][w] is written at
+ * edge pixels only. */
+int mg_edge_angles(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_coords, int64_t coord_cap,
+                   const int32_t* d_num_edges, float* d_angle, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * A8-A11 RANSAC circle candidates, scoring, greedy NMS (utils.py:145-199, 225-344)
  * ---------------------------------------------------------------------------------- */
+
+/* Layout of the circle de-duplication bitmap: centres are binned into 64 x 64 tiles of the padded
+ * centre grid (row + max_r, col + max_r); every (tile, radius) pair owns one 4096-bit "layer"
+ * (bit = (row_in_tile << 6) | col_in_tile); layers are ordered (tile_row, tile_col, r).
+ * n_layers = tile_rows * tile_cols * (max_r - min_r + 1), bitmap_words = 128 * n_layers. */
+int mg_dedup_layout(int h, int w, int min_r, int max_r, int* n_tile_rows, int* n_tile_cols, int64_t* n_layers,
+                    int64_t* bitmap_words);
 
 /* candidate_circles (utils.py:295-344) with the build's counter-based RNG (the reference
  * is unseeded): iteration i of plane p draws three 32-bit uniforms from
  * splitmix64(seed[p] + (3 i + k + 1) * golden) >> 32, p0 = coords[u0 * E >> 32],
  * p1, p2 = p0's cell list[u * count >> 32].  Then steps 4 of filter_circles
  * (utils.py:157-166): radius window, round-half-even, off-image rejection.  Survivors set
- * their bit in d_bitmap[n_planes][bitmap_words] (layout: ((r - min_r) * HH + row + max_r) * WW
- * + col + max_r, HH = h + 2 max_r, WW = w + 2 max_r), which de-duplicates them.
+ * their bit in d_bitmap[n_planes][bitmap_words] (mg_dedup_layout), which de-duplicates them:
+ * a circle's score depends only on (row, col, r).
  * d_raw (optional, float32 [n_planes][num_iter][3]) receives the unfiltered circles. */
 int mg_candidate_circles(const int32_t* d_coords, int64_t coord_cap, const int32_t* d_cell_starts,
                          const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w,
                          int grid, const uint64_t* d_seeds, int64_t num_iter, int min_r, int max_r,
                          uint32_t* d_bitmap, int64_t bitmap_words, float* d_raw, void* stream);
 
-/* Ordered compaction of the bitmap into the unique circle list, sorted by (r, row, col):
- * d_circles[n_planes][circle_cap][3] int32, d_num_circles[n_planes].  Clears the bitmap
- * words it consumes (the bitmap is all-zero again afterwards).  d_block_counts is scratch
- * of n_planes * ceil(bitmap_words / 1024) uint32. */
+/* Ordered compaction of the bitmap into the unique circle list in the build's canonical order
+ * (tile_row, tile_col, r, row, col): d_circles[n_planes][circle_cap][3] int32 (row, col, r),
+ * d_num_circles[n_planes], and d_layer_offsets[n_planes][n_layers + 1] (start of every layer in
+ * the list; the last entry is the total).  Clears the bitmap words it consumes (the bitmap is
+ * all-zero again afterwards). */
 int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, int n_planes, int h, int w, int min_r,
-                         int max_r, uint32_t* d_block_counts, int32_t* d_circles, int64_t circle_cap,
+                         int max_r, int32_t* d_layer_offsets, int32_t* d_circles, int64_t circle_cap,
                          int32_t* d_num_circles, void* stream);
 
-/* mean_grad / len(perimeter) (utils.py:183-188, 225-251): float64 sequential sum in
- * perimeter order, stored float32, divided by the perimeter length in float32.  Circles
- * with score >= min_roundness (float32 compare, utils.py:191) are appended (unordered) to
+/* mean_grad / len(perimeter) (utils.py:183-188, 225-251), one workgroup per centre tile with the
+ * tile's window of the 1-bit edge map staged in LDS.
+ * Pass A (exact prefilter): every term of the sum is <= 1, so circles with fewer than
+ * min_roundness * P edge pixels on their perimeter cannot pass (they get MG_SCORE_SKIPPED when
+ * write_skipped != 0, else their score is left unwritten).
+ * Pass B: the reference's float64 sum, sequential in perimeter order, stored float32 and divided
+ * by the perimeter length in float32; d_angle holds the gradient angle at edge pixels
+ * (mg_edge_angles); per_total = number of entries of the perimeter tables.
+ * Circles with score >= min_roundness (float32 compare, utils.py:191) are appended (unordered) to
  * d_alive[n_planes][circle_cap] (indices into d_circles), d_num_alive[n_planes] pre-zeroed;
- * d_max_rc[n_planes][2] (pre-set to INT32_MIN) receives max row / max col of the alive
- * circles (the claim-grid extent of utils.py:268-270). */
-int mg_score_circles(const float* d_angle, int n_planes, int h, int w, const int32_t* d_circles,
-                     int64_t circle_cap, const int32_t* d_num_circles, int min_r, int max_r,
-                     const int32_t* d_per_rc, const double* d_per_expected, const int32_t* d_per_starts,
-                     float min_roundness, float* d_scores, int32_t* d_alive, int32_t* d_num_alive,
-                     int32_t* d_max_rc, void* stream);
+ * d_max_rc[n_planes][2] (pre-set to INT32_MIN) receives max row / max col of the alive circles
+ * (the claim-grid extent of utils.py:268-270). */
+int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, int64_t words_per_plane, int n_planes, int h,
+                     int w, const int32_t* d_circles, int64_t circle_cap, const int32_t* d_layer_offsets, int min_r,
+                     int max_r, const int32_t* d_per_rc, const double* d_per_expected, const int32_t* d_per_starts,
+                     int per_total, float min_roundness, int write_skipped, float* d_scores, int32_t* d_alive,
+                     int32_t* d_num_alive, int32_t* d_max_rc, void* stream);
 
 /* One round of the parallel-but-equivalent greedy suppression of filter_neighbors
  * (utils.py:254-292).  Priority = (score desc, index in d_circles asc) -- the build's
- * canonical tie order.  d_grid[n_planes][grid_cap] uint64 claim grid pre-set to all-ones;
+ * canonical tie order (tile_row, tile_col, r, row, col).  d_grid[n_planes][grid_cap] uint64 claim grid pre-set to all-ones;
  * d_state[n_planes][circle_cap] uint8 (0 undecided, 1 kept, 2 dropped) pre-zeroed for
  * alive circles; d_undecided[n_planes] is overwritten with the number still undecided.
  * Ring = 4-connected perimeter of radius min_dist (d_ring_rc, ring_len); indices wrap

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libmagnify_hip.so")
 
 MG_U8, MG_U16, MG_F32, MG_F64 = 0, 1, 2, 3
 MG_NO_EDGE = 100.0
+MG_SCORE_SKIPPED = -2.0
 
 _p = C.c_void_p
 _i = C.c_int
@@ -30,18 +31,21 @@ PROTOTYPES = {
     "mg_disk_halfwidths": [_i, _p],
     "mg_cv_disk_halfwidths": [_i, _p],
     "mg_perimeter_table": [_i, _i, _p, _p, _p, _i],
-    "mg_flatfield_max": [_p, _i, _l, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p],
-    "mg_flatfield_apply_stitch": [_p, _i, _l, _i, _i, _i, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p, _p, _p],
+    "mg_flatfield_max": [_p, _i, _l, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p],
+    "mg_flatfield_apply_stitch": [_p, _i, _l, _i, _i, _i, _i, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p, _p, _p],
     "mg_plane_minmax": [_p, _i, _i, _l, _i, _i, _l, _p, _p],
     "mg_to_uint8_blur": [_p, _i, _i, _l, _i, _i, _l, _p, _p, _p, _p],
     "mg_scharr_hist": [_p, _i, _i, _i, _p, _i, _i, _p, _p],
     "mg_canny_nms": [_p, _i, _i, _i, _p, _p, _p],
-    "mg_canny_hysteresis": [_p, _i, _i, _i, _p, _p],
-    "mg_edges_finalize": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
-    "mg_edge_grid": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p],
+    "mg_canny_hysteresis": [_p, _i, _i, _i, _p, _p, _p, _p],
+    "mg_hysteresis_tiles": [_i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "mg_edges_finalize": [_p, _p, _i, _i, _i, _p, _l, _i, _p, _p],
+    "mg_edge_grid": [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p],
     "mg_candidate_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _p, _p],
     "mg_bitmap_to_circles": [_p, _l, _i, _i, _i, _i, _i, _p, _p, _l, _p, _p],
-    "mg_score_circles": [_p, _i, _i, _i, _p, _l, _p, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p],
+    "mg_edge_angles": [_p, _i, _i, _i, _p, _l, _p, _p, _p],
+    "mg_dedup_layout": [_i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    "mg_score_circles": [_p, _p, _l, _i, _i, _i, _p, _l, _p, _i, _i, _p, _p, _p, _i, _f, _i, _p, _p, _p, _p, _p],
     "mg_nms_round": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _p],
     "mg_collect_circles": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p],
     "mg_circle_labels": [_p, _l, _p, _i, _i, _i, _p, _i, _p, _p],
@@ -127,3 +131,11 @@ def perimeter_table(min_r: int, max_r: int):
     expected = np.empty(total, dtype=np.float64)
     lib().mg_perimeter_table(int(min_r), int(max_r), rc.ctypes.data, expected.ctypes.data, starts.ctypes.data, total)
     return rc, expected, starts
+
+
+def dedup_layout(h: int, w: int, min_r: int, max_r: int):
+    """(tile_rows, tile_cols, n_layers, bitmap_words) of the circle de-duplication bitmap."""
+    a, b = C.c_int(0), C.c_int(0)
+    n, words = C.c_int64(0), C.c_int64(0)
+    check(lib().mg_dedup_layout(h, w, min_r, max_r, C.byref(a), C.byref(b), C.byref(n), C.byref(words)), "mg_dedup_layout")
+    return a.value, b.value, n.value, words.value

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(NT) void k_candidates(const int32_t* __restrict__ d
   const int32_t* starts = d_starts + (int64_t)plane * n_cells;
   const int32_t* counts = d_counts + (int64_t)plane * n_cells;
   const uint64_t seed = d_seeds[plane];
-  const int hh = h + 2 * max_r, ww = w + 2 * max_r;
+  const int ntc = (w + 2 * max_r + 63) >> 6, nr = max_r - min_r + 1;
   uint32_t* bitmap = d_bitmap + (int64_t)plane * bitmap_words;
   const double eps = (double)1e-20f;
   for (int64_t it = (int64_t)blockIdx.x * NT + threadIdx.x; it < num_iter; it += (int64_t)gridDim.x * NT) {
@@ -83,124 +83,199 @@ __global__ __launch_bounds__(NT) void k_candidates(const int32_t* __restrict__ d
     if (!(fabsf(rr) < 1.0e9f && fabsf(rc) < 1.0e9f)) continue;  // cannot be on the image (and NaN)
     const int ir = (int)rr, ic = (int)rc, irad = (int)rintf(rad);
     if (ir + irad < 0 || ic + irad < 0 || ir - irad >= h || ic - irad >= w) continue;
-    const int64_t bit = ((int64_t)(irad - min_r) * hh + (ir + max_r)) * ww + (ic + max_r);
+    // tile-major de-duplication bitmap: 64 x 64 tiles of the padded centre grid, one 4096-bit layer
+    // per (tile, radius); the ordered compaction then emits circles grouped by tile
+    const int pr = ir + max_r, pc = ic + max_r;
+    const int64_t layer = ((int64_t)(pr >> 6) * ntc + (pc >> 6)) * nr + (irad - min_r);
+    const int64_t bit = (layer << 12) + ((pr & 63) << 6) + (pc & 63);
     atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
   }
 }
 
 // ---- K8: bitmap -> ordered unique circle list ---------------------------------------------------
-constexpr int WORDS_PER_BLOCK = 1024;  // 4 words per thread
+// One wave per 4096-bit layer (= one radius of one 64 x 64 centre tile): lane l owns tile row l
+// (64 bits).  Emission order = (tile_row, tile_col, r, row, col): the build's canonical order.
+constexpr int TS = 64;
+constexpr int LAYER_WORDS = 128;
 
-__global__ __launch_bounds__(NT) void k_bitmap_count(const uint32_t* __restrict__ d_bitmap, int64_t bitmap_words,
-                                                     int n_blocks, uint32_t* __restrict__ d_block_counts) {
+__global__ __launch_bounds__(NT) void k_layer_count(const uint32_t* __restrict__ d_bitmap, int64_t bitmap_words,
+                                                    int n_layers, int32_t* __restrict__ d_layer_offsets) {
   const int plane = blockIdx.y;
-  const uint32_t* bm = d_bitmap + (int64_t)plane * bitmap_words;
-  const int64_t w0 = (int64_t)blockIdx.x * WORDS_PER_BLOCK + threadIdx.x * 4;
-  int c = 0;
-  if (w0 + 4 <= bitmap_words && ((reinterpret_cast<uintptr_t>(bm + w0) & 15) == 0)) {
-    const uint4 v = *reinterpret_cast<const uint4*>(bm + w0);
-    c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-  } else {
-    for (int j = 0; j < 4; ++j)
-      if (w0 + j < bitmap_words) c += __popc(bm[w0 + j]);
-  }
-  int total;
-  mg_block_exscan(c, &total);
-  if (threadIdx.x == 0) d_block_counts[(int64_t)plane * n_blocks + blockIdx.x] = (uint32_t)total;
+  const int layer = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (layer >= n_layers) return;
+  const int lane = threadIdx.x & 63;
+  const uint2 v = reinterpret_cast<const uint2*>(d_bitmap + (int64_t)plane * bitmap_words +
+                                                 (int64_t)layer * LAYER_WORDS)[lane];
+  const int c = mg_wave_sum_i32(__popc(v.x) + __popc(v.y));
+  if (lane == 0) d_layer_offsets[(int64_t)plane * (n_layers + 1) + layer] = c;
 }
 
-__global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ d_block_counts, int n_blocks,
+__global__ __launch_bounds__(1024) void k_layer_scan(int32_t* __restrict__ d_layer_offsets, int n_layers,
                                                      int32_t* __restrict__ d_num_circles, int64_t cap) {
   const int plane = blockIdx.x;
-  uint32_t* cnt = d_block_counts + (int64_t)plane * n_blocks;
+  int32_t* cnt = d_layer_offsets + (int64_t)plane * (n_layers + 1);
   int carry = 0;
-  for (int base = 0; base < n_blocks; base += 1024) {
+  for (int base = 0; base < n_layers; base += 1024) {
     const int i = base + threadIdx.x;
-    const int v = i < n_blocks ? (int)cnt[i] : 0;
+    const int v = i < n_layers ? cnt[i] : 0;
     int total;
     const int ex = mg_block_exscan(v, &total);
-    if (i < n_blocks) cnt[i] = (uint32_t)(carry + ex);
+    if (i < n_layers) cnt[i] = carry + ex;
     carry += total;
   }
-  if (threadIdx.x == 0) d_num_circles[plane] = (int32_t)min((int64_t)carry, cap);
-}
-
-__global__ __launch_bounds__(NT) void k_bitmap_emit(uint32_t* __restrict__ d_bitmap, int64_t bitmap_words, int n_blocks,
-                                                    const uint32_t* __restrict__ d_block_offsets, int h, int w,
-                                                    int min_r, int max_r, int32_t* __restrict__ d_circles,
-                                                    int64_t circle_cap) {
-  const int plane = blockIdx.y;
-  uint32_t* bm = d_bitmap + (int64_t)plane * bitmap_words;
-  const int64_t w0 = (int64_t)blockIdx.x * WORDS_PER_BLOCK + threadIdx.x * 4;
-  uint32_t v[4] = {0, 0, 0, 0};
-  int c = 0;
-  for (int j = 0; j < 4; ++j)
-    if (w0 + j < bitmap_words) {
-      v[j] = bm[w0 + j];
-      c += __popc(v[j]);
-    }
-  int total;
-  const int ex = mg_block_exscan(c, &total);
-  if (total == 0) return;
-  int64_t pos = (int64_t)d_block_offsets[(int64_t)plane * n_blocks + blockIdx.x] + ex;
-  const int hh = h + 2 * max_r, ww = w + 2 * max_r;
-  int32_t* out = d_circles + (int64_t)plane * circle_cap * 3;
-  for (int j = 0; j < 4; ++j) {
-    uint32_t bits = v[j];
-    if (bits) bm[w0 + j] = 0;  // leave the bitmap clean for the next use
-    while (bits) {
-      const int b = __ffs(bits) - 1;
-      bits &= bits - 1;
-      const int64_t idx = ((w0 + j) << 5) + b;
-      const int col = (int)(idx % ww);
-      const int64_t t = idx / ww;
-      const int row = (int)(t % hh);
-      const int rad = (int)(t / hh);
-      if (pos < circle_cap) {
-        out[3 * pos] = row - max_r;
-        out[3 * pos + 1] = col - max_r;
-        out[3 * pos + 2] = rad + min_r;
-      }
-      ++pos;
-    }
+  if (threadIdx.x == 0) {
+    cnt[n_layers] = carry;
+    d_num_circles[plane] = (int32_t)min((int64_t)carry, cap);
   }
 }
 
-// ---- K9: scoring ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_score(const float* __restrict__ d_angle, int h, int w,
-                                              const int32_t* __restrict__ d_circles, int64_t circle_cap,
-                                              const int32_t* __restrict__ d_num_circles, int min_r,
-                                              const int32_t* __restrict__ d_per_rc,
-                                              const double* __restrict__ d_per_expected,
-                                              const int32_t* __restrict__ d_per_starts, float min_roundness,
-                                              float* __restrict__ d_scores, int32_t* __restrict__ d_alive,
-                                              int32_t* __restrict__ d_num_alive, int32_t* __restrict__ d_max_rc) {
+__global__ __launch_bounds__(NT) void k_layer_emit(uint32_t* __restrict__ d_bitmap, int64_t bitmap_words, int n_layers,
+                                                   const int32_t* __restrict__ d_layer_offsets, int ntc, int nr,
+                                                   int min_r, int max_r, int32_t* __restrict__ d_circles,
+                                                   int64_t circle_cap) {
   const int plane = blockIdx.y;
-  const int n = d_num_circles[plane];
-  const float* ang = d_angle + (int64_t)plane * h * w;
+  const int layer = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (layer >= n_layers) return;
+  const int lane = threadIdx.x & 63;
+  const int32_t* lo = d_layer_offsets + (int64_t)plane * (n_layers + 1);
+  if (lo[layer + 1] == lo[layer]) return;  // empty layer (wave-uniform)
+  uint2* words = reinterpret_cast<uint2*>(d_bitmap + (int64_t)plane * bitmap_words + (int64_t)layer * LAYER_WORDS);
+  const uint2 v = words[lane];
+  uint64_t bits = ((uint64_t)v.y << 32) | v.x;
+  if (bits) words[lane] = make_uint2(0u, 0u);  // leave the bitmap clean for the next use
+  const int c = __popcll(bits);
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  int64_t pos = (int64_t)lo[layer] + incl - c;
+  const int tile = layer / nr, ri = layer - tile * nr;
+  const int row = (tile / ntc) * TS + lane - max_r, col0 = (tile % ntc) * TS - max_r;
+  int32_t* out = d_circles + (int64_t)plane * circle_cap * 3;
+  while (bits) {
+    const int b = __ffsll((unsigned long long)bits) - 1;
+    bits &= bits - 1;
+    if (pos < circle_cap) {
+      out[3 * pos] = row;
+      out[3 * pos + 1] = col0 + b;
+      out[3 * pos + 2] = min_r + ri;
+    }
+    ++pos;
+  }
+}
+
+// ---- K9: scoring, one workgroup per centre tile ------------------------------------------------------
+// All circles of a tile (centres in a 64 x 64 block, radius <= max_r) touch only the
+// (64 + 2 max_r)^2 window around it, so the window of the 1-bit edge map is staged in LDS once
+// and every perimeter test is an LDS read (the global-gather version is bound by one cache-line
+// transaction per test).
+//   pass A (exact prefilter): every term of the alignment sum is <= 1, so a circle with fewer
+//     than min_roundness * P edge pixels on its perimeter cannot reach the threshold;
+//   pass B: the reference's float64 sum in perimeter order for the survivors (block-local list),
+//     gradient angles gathered from the precomputed edge-angle map.
+__device__ __forceinline__ uint32_t bits_at(const uint32_t* __restrict__ bits, int64_t bit0, int n) {
+  const int64_t wi = bit0 >> 5;
+  const int sh = (int)(bit0 & 31);
+  uint64_t two = bits[wi];
+  if (sh + n > 32) two |= (uint64_t)bits[wi + 1] << 32;
+  const uint32_t v = (uint32_t)(two >> sh);
+  return n >= 32 ? v : (v & ((1u << n) - 1u));
+}
+
+constexpr int CHUNK = 1024;  // circles per prefilter/exact round (bounds the LDS survivor list)
+
+__global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_angle,
+                                                    const uint32_t* __restrict__ d_bits, int64_t words_per_plane,
+                                                    int h, int w, const int32_t* __restrict__ d_circles,
+                                                    int64_t circle_cap, const int32_t* __restrict__ d_layer_offsets,
+                                                    int n_layers, int nr, int ntc, int min_r, int max_r,
+                                                    const int32_t* __restrict__ d_per_rc, int per_total,
+                                                    const double* __restrict__ d_per_expected,
+                                                    const int32_t* __restrict__ d_per_starts, float min_roundness,
+                                                    int write_skipped, float* __restrict__ d_scores,
+                                                    int32_t* __restrict__ d_alive, int32_t* __restrict__ d_num_alive,
+                                                    int32_t* __restrict__ d_max_rc) {
+  extern __shared__ uint32_t lds[];
+  __shared__ int n_surv;
+  const int plane = blockIdx.y, tile = blockIdx.x;
+  const int32_t* lo = d_layer_offsets + (int64_t)plane * (n_layers + 1);
+  const int64_t first = lo[(int64_t)tile * nr];
+  const int64_t last = min((int64_t)lo[(int64_t)(tile + 1) * nr], circle_cap);
+  if (first >= last) return;
+  const int side = TS + 2 * max_r, wpr = (side + 31) >> 5;
+  uint32_t* win = lds;                                    // [side][wpr]
+  int32_t* tab = reinterpret_cast<int32_t*>(lds + side * wpr);  // packed (dr << 16) | (dc & 0xFFFF)
+  int32_t* list = tab + per_total;                        // [CHUNK]
+  const int wy0 = (tile / ntc) * TS - 2 * max_r, wx0 = (tile % ntc) * TS - 2 * max_r;
+  const uint32_t* bits = d_bits + plane * words_per_plane;
+  for (int i = threadIdx.x; i < side * wpr; i += NT) {
+    const int j = i / wpr, k = i - j * wpr;
+    const int y = wy0 + j, xs = wx0 + 32 * k;
+    uint32_t v = 0;
+    if (y >= 0 && y < h) {
+      const int x_lo = max(xs, 0), x_hi = min(xs + 32, w);
+      if (x_lo < x_hi) v = bits_at(bits, (int64_t)y * w + x_lo, x_hi - x_lo) << (x_lo - xs);
+    }
+    win[i] = v;
+  }
+  for (int i = threadIdx.x; i < per_total; i += NT) tab[i] = (d_per_rc[2 * i] << 16) | (d_per_rc[2 * i + 1] & 0xFFFF);
+  __syncthreads();
   const int32_t* circles = d_circles + (int64_t)plane * circle_cap * 3;
+  const float* ang = d_angle + (int64_t)plane * h * w;
+  float* scores = d_scores + (int64_t)plane * circle_cap;
   const double PI = 3.141592653589793;
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-    const int row = circles[3 * i], col = circles[3 * i + 1], rad = circles[3 * i + 2];
-    const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
-    double acc = 0.0;
-    for (int p = p0; p < p1; ++p) {
-      const int rr = row + d_per_rc[2 * p], cc = col + d_per_rc[2 * p + 1];
-      if (rr < 0 || rr >= h || cc < 0 || cc >= w) continue;  // zero padding: no edge (utils.py:172-174)
-      const float a = ang[(int64_t)rr * w + cc];
-      if (a == MG_NO_EDGE) continue;
-      double d = fabs((double)a - d_per_expected[p]);
-      if (d > PI) d = d - PI;
-      acc += 4.0 * fabs(d - PI / 2.0) / PI - 1.0;
+  for (int64_t chunk = first; chunk < last; chunk += CHUNK) {
+    if (threadIdx.x == 0) n_surv = 0;
+    __syncthreads();
+    for (int64_t i = chunk + threadIdx.x; i < min(chunk + CHUNK, last); i += NT) {
+      const int row = circles[3 * i], col = circles[3 * i + 1], rad = circles[3 * i + 2];
+      const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
+      const int len = p1 - p0;
+      // need: hits >= min_roundness * len - 1e-3 (margin far above any rounding of the real sum)
+      const int need = (int)ceil((double)min_roundness * len - 1e-3);
+      const int by = row - wy0, bx = col - wx0;
+      int hits = 0;
+      for (int p = p0; p < p1; ++p) {
+        const int v = tab[p];
+        const int y = by + (v >> 16), x = bx + (int)(int16_t)(v & 0xFFFF);
+        hits += (win[y * wpr + (x >> 5)] >> (x & 31)) & 1u;
+      }
+      if (hits >= need) {
+        list[atomicAdd(&n_surv, 1)] = (int32_t)(i - chunk);
+      } else if (write_skipped) {
+        scores[i] = MG_SCORE_SKIPPED;
+      }
     }
-    const float score = (float)acc / (float)(p1 - p0);
-    d_scores[(int64_t)plane * circle_cap + i] = score;
-    if (score >= min_roundness) {
-      const int k = atomicAdd(&d_num_alive[plane], 1);
-      d_alive[(int64_t)plane * circle_cap + k] = (int32_t)i;
-      atomicMax(&d_max_rc[2 * plane], row);
-      atomicMax(&d_max_rc[2 * plane + 1], col);
+    __syncthreads();
+    const int ns = n_surv;
+    for (int a = threadIdx.x; a < ns; a += NT) {
+      const int64_t i = chunk + list[a];
+      const int row = circles[3 * i], col = circles[3 * i + 1], rad = circles[3 * i + 2];
+      const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
+      const int by = row - wy0, bx = col - wx0;
+      double acc = 0.0;
+      for (int p = p0; p < p1; ++p) {
+        const int v = tab[p];
+        const int dr = v >> 16, dc = (int)(int16_t)(v & 0xFFFF);
+        const int y = by + dr, x = bx + dc;
+        if (!((win[y * wpr + (x >> 5)] >> (x & 31)) & 1u)) continue;
+        const float an = ang[(int64_t)(row + dr) * w + (col + dc)];
+        double d = fabs((double)an - d_per_expected[p]);
+        if (d > PI) d = d - PI;
+        acc += 4.0 * fabs(d - PI / 2.0) / PI - 1.0;
+      }
+      const float score = (float)acc / (float)(p1 - p0);
+      scores[i] = score;
+      if (score >= min_roundness) {
+        const int k = atomicAdd(&d_num_alive[plane], 1);
+        d_alive[(int64_t)plane * circle_cap + k] = (int32_t)i;
+        atomicMax(&d_max_rc[2 * plane], row);
+        atomicMax(&d_max_rc[2 * plane + 1], col);
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -334,8 +409,10 @@ extern "C" int mg_candidate_circles(const int32_t* d_coords, int64_t coord_cap, 
   if (!d_coords || !d_cell_starts || !d_cell_counts || !d_num_edges || !d_seeds || !d_bitmap) return MG_EINVAL;
   if (n_planes < 0 || n_planes > 65535 || h <= 0 || w <= 0 || grid <= 0 || num_iter < 0 || min_r < 0 || max_r < min_r)
     return MG_EINVAL;
-  const int64_t need_bits = (int64_t)(max_r - min_r + 1) * (h + 2 * max_r) * (w + 2 * max_r);
-  if (bitmap_words * 32 < need_bits) return MG_EINVAL;
+  int ntr_, ntc_;
+  int64_t n_layers_, need_words_;
+  if (mg_dedup_layout(h, w, min_r, max_r, &ntr_, &ntc_, &n_layers_, &need_words_) != MG_OK) return MG_EINVAL;
+  if (bitmap_words < need_words_) return MG_EINVAL;
   if (n_planes == 0 || num_iter == 0) return MG_OK;
   const int gr = (h + grid - 1) / grid, gc = (w + grid - 1) / grid;
   hipLaunchKernelGGL(k_candidates, dim3(grid_x(num_iter), n_planes), dim3(NT), 0, mg_stream(stream), d_coords,
@@ -345,40 +422,70 @@ extern "C" int mg_candidate_circles(const int32_t* d_coords, int64_t coord_cap, 
   return MG_OK;
 }
 
-extern "C" int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, int n_planes, int h, int w, int min_r,
-                                    int max_r, uint32_t* d_block_counts, int32_t* d_circles, int64_t circle_cap,
-                                    int32_t* d_num_circles, void* stream) {
-  if (!d_bitmap || !d_block_counts || !d_circles || !d_num_circles || n_planes < 0 || n_planes > 65535 ||
-      bitmap_words <= 0 || circle_cap < 0)
+extern "C" int mg_dedup_layout(int h, int w, int min_r, int max_r, int* n_tile_rows, int* n_tile_cols,
+                               int64_t* n_layers, int64_t* bitmap_words) {
+  if (h <= 0 || w <= 0 || min_r < 0 || max_r < min_r || !n_tile_rows || !n_tile_cols || !n_layers || !bitmap_words)
     return MG_EINVAL;
+  const int ntr = (h + 2 * max_r + TS - 1) / TS, ntc = (w + 2 * max_r + TS - 1) / TS;
+  *n_tile_rows = ntr;
+  *n_tile_cols = ntc;
+  *n_layers = (int64_t)ntr * ntc * (max_r - min_r + 1);
+  *bitmap_words = *n_layers * LAYER_WORDS;
+  return MG_OK;
+}
+
+extern "C" int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, int n_planes, int h, int w, int min_r,
+                                    int max_r, int32_t* d_layer_offsets, int32_t* d_circles, int64_t circle_cap,
+                                    int32_t* d_num_circles, void* stream) {
+  if (!d_bitmap || !d_layer_offsets || !d_circles || !d_num_circles || n_planes < 0 || n_planes > 65535 ||
+      circle_cap < 0)
+    return MG_EINVAL;
+  int ntr, ntc;
+  int64_t n_layers, need_words;
+  if (mg_dedup_layout(h, w, min_r, max_r, &ntr, &ntc, &n_layers, &need_words) != MG_OK) return MG_EINVAL;
+  if (bitmap_words < need_words || n_layers > 0x7FFFFFF0) return MG_EINVAL;
   if (n_planes == 0) return MG_OK;
-  const int64_t nb64 = (bitmap_words + WORDS_PER_BLOCK - 1) / WORDS_PER_BLOCK;
-  if (nb64 > 0x7FFFFFFF) return MG_EINVAL;
-  const int nb = (int)nb64;
+  const int nl = (int)n_layers, nr = max_r - min_r + 1;
   hipStream_t s = mg_stream(stream);
-  hipLaunchKernelGGL(k_bitmap_count, dim3(nb, n_planes), dim3(NT), 0, s, d_bitmap, bitmap_words, nb, d_block_counts);
+  const dim3 g((nl + 3) / 4, n_planes);
+  hipLaunchKernelGGL(k_layer_count, g, dim3(NT), 0, s, d_bitmap, bitmap_words, nl, d_layer_offsets);
   MG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_block_scan, dim3(n_planes), dim3(1024), 0, s, d_block_counts, nb, d_num_circles, circle_cap);
+  hipLaunchKernelGGL(k_layer_scan, dim3(n_planes), dim3(1024), 0, s, d_layer_offsets, nl, d_num_circles, circle_cap);
   MG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_bitmap_emit, dim3(nb, n_planes), dim3(NT), 0, s, d_bitmap, bitmap_words, nb, d_block_counts, h,
-                     w, min_r, max_r, d_circles, circle_cap);
+  hipLaunchKernelGGL(k_layer_emit, g, dim3(NT), 0, s, d_bitmap, bitmap_words, nl, d_layer_offsets, ntc, nr, min_r, max_r,
+                     d_circles, circle_cap);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
 
-extern "C" int mg_score_circles(const float* d_angle, int n_planes, int h, int w, const int32_t* d_circles,
-                                int64_t circle_cap, const int32_t* d_num_circles, int min_r, int max_r,
-                                const int32_t* d_per_rc, const double* d_per_expected, const int32_t* d_per_starts,
-                                float min_roundness, float* d_scores, int32_t* d_alive, int32_t* d_num_alive,
-                                int32_t* d_max_rc, void* stream) {
-  if (!d_angle || !d_circles || !d_num_circles || !d_per_rc || !d_per_expected || !d_per_starts || !d_scores ||
-      !d_alive || !d_num_alive || !d_max_rc)
+extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, int64_t words_per_plane,
+                                int n_planes, int h, int w, const int32_t* d_circles, int64_t circle_cap,
+                                const int32_t* d_layer_offsets, int min_r, int max_r, const int32_t* d_per_rc,
+                                const double* d_per_expected, const int32_t* d_per_starts, int per_total,
+                                float min_roundness, int write_skipped, float* d_scores, int32_t* d_alive,
+                                int32_t* d_num_alive, int32_t* d_max_rc, void* stream) {
+  if (!d_angle || !d_edge_bits || !d_circles || !d_layer_offsets || !d_per_rc || !d_per_expected || !d_per_starts ||
+      !d_scores || !d_alive || !d_num_alive || !d_max_rc)
     return MG_EINVAL;
-  if (n_planes < 0 || n_planes > 65535 || max_r < min_r) return MG_EINVAL;
+  if (n_planes < 0 || n_planes > 65535 || per_total <= 0 || max_r > 16000) return MG_EINVAL;
+  int ntr, ntc;
+  int64_t n_layers, words;
+  if (mg_dedup_layout(h, w, min_r, max_r, &ntr, &ntc, &n_layers, &words) != MG_OK) return MG_EINVAL;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
-  hipLaunchKernelGGL(k_score, dim3(grid_x(circle_cap), n_planes), dim3(NT), 0, mg_stream(stream), d_angle, h, w,
-                     d_circles, circle_cap, d_num_circles, min_r, d_per_rc, d_per_expected, d_per_starts,
-                     min_roundness, d_scores, d_alive, d_num_alive, d_max_rc);
+  const int side = TS + 2 * max_r, wpr = (side + 31) >> 5;
+  const size_t lds_bytes = ((size_t)side * wpr + per_total + CHUNK) * 4;
+  if (lds_bytes > 150 * 1024) return MG_EINVAL;  // radii beyond ~300 px: outside this build's envelope
+  static bool attr_set = false;
+  if (lds_bytes > 48 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_tiles), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            150 * 1024) != hipSuccess)
+      return MG_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_score_tiles, dim3(ntr * ntc, n_planes), dim3(NT), lds_bytes, mg_stream(stream), d_angle,
+                     d_edge_bits, words_per_plane, h, w, d_circles, circle_cap, d_layer_offsets, (int)n_layers,
+                     max_r - min_r + 1, ntc, min_r, max_r, d_per_rc, per_total, d_per_expected, d_per_starts,
+                     min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -2,6 +2,7 @@
 // Built with -ffp-contract=off: float64 sequences must round exactly like NumPy's.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "../../include/magnify_hip.h"
@@ -123,4 +124,17 @@ __device__ __forceinline__ int mg_block_exscan(int v, int* total) {
   *total = s_total;
   __syncthreads();
   return res;
+}
+
+// float32 gradient angle at an edge pixel: Scharr on the blurred image (BORDER_REFLECT_101),
+// arctan2(dy, dx) evaluated in float64 and rounded once (utils.py:118-119, 170).
+__device__ __forceinline__ float mg_edge_angle(const uint8_t* __restrict__ pb, int h, int w, int y, int x) {
+  const int ym = mg_reflect101(y - 1, h), yp = mg_reflect101(y + 1, h);
+  const int xm = mg_reflect101(x - 1, w), xp = mg_reflect101(x + 1, w);
+  const int a = pb[(int64_t)ym * w + xm], b = pb[(int64_t)ym * w + x], c = pb[(int64_t)ym * w + xp];
+  const int d = pb[(int64_t)y * w + xm], f = pb[(int64_t)y * w + xp];
+  const int g = pb[(int64_t)yp * w + xm], hh = pb[(int64_t)yp * w + x], ii = pb[(int64_t)yp * w + xp];
+  const int dx = 3 * (c - a) + 10 * (f - d) + 3 * (ii - g);
+  const int dy = 3 * (g - a) + 10 * (hh - b) + 3 * (ii - c);
+  return (float)atan2((double)dy, (double)dx);
 }

@@ -228,11 +228,25 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
 
 // ---- K4: hysteresis sweep ------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_hysteresis(uint8_t* __restrict__ d_map, int h, int w,
-                                                   uint32_t* __restrict__ d_changed) {
+                                                   uint32_t* __restrict__ d_changed,
+                                                   const uint8_t* __restrict__ d_flags_in,
+                                                   uint8_t* __restrict__ d_flags_out) {
   constexpr int LS = TW + 4;
   __shared__ uint8_t t[TH + 2][LS];
   const int plane = blockIdx.z;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+  const int ntx = gridDim.x, nty = gridDim.y;
+  if (d_flags_in) {
+    // A tile can only gain edges if it or one of its 8 neighbours changed in the previous sweep.
+    const uint8_t* f = d_flags_in + (int64_t)plane * ntx * nty;
+    bool active = false;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int bx = (int)blockIdx.x + dx, by = (int)blockIdx.y + dy;
+        if (bx >= 0 && bx < ntx && by >= 0 && by < nty) active |= f[by * ntx + bx] != 0;
+      }
+    if (!active) return;
+  }
   uint8_t* pm = d_map + (int64_t)plane * h * w;
   int has_weak = 0, has_strong = 0;
   for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += NT) {
@@ -269,39 +283,90 @@ __global__ __launch_bounds__(NT) void k_hysteresis(uint8_t* __restrict__ d_map, 
   } while (again);
   for (int rr = 0; rr < ROWS_PER_THREAD; ++rr)
     if (mine & (1u << rr)) pm[(int64_t)(ty0 + r0 - 1 + rr) * w + (tx0 + c - 1)] = 2;
-  if (__syncthreads_or(mine != 0) && threadIdx.x == 0) atomicAdd(&d_changed[plane], 1u);
-}
-
-// ---- K5: finalise: {0,1} edges, angle map, cell counts ---------------------------------------
-__global__ __launch_bounds__(NT) void k_edges_finalize(uint8_t* __restrict__ d_map, const uint8_t* __restrict__ d_blur,
-                                                       int h, int w, int grid, int gc, int n_cells,
-                                                       float* __restrict__ d_angle, int32_t* __restrict__ d_counts) {
-  const int plane = blockIdx.y;
-  const int64_t npix = (int64_t)h * w;
-  uint8_t* pm = d_map + plane * npix;
-  const uint8_t* pb = d_blur + plane * npix;
-  float* pa = d_angle ? d_angle + plane * npix : nullptr;
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < npix; i += (int64_t)gridDim.x * NT) {
-    const bool e = pm[i] == 2;
-    pm[i] = e ? 1 : 0;
-    float ang = MG_NO_EDGE;
-    if (e) {
-      const int y = (int)(i / w), x = (int)(i - (int64_t)y * w);
-      const int ym = mg_reflect101(y - 1, h), yp = mg_reflect101(y + 1, h);
-      const int xm = mg_reflect101(x - 1, w), xp = mg_reflect101(x + 1, w);
-      const int a = pb[(int64_t)ym * w + xm], b = pb[(int64_t)ym * w + x], c = pb[(int64_t)ym * w + xp];
-      const int d = pb[(int64_t)y * w + xm], f = pb[(int64_t)y * w + xp];
-      const int g = pb[(int64_t)yp * w + xm], hh = pb[(int64_t)yp * w + x], ii = pb[(int64_t)yp * w + xp];
-      const int dx = 3 * (c - a) + 10 * (f - d) + 3 * (ii - g);
-      const int dy = 3 * (g - a) + 10 * (hh - b) + 3 * (ii - c);
-      ang = (float)atan2((double)dy, (double)dx);  // correctly rounded float32 arctan2 (utils.py:170)
-      if (d_counts) atomicAdd(&d_counts[(int64_t)plane * n_cells + (y / grid) * gc + (x / grid)], 1);
-    }
-    if (pa) pa[i] = ang;
+  if (__syncthreads_or(mine != 0) && threadIdx.x == 0) {
+    atomicAdd(&d_changed[plane], 1u);
+    if (d_flags_out) d_flags_out[(int64_t)plane * ntx * nty + blockIdx.y * ntx + blockIdx.x] = 1;
   }
 }
 
-// ---- K6: grid_array: scan of the cell counts, then ordered coordinate fill -------------------
+// ---- K5: finalise: edge bitmap (+ optional {0,1} byte map and angle map) ----------------------
+// One thread owns 16 consecutive pixels (one 16-byte load of the Canny map); a pair of lanes
+// forms one 32-bit word of the bitmap (bit i of word k <-> linear pixel 32 k + i).
+__global__ __launch_bounds__(NT) void k_edges_finalize(uint8_t* __restrict__ d_map, const uint8_t* __restrict__ d_blur,
+                                                       int h, int w, int64_t words_per_plane,
+                                                       uint32_t* __restrict__ d_bits, int write_bytes,
+                                                       float* __restrict__ d_angle) {
+  const int plane = blockIdx.y;
+  const int64_t npix = (int64_t)h * w;
+  uint8_t* pm = d_map + plane * npix;
+  uint32_t* bits = d_bits + plane * words_per_plane;
+  float* pa = d_angle ? d_angle + plane * npix : nullptr;
+  const int64_t n_chunks = (npix + 15) / 16;
+  const int64_t n_iter = (n_chunks + (int64_t)gridDim.x * NT - 1) / ((int64_t)gridDim.x * NT);
+  for (int64_t it = 0; it < n_iter; ++it) {
+    const int64_t chunk = (it * gridDim.x + blockIdx.x) * NT + threadIdx.x;  // all lanes stay in the loop
+    const int64_t i0 = chunk * 16;
+    uint32_t m16 = 0;
+    if (i0 < npix) {
+      uint8_t v[16];
+      if (i0 + 16 <= npix && ((reinterpret_cast<uintptr_t>(pm + i0) & 15) == 0)) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(pm + i0);
+        __builtin_memcpy(v, &raw, 16);
+      } else {
+        for (int j = 0; j < 16; ++j) v[j] = (i0 + j < npix) ? pm[i0 + j] : 1;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) m16 |= (uint32_t)(v[j] == 2) << j;
+      if (write_bytes) {
+        uint8_t o[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j] = (m16 >> j) & 1;
+        if (i0 + 16 <= npix && ((reinterpret_cast<uintptr_t>(pm + i0) & 15) == 0)) {
+          uint4 raw;
+          __builtin_memcpy(&raw, o, 16);
+          *reinterpret_cast<uint4*>(pm + i0) = raw;
+        } else {
+          for (int j = 0; j < 16 && i0 + j < npix; ++j) pm[i0 + j] = o[j];
+        }
+      }
+      if (pa) {  // inspection only: mark non-edge pixels (edge pixels are written by mg_edge_angles)
+        for (int j = 0; j < 16 && i0 + j < npix; ++j)
+          if (!((m16 >> j) & 1)) pa[i0 + j] = MG_NO_EDGE;
+      }
+    }
+    const uint32_t hi = (uint32_t)__shfl_down((int)m16, 1);
+    if ((threadIdx.x & 1) == 0 && i0 < npix) bits[chunk >> 1] = m16 | (hi << 16);
+  }
+}
+
+// ---- K6: grid_array from the bitmap: per-cell counts, scan, ordered coordinate fill -------------
+__device__ __forceinline__ uint32_t row_bits(const uint32_t* __restrict__ bits, int64_t bit0, int n) {
+  // n (<= 32) consecutive bits starting at linear bit index bit0
+  const int64_t wi = bit0 >> 5;
+  const int sh = (int)(bit0 & 31);
+  uint64_t two = bits[wi];
+  if (sh + n > 32) two |= (uint64_t)bits[wi + 1] << 32;
+  const uint32_t v = (uint32_t)(two >> sh);
+  return n >= 32 ? v : (v & ((1u << n) - 1u));
+}
+
+__global__ __launch_bounds__(NT) void k_cell_count(const uint32_t* __restrict__ d_bits, int64_t words_per_plane, int h,
+                                                   int w, int grid, int gc, int n_cells,
+                                                   int32_t* __restrict__ d_counts) {
+  const int plane = blockIdx.y;
+  const int cell = blockIdx.x * NT + threadIdx.x;
+  if (cell >= n_cells) return;
+  const uint32_t* bits = d_bits + plane * words_per_plane;
+  const int cr = cell / gc, cc = cell - cr * gc;
+  const int y0 = cr * grid, x0 = cc * grid;
+  const int ch = min(grid, h - y0), cw = min(grid, w - x0);
+  int cnt = 0;
+  for (int r = 0; r < ch; ++r)
+    for (int c0 = 0; c0 < cw; c0 += 32)
+      cnt += __popc(row_bits(bits, (int64_t)(y0 + r) * w + x0 + c0, min(32, cw - c0)));
+  d_counts[(int64_t)plane * n_cells + cell] = cnt;
+}
+
 __global__ __launch_bounds__(1024) void k_cell_scan(const int32_t* __restrict__ d_counts, int n_cells,
                                                     int32_t* __restrict__ d_starts, int32_t* __restrict__ d_num_edges) {
   const int plane = blockIdx.x;
@@ -319,38 +384,44 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const int32_t* __restrict__ 
   if (threadIdx.x == 0) d_num_edges[plane] = carry;
 }
 
-__global__ __launch_bounds__(NT) void k_cell_fill(const uint8_t* __restrict__ d_edges, int h, int w, int grid, int gc,
-                                                  int n_cells, const int32_t* __restrict__ d_starts,
-                                                  int32_t* __restrict__ d_coords, int64_t coord_cap) {
+__global__ __launch_bounds__(NT) void k_cell_fill(const uint32_t* __restrict__ d_bits, int64_t words_per_plane, int h,
+                                                  int w, int grid, int gc, int n_cells,
+                                                  const int32_t* __restrict__ d_starts, int32_t* __restrict__ d_coords,
+                                                  int64_t coord_cap) {
   const int plane = blockIdx.y;
-  const int cell = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  const int cell = blockIdx.x * NT + threadIdx.x;
   if (cell >= n_cells) return;
-  const int lane = threadIdx.x & 63;
+  const uint32_t* bits = d_bits + plane * words_per_plane;
   const int cr = cell / gc, cc = cell - cr * gc;
   const int y0 = cr * grid, x0 = cc * grid;
   const int ch = min(grid, h - y0), cw = min(grid, w - x0);
-  const uint8_t* pe = d_edges + (int64_t)plane * h * w;
-  int32_t* out = d_coords + (int64_t)plane * coord_cap * 2;
-  int pos = d_starts[(int64_t)plane * n_cells + cell];
-  const int n = ch * cw;
-  for (int base = 0; base < n; base += 64) {
-    const int p = base + lane;
-    int y = 0, x = 0;
-    bool e = false;
-    if (p < n) {
-      y = y0 + p / cw;
-      x = x0 + p % cw;
-      e = pe[(int64_t)y * w + x] != 0;
-    }
-    const unsigned long long ballot = __ballot(e);
-    if (e) {
-      const int k = pos + __popcll(ballot & ((1ull << lane) - 1ull));
-      if (k < coord_cap) {
-        out[2 * (int64_t)k] = y;
-        out[2 * (int64_t)k + 1] = x;
+  int2* out = reinterpret_cast<int2*>(d_coords + (int64_t)plane * coord_cap * 2);
+  int64_t pos = d_starts[(int64_t)plane * n_cells + cell];
+  for (int r = 0; r < ch; ++r)
+    for (int c0 = 0; c0 < cw; c0 += 32) {
+      uint32_t v = row_bits(bits, (int64_t)(y0 + r) * w + x0 + c0, min(32, cw - c0));
+      while (v) {
+        const int b = __ffs(v) - 1;
+        v &= v - 1;
+        if (pos < coord_cap) out[pos] = make_int2(y0 + r, x0 + c0 + b);
+        ++pos;
       }
     }
-    pos += __popcll(ballot);
+}
+
+// ---- K6b: gradient angle at every edge pixel (thread per entry of the compact edge list) --------
+__global__ __launch_bounds__(NT) void k_edge_angles(const uint8_t* __restrict__ d_blur, int h, int w,
+                                                    const int32_t* __restrict__ d_coords, int64_t coord_cap,
+                                                    const int32_t* __restrict__ d_num_edges,
+                                                    float* __restrict__ d_angle) {
+  const int plane = blockIdx.y;
+  const int n = min((int64_t)d_num_edges[plane], coord_cap);
+  const uint8_t* pb = d_blur + (int64_t)plane * h * w;
+  const int2* co = reinterpret_cast<const int2*>(d_coords + (int64_t)plane * coord_cap * 2);
+  float* pa = d_angle + (int64_t)plane * h * w;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    const int2 yx = co[i];
+    pa[(int64_t)yx.x * w + yx.y] = mg_edge_angle(pb, h, w, yx.x, yx.y);
   }
 }
 
@@ -415,44 +486,74 @@ extern "C" int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, c
   return MG_OK;
 }
 
-extern "C" int mg_canny_hysteresis(uint8_t* d_map, int n_planes, int h, int w, uint32_t* d_changed, void* stream) {
+extern "C" int mg_canny_hysteresis(uint8_t* d_map, int n_planes, int h, int w, uint32_t* d_changed,
+                                   const uint8_t* d_flags_in, uint8_t* d_flags_out, void* stream) {
   if (!d_map || !d_changed || n_planes < 0 || h < 0 || w < 0) return MG_EINVAL;
   if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
   const dim3 g = tile_grid(h, w, n_planes);
   if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
-  hipLaunchKernelGGL(k_hysteresis, g, dim3(NT), 0, mg_stream(stream), d_map, h, w, d_changed);
+  hipLaunchKernelGGL(k_hysteresis, g, dim3(NT), 0, mg_stream(stream), d_map, h, w, d_changed, d_flags_in, d_flags_out);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
 
-extern "C" int mg_edges_finalize(uint8_t* d_map, const uint8_t* d_blur, int n_planes, int h, int w, int grid,
-                                 float* d_angle, int32_t* d_cell_counts, void* stream) {
-  if (!d_map || !d_blur || n_planes < 0 || h < 0 || w < 0 || grid <= 0 || n_planes > 65535) return MG_EINVAL;
-  if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
-  const int gr = (h + grid - 1) / grid, gc = (w + grid - 1) / grid;
+extern "C" int mg_hysteresis_tiles(int h, int w, int* tiles_x, int* tiles_y) {
+  if (!tiles_x || !tiles_y) return MG_EINVAL;
+  *tiles_x = (w + TW - 1) / TW;
+  *tiles_y = (h + TH - 1) / TH;
+  return MG_OK;
+}
+
+extern "C" int mg_edges_finalize(uint8_t* d_map, const uint8_t* d_blur, int n_planes, int h, int w,
+                                 uint32_t* d_edge_bits, int64_t words_per_plane, int write_bytes, float* d_angle,
+                                 void* stream) {
+  if (!d_map || !d_blur || !d_edge_bits || n_planes < 0 || h < 0 || w < 0 || n_planes > 65535) return MG_EINVAL;
   const int64_t npix = (int64_t)h * w;
-  const int bx = (int)std::min<int64_t>((npix + NT - 1) / NT, 4096);
-  hipLaunchKernelGGL(k_edges_finalize, dim3(bx, n_planes), dim3(NT), 0, mg_stream(stream), d_map, d_blur, h, w, grid,
-                     gc, gr * gc, d_angle, d_cell_counts);
+  if (words_per_plane * 32 < ((npix + 31) / 32) * 32 || (words_per_plane & 1)) return MG_EINVAL;
+  if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
+  const int64_t n_chunks = (npix + 15) / 16;
+  const int bx = (int)std::min<int64_t>((n_chunks + NT - 1) / NT, 2048);
+  hipLaunchKernelGGL(k_edges_finalize, dim3(bx, n_planes), dim3(NT), 0, mg_stream(stream), d_map, d_blur, h, w,
+                     words_per_plane, d_edge_bits, write_bytes, d_angle);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
 
-extern "C" int mg_edge_grid(const uint8_t* d_edges, int n_planes, int h, int w, int grid, const int32_t* d_cell_counts,
-                            int32_t* d_cell_starts, int32_t* d_num_edges, int32_t* d_coords, int64_t coord_cap,
-                            void* stream) {
-  if (!d_edges || !d_cell_counts || !d_cell_starts || !d_num_edges || !d_coords || n_planes < 0 || grid <= 0 ||
-      coord_cap < 0 || n_planes > 65535)
+extern "C" int mg_edge_grid(const uint32_t* d_edge_bits, int64_t words_per_plane, int n_planes, int h, int w, int grid,
+                            int32_t* d_cell_counts, int32_t* d_cell_starts, int32_t* d_num_edges, int32_t* d_coords,
+                            int64_t coord_cap, void* stream) {
+  if (!d_edge_bits || !d_cell_counts || !d_cell_starts || !d_num_edges || n_planes < 0 || grid <= 0 || coord_cap < 0 ||
+      n_planes > 65535)
     return MG_EINVAL;
   if (n_planes == 0) return MG_OK;
   const int gr = (h + grid - 1) / grid, gc = (w + grid - 1) / grid, n_cells = gr * gc;
   hipStream_t s = mg_stream(stream);
-  hipLaunchKernelGGL(k_cell_scan, dim3(n_planes), dim3(1024), 0, s, d_cell_counts, n_cells, d_cell_starts, d_num_edges);
-  MG_CHECK_LAUNCH();
-  if (n_cells > 0) {
-    hipLaunchKernelGGL(k_cell_fill, dim3((n_cells + 3) / 4, n_planes), dim3(NT), 0, s, d_edges, h, w, grid, gc, n_cells,
-                       d_cell_starts, d_coords, coord_cap);
+  if (!d_coords) {  // phase 1: counts + scan (the caller sizes the coordinate list from d_num_edges)
+    if (n_cells > 0) {
+      hipLaunchKernelGGL(k_cell_count, dim3((n_cells + NT - 1) / NT, n_planes), dim3(NT), 0, s, d_edge_bits,
+                         words_per_plane, h, w, grid, gc, n_cells, d_cell_counts);
+      MG_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_cell_scan, dim3(n_planes), dim3(1024), 0, s, d_cell_counts, n_cells, d_cell_starts, d_num_edges);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+  }
+  if (n_cells > 0) {  // phase 2: ordered fill
+    hipLaunchKernelGGL(k_cell_fill, dim3((n_cells + NT - 1) / NT, n_planes), dim3(NT), 0, s, d_edge_bits,
+                       words_per_plane, h, w, grid, gc, n_cells, d_cell_starts, d_coords, coord_cap);
     MG_CHECK_LAUNCH();
   }
+  return MG_OK;
+}
+
+extern "C" int mg_edge_angles(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_coords,
+                              int64_t coord_cap, const int32_t* d_num_edges, float* d_angle, void* stream) {
+  if (!d_blur || !d_coords || !d_num_edges || !d_angle || n_planes < 0 || n_planes > 65535 || coord_cap < 0)
+    return MG_EINVAL;
+  if (n_planes == 0 || coord_cap == 0) return MG_OK;
+  const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((coord_cap + NT - 1) / NT, 4096));
+  hipLaunchKernelGGL(k_edge_angles, dim3(bx, n_planes), dim3(NT), 0, mg_stream(stream), d_blur, h, w, d_coords,
+                     coord_cap, d_num_edges, d_angle);
+  MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -93,12 +93,36 @@ __device__ __forceinline__ void block_atomic_max2(double m1, double m2, double* 
 }
 
 // ---- pass 1: global maxima -----------------------------------------------------------
+// Division-free filter for M2 = max(t / flat): the float32 reciprocal gives the quotient to
+// ~2e-7; only pixels whose approximate quotient is within 1e-6 of the running maximum pay for
+// the exact float64 division, so the result is the exact maximum of the exact quotients.
+__device__ __forceinline__ bool flat_in_range(double fl) { return fl > 1e-30 && fl < 1e30; }
+
+__device__ __forceinline__ void max_step(double t, double fl, bool fast_m2, double& m1, double& m2) {
+  m1 = mg_nanmax(m1, t);
+  if (fast_m2) return;
+  if (flat_in_range(fl) && t == t) {
+    if (t == 0.0) {
+      m2 = mg_nanmax(m2, 0.0);
+      return;
+    }
+    const double qa = t * (double)__builtin_amdgcn_rcpf((float)fl);
+    if (m2 == m2 && qa < m2 * (1.0 - 1e-6)) return;  // provably below the running maximum
+  }
+  m2 = mg_nanmax(m2, t / fl);
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void k_flatfield_max(const T* __restrict__ tiles, int64_t n, int64_t tile_elems,
-                                                        double dark, const void* __restrict__ d_dark, int dark_dt,
-                                                        double flat, const void* __restrict__ d_flat, int flat_dt,
+__global__ __launch_bounds__(256) void k_flatfield_max(const T* __restrict__ tiles, int64_t n_per_group,
+                                                        int64_t tile_elems, double dark,
+                                                        const void* __restrict__ d_dark, int dark_dt, double flat,
+                                                        const void* __restrict__ d_flat, int flat_dt,
                                                         double* __restrict__ out) {
   constexpr int N = VecOf<T>::N;
+  const int group = blockIdx.y;
+  tiles += (int64_t)group * n_per_group;
+  out += 2 * group;
+  const int64_t n = n_per_group;
   const bool fast_m2 = (d_flat == nullptr) && (flat > 0.0);  // x / flat is monotone: M2 = M1 / flat
   double m1 = -INFINITY, m2 = -INFINITY;
   const int64_t nvec = n / N;
@@ -110,27 +134,20 @@ __global__ __launch_bounds__(256) void k_flatfield_max(const T* __restrict__ til
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       const double dk = d_dark ? mg_load_f64(d_dark, dark_dt, p) : dark;
+      const double fl = d_flat ? mg_load_f64(d_flat, flat_dt, p) : flat;
       double t = (double)x[j] - dk;
       t = t < 0.0 ? 0.0 : t;
-      m1 = mg_nanmax(m1, t);
-      if (!fast_m2) {
-        const double fl = d_flat ? mg_load_f64(d_flat, flat_dt, p) : flat;
-        m2 = mg_nanmax(m2, t / fl);
-      }
+      max_step(t, fl, fast_m2, m1, m2);
       if (++p == tile_elems) p = 0;
     }
   }
-  // tail
   for (int64_t i = nvec * N + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int64_t p = i % tile_elems;
     const double dk = d_dark ? mg_load_f64(d_dark, dark_dt, p) : dark;
+    const double fl = d_flat ? mg_load_f64(d_flat, flat_dt, p) : flat;
     double t = (double)tiles[i] - dk;
     t = t < 0.0 ? 0.0 : t;
-    m1 = mg_nanmax(m1, t);
-    if (!fast_m2) {
-      const double fl = d_flat ? mg_load_f64(d_flat, flat_dt, p) : flat;
-      m2 = mg_nanmax(m2, t / fl);
-    }
+    max_step(t, fl, fast_m2, m1, m2);
   }
   if (fast_m2) m2 = (m1 == -INFINITY) ? m1 : m1 / flat;
   block_atomic_max2(m1, m2, out);
@@ -139,9 +156,44 @@ __global__ __launch_bounds__(256) void k_flatfield_max(const T* __restrict__ til
 // ---- pass 2: apply + stitch (+ output min/max) ----------------------------------------
 constexpr int ROWS_PER_BLOCK = 8;
 
+// out = trunc(((t / fl) * m1) / m2) for an integer output type without the two float64 divisions:
+// v = t * rcp(fl) * (m1 / m2) with a Newton-refined reciprocal agrees with the reference's three
+// roundings to ~1e-15 relative, so the truncation is the same unless v lies within 1e-6 of an
+// integer -- those (rare) pixels take the exact path.
+template <typename T>
+struct IsIntegral {
+  static constexpr bool value = false;
+};
+template <>
+struct IsIntegral<uint8_t> {
+  static constexpr bool value = true;
+};
+template <>
+struct IsIntegral<uint16_t> {
+  static constexpr bool value = true;
+};
+
+template <typename T>
+__device__ __forceinline__ T correct_pixel(double t, double fl, double m1, double m2, double k, bool fast_ok) {
+  if (IsIntegral<T>::value && fast_ok && flat_in_range(fl)) {
+    if (t == 0.0) return (T)0;  // 0 / fl * m1 / m2 == 0 exactly (m1, m2 finite and positive here)
+    double r = (double)__builtin_amdgcn_rcpf((float)fl);
+    r = r * (2.0 - fl * r);
+    r = r * (2.0 - fl * r);
+    const double v = t * r * k;
+    const double fv = floor(v);
+    const double fr = v - fv;
+    if (fr > 1e-6 && fr < 1.0 - 1e-6 && v < 4.0e9) return (T)(unsigned int)fv;
+  }
+  double e = t / fl;
+  e = e * m1;
+  e = e / m2;
+  return cast_trunc<T>(e);
+}
+
 template <typename T, bool APPLY>
 __global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tiles, int n_tr, int n_tc, int ty, int tx,
-                                                       int clip, int hy, int hx, double dark,
+                                                       int clip, int hy, int hx, int planes_per_group, double dark,
                                                        const void* __restrict__ d_dark, int dark_dt, double flat,
                                                        const void* __restrict__ d_flat, int flat_dt,
                                                        const double* __restrict__ d_max2, T* __restrict__ image,
@@ -150,10 +202,14 @@ __global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tile
   const int plane = blockIdx.z;
   const int h_out = n_tr * hy, w_out = n_tc * hx;
   const int ox0 = (blockIdx.x * blockDim.x + threadIdx.x) * N;
-  double m1 = 0.0, m2 = 1.0;
+  double m1 = 0.0, m2 = 1.0, kk = 1.0;
+  bool fast_ok = false;
   if (APPLY) {
-    m1 = d_max2[0];
-    m2 = d_max2[1];
+    const int group = plane / planes_per_group;
+    m1 = d_max2[2 * group];
+    m2 = d_max2[2 * group + 1];
+    kk = m1 / m2;
+    fast_ok = kk > 0.0 && kk < 1e30 && m1 > 0.0 && m1 < 1e300 && m2 > 0.0 && m2 < 1e300;
   }
   double vmin = INFINITY, vmax = -INFINITY;
   const int64_t tile_elems = (int64_t)ty * tx;
@@ -194,10 +250,7 @@ __global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tile
             const double fl = d_flat ? mg_load_f64(d_flat, flat_dt, pix[j]) : flat;
             double t = (double)x[j] - dk;
             t = t < 0.0 ? 0.0 : t;
-            t = t / fl;
-            t = t * m1;
-            t = t / m2;
-            o[j] = cast_trunc<T>(t);
+            o[j] = correct_pixel<T>(t, fl, m1, m2, kk, fast_ok);
           } else {
             o[j] = x[j];
           }
@@ -289,20 +342,22 @@ __global__ __launch_bounds__(256) void k_plane_minmax(const T* __restrict__ src,
 }
 
 template <typename T>
-int launch_max(const void* d_tiles, int64_t n, int64_t tile_elems, double dark, const void* d_dark, int dark_dt,
-               double flat, const void* d_flat, int flat_dt, double* d_max2, hipStream_t s) {
-  if (n == 0) return MG_OK;
-  const int64_t nvec = n / VecOf<T>::N + 1;
-  int blocks = (int)std::min<int64_t>((nvec + 255) / 256, 256 * 8);
-  hipLaunchKernelGGL((k_flatfield_max<T>), dim3(blocks), dim3(256), 0, s, (const T*)d_tiles, n, tile_elems, dark,
-                     d_dark, dark_dt, flat, d_flat, flat_dt, d_max2);
+int launch_max(const void* d_tiles, int64_t n_per_group, int n_groups, int64_t tile_elems, double dark,
+               const void* d_dark, int dark_dt, double flat, const void* d_flat, int flat_dt, double* d_max2,
+               hipStream_t s) {
+  if (n_per_group == 0 || n_groups == 0) return MG_OK;
+  const int64_t nvec = n_per_group / VecOf<T>::N + 1;
+  const int per_group = std::max(1, 2048 / n_groups);
+  int blocks = (int)std::min<int64_t>((nvec + 255) / 256, per_group);
+  hipLaunchKernelGGL((k_flatfield_max<T>), dim3(blocks, n_groups), dim3(256), 0, s, (const T*)d_tiles, n_per_group,
+                     tile_elems, dark, d_dark, dark_dt, flat, d_flat, flat_dt, d_max2);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
 
 template <typename T>
 int launch_apply(const void* d_tiles, int64_t n_planes, int n_tr, int n_tc, int ty, int tx, int overlap, int apply,
-                 double dark, const void* d_dark, int dark_dt, double flat, const void* d_flat, int flat_dt,
+                 int planes_per_group, double dark, const void* d_dark, int dark_dt, double flat, const void* d_flat, int flat_dt,
                  const double* d_max2, void* d_image, double* d_minmax, hipStream_t s) {
   const int clip = overlap / 2, rem = overlap % 2;
   const int hy = ty - 2 * clip - rem, hx = tx - 2 * clip - rem;
@@ -313,10 +368,12 @@ int launch_apply(const void* d_tiles, int64_t n_planes, int n_tr, int n_tc, int 
   if (grid.y > 65535 || grid.z > 65535) return MG_EINVAL;
   if (apply)
     hipLaunchKernelGGL((k_apply_stitch<T, true>), grid, dim3(256), 0, s, (const T*)d_tiles, n_tr, n_tc, ty, tx, clip,
-                       hy, hx, dark, d_dark, dark_dt, flat, d_flat, flat_dt, d_max2, (T*)d_image, d_minmax);
+                       hy, hx, planes_per_group, dark, d_dark, dark_dt, flat, d_flat, flat_dt, d_max2, (T*)d_image,
+                       d_minmax);
   else
     hipLaunchKernelGGL((k_apply_stitch<T, false>), grid, dim3(256), 0, s, (const T*)d_tiles, n_tr, n_tc, ty, tx, clip,
-                       hy, hx, dark, d_dark, dark_dt, flat, d_flat, flat_dt, d_max2, (T*)d_image, d_minmax);
+                       hy, hx, planes_per_group, dark, d_dark, dark_dt, flat, d_flat, flat_dt, d_max2, (T*)d_image,
+                       d_minmax);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -339,36 +396,41 @@ bool df_dtype_ok(const void* p, int dt) { return p == nullptr || dt == MG_F32 ||
 
 extern "C" int mg_version(void) { return 1; }
 
-extern "C" int mg_flatfield_max(const void* d_tiles, int dtype, int64_t n_tiles, int ty, int tx, double dark,
-                                const void* d_dark, int dark_dtype, double flat, const void* d_flat, int flat_dtype,
-                                double* d_max2, void* stream) {
-  if (!d_tiles || !d_max2 || n_tiles < 0 || ty <= 0 || tx <= 0) return MG_EINVAL;
+extern "C" int mg_flatfield_max(const void* d_tiles, int dtype, int64_t n_tiles, int n_groups, int ty, int tx,
+                                double dark, const void* d_dark, int dark_dtype, double flat, const void* d_flat,
+                                int flat_dtype, double* d_max2, void* stream) {
+  if (!d_tiles || !d_max2 || n_tiles < 0 || ty <= 0 || tx <= 0 || n_groups <= 0 || n_groups > 65535) return MG_EINVAL;
+  if (n_tiles % n_groups) return MG_EINVAL;
   if (!df_dtype_ok(d_dark, dark_dtype) || !df_dtype_ok(d_flat, flat_dtype)) return MG_EINVAL;
-  const int64_t tile_elems = (int64_t)ty * tx, n = n_tiles * tile_elems;
+  const int64_t tile_elems = (int64_t)ty * tx, n = (n_tiles / n_groups) * tile_elems;
   hipStream_t s = mg_stream(stream);
+#define MG_MAX(T) \
+  return launch_max<T>(d_tiles, n, n_groups, tile_elems, dark, d_dark, dark_dtype, flat, d_flat, flat_dtype, d_max2, s)
   switch (dtype) {
-    case MG_U8: return launch_max<uint8_t>(d_tiles, n, tile_elems, dark, d_dark, dark_dtype, flat, d_flat, flat_dtype, d_max2, s);
-    case MG_U16: return launch_max<uint16_t>(d_tiles, n, tile_elems, dark, d_dark, dark_dtype, flat, d_flat, flat_dtype, d_max2, s);
-    case MG_F32: return launch_max<float>(d_tiles, n, tile_elems, dark, d_dark, dark_dtype, flat, d_flat, flat_dtype, d_max2, s);
-    case MG_F64: return launch_max<double>(d_tiles, n, tile_elems, dark, d_dark, dark_dtype, flat, d_flat, flat_dtype, d_max2, s);
+    case MG_U8: MG_MAX(uint8_t);
+    case MG_U16: MG_MAX(uint16_t);
+    case MG_F32: MG_MAX(float);
+    case MG_F64: MG_MAX(double);
   }
+#undef MG_MAX
   return MG_EINVAL;
 }
 
 extern "C" int mg_flatfield_apply_stitch(const void* d_tiles, int dtype, int64_t n_planes, int n_tile_rows,
                                          int n_tile_cols, int ty, int tx, int overlap, int apply_flatfield,
-                                         double dark, const void* d_dark, int dark_dtype, double flat,
-                                         const void* d_flat, int flat_dtype, const double* d_max2, void* d_image,
-                                         double* d_minmax, void* stream) {
+                                         int planes_per_group, double dark, const void* d_dark, int dark_dtype,
+                                         double flat, const void* d_flat, int flat_dtype, const double* d_max2,
+                                         void* d_image, double* d_minmax, void* stream) {
   if (!d_tiles || !d_image || n_planes < 0 || n_tile_rows <= 0 || n_tile_cols <= 0 || ty <= 0 || tx <= 0)
     return MG_EINVAL;
   if (overlap < 0 || overlap >= ty || overlap >= tx) return MG_EINVAL;
-  if (apply_flatfield && !d_max2) return MG_EINVAL;
+  if (apply_flatfield && (!d_max2 || planes_per_group <= 0)) return MG_EINVAL;
   if (!df_dtype_ok(d_dark, dark_dtype) || !df_dtype_ok(d_flat, flat_dtype)) return MG_EINVAL;
   hipStream_t s = mg_stream(stream);
 #define MG_APPLY(T) \
-  return launch_apply<T>(d_tiles, n_planes, n_tile_rows, n_tile_cols, ty, tx, overlap, apply_flatfield, dark, d_dark, \
-                         dark_dtype, flat, d_flat, flat_dtype, d_max2, d_image, d_minmax, s)
+  return launch_apply<T>(d_tiles, n_planes, n_tile_rows, n_tile_cols, ty, tx, overlap, apply_flatfield, \
+                         planes_per_group > 0 ? planes_per_group : 1, dark, d_dark, dark_dtype, flat, d_flat, \
+                         flat_dtype, d_max2, d_image, d_minmax, s)
   switch (dtype) {
     case MG_U8: MG_APPLY(uint8_t);
     case MG_U16: MG_APPLY(uint16_t);

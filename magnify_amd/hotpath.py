@@ -115,23 +115,24 @@ def _df_operand(value, ty, tx, device):
     return 0.0, arr, nat.dtype_code(arr.dtype)
 
 
-def flatfield_max(tiles: torch.Tensor, flatfield=1.0, darkfield=0.0) -> torch.Tensor:
-    """Pass 1 of flatfield_correct: the two global maxima as a float64[2] device tensor."""
+def flatfield_max(tiles: torch.Tensor, flatfield=1.0, darkfield=0.0, n_groups=1) -> torch.Tensor:
+    """Pass 1 of flatfield_correct: the two global maxima as a float64 (n_groups, 2) device tensor
+    (``n_groups`` equal blocks along the leading axes: one per independent assay)."""
     require_gpu()
     ty, tx = tiles.shape[-2:]
     tiles = tiles.contiguous()
     dk, dkt, dkc = _df_operand(darkfield, ty, tx, tiles.device)
     fl, flt, flc = _df_operand(flatfield, ty, tx, tiles.device)
-    max2 = torch.full((2,), -math.inf, dtype=torch.float64, device=tiles.device)
+    max2 = torch.full((n_groups, 2), -math.inf, dtype=torch.float64, device=tiles.device)
     n_tiles = tiles.numel() // (ty * tx)
-    _call("mg_flatfield_max", tiles.data_ptr(), nat.dtype_code(tiles.dtype), n_tiles, ty, tx, dk, _ptr(dkt),
+    _call("mg_flatfield_max", tiles.data_ptr(), nat.dtype_code(tiles.dtype), n_tiles, n_groups, ty, tx, dk, _ptr(dkt),
                                          dkc, fl, _ptr(flt), flc, max2.data_ptr(), _stream())
     return max2
 
 
 def flatfield_stitch(tiles: torch.Tensor, overlap: int, flatfield=1.0, darkfield=0.0, apply_flatfield=True,
                      max2: torch.Tensor | None = None, want_minmax=True, out: torch.Tensor | None = None,
-                     minmax_out: torch.Tensor | None = None):
+                     minmax_out: torch.Tensor | None = None, n_groups=1):
     """tiles (C, T, R, Cc, ty, tx) -> image (C, T, R*hy, Cc*hx) and per-plane min/max (C*T, 2).
 
     ``max2`` lets a multi-GPU caller supply all-reduced maxima."""
@@ -146,8 +147,10 @@ def flatfield_stitch(tiles: torch.Tensor, overlap: int, flatfield=1.0, darkfield
     hy, hx = ty - 2 * clip - rem, tx - 2 * clip - rem
     dk, dkt, dkc = _df_operand(darkfield, ty, tx, tiles.device)
     fl, flt, flc = _df_operand(flatfield, ty, tx, tiles.device)
+    if (c * t) % n_groups:
+        raise ValueError("n_groups must divide the number of planes")
     if apply_flatfield and max2 is None:
-        max2 = flatfield_max(tiles, flatfield, darkfield)
+        max2 = flatfield_max(tiles, flatfield, darkfield, n_groups)
     if out is None:
         image = torch.empty((c, t, nr * hy, nc * hx), dtype=tiles.dtype, device=tiles.device)
     else:
@@ -163,7 +166,7 @@ def flatfield_stitch(tiles: torch.Tensor, overlap: int, flatfield=1.0, darkfield
         minmax.view(-1, 2)[:, 0] = math.inf
         minmax.view(-1, 2)[:, 1] = -math.inf
     _call("mg_flatfield_apply_stitch", tiles.data_ptr(), nat.dtype_code(tiles.dtype), c * t, nr, nc, ty, tx,
-                                                  overlap, int(bool(apply_flatfield)), dk, _ptr(dkt), dkc, fl,
+                                                  overlap, int(bool(apply_flatfield)), (c * t) // n_groups, dk, _ptr(dkt), dkc, fl,
                                                   _ptr(flt), flc, _ptr(max2), image.data_ptr(), _ptr(minmax),
                                                   _stream())
     return image, minmax
@@ -265,21 +268,25 @@ class CircleFinder:
         i32, u8 = torch.int32, torch.uint8
         self.blur = torch.empty((P, h, w), dtype=u8, device=dev)
         self.edges = torch.empty((P, h, w), dtype=u8, device=dev)  # Canny map, then {0,1} edges
-        self.angle = torch.empty((P, h, w), dtype=torch.float32, device=dev)
+        self.angle = torch.empty((P, h, w), dtype=torch.float32, device=dev)  # valid at edge pixels
         self.hist = torch.zeros((P, FINE_BINS), dtype=i32, device=dev)
         self.hist_base = torch.zeros((P,), dtype=i32, device=dev)
         self.thresh = torch.zeros((P, 2), dtype=i32, device=dev)
         self.changed = torch.zeros((P,), dtype=i32, device=dev)
+        tx, ty = nat.C.c_int(0), nat.C.c_int(0)
+        nat.check(nat.lib().mg_hysteresis_tiles(h, w, nat.C.byref(tx), nat.C.byref(ty)), "mg_hysteresis_tiles")
+        self.tile_flags = torch.zeros((2, P, ty.value, tx.value), dtype=u8, device=dev)
+        self.words = 2 * ((h * w + 63) // 64)  # edge bitmap words per plane (even)
+        self.edge_bits = torch.zeros((P, self.words), dtype=i32, device=dev)
+        self.keep_debug_maps = False  # True: also produce the {0,1} byte map and the angle map (tests)
         self.cell_counts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
         self.cell_starts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
         self.num_edges = torch.zeros((P,), dtype=i32, device=dev)
         self.coords = None
-        nr = self.max_r - self.min_r + 1
-        bits = nr * (h + 2 * self.max_r) * (w + 2 * self.max_r)
-        self.bitmap_words = (bits + 31) // 32
+        _, _, self.n_layers, self.bitmap_words = nat.dedup_layout(h, w, self.min_r, self.max_r)
         self.bitmap = torch.zeros((P, self.bitmap_words), dtype=i32, device=dev)
-        self.block_counts = torch.zeros((P, (self.bitmap_words + 1023) // 1024), dtype=i32, device=dev)
-        self.cap = max(1, min(self.num_iter, bits))
+        self.layer_offsets = torch.zeros((P, self.n_layers + 1), dtype=i32, device=dev)
+        self.cap = max(1, min(self.num_iter, self.bitmap_words * 32))
         self.circles = torch.empty((P, self.cap, 3), dtype=i32, device=dev)
         self.num_circles = torch.zeros((P,), dtype=i32, device=dev)
         self.scores = torch.empty((P, self.cap), dtype=torch.float32, device=dev)
@@ -361,20 +368,28 @@ class CircleFinder:
         sweeps = 0
         while True:
             self.changed.zero_()
-            _call("mg_canny_hysteresis", self.edges.data_ptr(), P, h, w, self.changed.data_ptr(), s)
+            cur = self.tile_flags[sweeps & 1]
+            cur.zero_()
+            prev = self.tile_flags[(sweeps + 1) & 1] if sweeps > 0 else None
+            _call("mg_canny_hysteresis", self.edges.data_ptr(), P, h, w, self.changed.data_ptr(), _ptr(prev),
+                  cur.data_ptr(), s)
             sweeps += 1
             if int(self.changed.sum().item()) == 0:
                 break
         self.stats["hysteresis_sweeps"] = sweeps
-        self.cell_counts.zero_()
-        _call("mg_edges_finalize", self.edges.data_ptr(), self.blur.data_ptr(), P, h, w, self.grid,
-                                      self.angle.data_ptr(), self.cell_counts.data_ptr(), s)
-        n_edges = self.cell_counts.sum(dim=1).cpu().numpy()
+        _call("mg_edges_finalize", self.edges.data_ptr(), self.blur.data_ptr(), P, h, w, self.edge_bits.data_ptr(),
+              self.words, int(self.keep_debug_maps), _ptr(self.angle if self.keep_debug_maps else None), s)
+        _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, P, h, w, self.grid, self.cell_counts.data_ptr(),
+              self.cell_starts.data_ptr(), self.num_edges.data_ptr(), 0, 0, s)
+        n_edges = self.num_edges.cpu().numpy()
         self.coord_cap = max(1, int(n_edges.max()))
-        self.coords = torch.empty((P, self.coord_cap, 2), dtype=torch.int32, device=self.dev)
-        _call("mg_edge_grid", self.edges.data_ptr(), P, h, w, self.grid, self.cell_counts.data_ptr(),
-                                 self.cell_starts.data_ptr(), self.num_edges.data_ptr(), self.coords.data_ptr(),
-                                 self.coord_cap, s)
+        if self.coords is None or self.coords.shape[1] < self.coord_cap:
+            self.coords = torch.empty((P, int(self.coord_cap * 1.25) + 1, 2), dtype=torch.int32, device=self.dev)
+        self.coord_cap = self.coords.shape[1]
+        _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, P, h, w, self.grid, self.cell_counts.data_ptr(),
+              self.cell_starts.data_ptr(), self.num_edges.data_ptr(), self.coords.data_ptr(), self.coord_cap, s)
+        _call("mg_edge_angles", self.blur.data_ptr(), P, h, w, self.coords.data_ptr(), self.coord_cap,
+              self.num_edges.data_ptr(), self.angle.data_ptr(), s)
         self.n_edges_host = n_edges
         return n_edges
 
@@ -389,15 +404,15 @@ class CircleFinder:
                                          self.seeds.data_ptr(), self.num_iter, self.min_r, self.max_r,
                                          self.bitmap.data_ptr(), self.bitmap_words, _ptr(self.raw), s)
         _call("mg_bitmap_to_circles", self.bitmap.data_ptr(), self.bitmap_words, P, h, w, self.min_r, self.max_r,
-                                         self.block_counts.data_ptr(), self.circles.data_ptr(), self.cap,
+                                         self.layer_offsets.data_ptr(), self.circles.data_ptr(), self.cap,
                                          self.num_circles.data_ptr(), s)
         self.num_alive.zero_()
         self.max_rc.fill_(-(2**31))
-        _call("mg_score_circles", self.angle.data_ptr(), P, h, w, self.circles.data_ptr(), self.cap,
-                                     self.num_circles.data_ptr(), self.min_r, self.max_r, self.per_rc.data_ptr(),
-                                     self.per_exp.data_ptr(), self.per_starts.data_ptr(), float(min_roundness),
-                                     self.scores.data_ptr(), self.alive.data_ptr(), self.num_alive.data_ptr(),
-                                     self.max_rc.data_ptr(), s)
+        _call("mg_score_circles", self.angle.data_ptr(), self.edge_bits.data_ptr(), self.words, P, h, w,
+              self.circles.data_ptr(), self.cap, self.layer_offsets.data_ptr(), self.min_r, self.max_r,
+              self.per_rc.data_ptr(), self.per_exp.data_ptr(), self.per_starts.data_ptr(), int(self.per_rc.shape[0]),
+              float(min_roundness), int(self.keep_debug_maps), self.scores.data_ptr(), self.alive.data_ptr(),
+              self.num_alive.data_ptr(), self.max_rc.data_ptr(), s)
 
     # -- stage 3: greedy suppression + ordered output -------------------------------------------
     def nms_stage(self, min_dist: int):

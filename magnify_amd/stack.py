@@ -46,14 +46,11 @@ class StackProcessor:
     def flatfield(self, stack: torch.Tensor, flatfield=1.0, darkfield=0.0, max2=None):
         """stack (T, C, H, W) -> self.image (T, C, H, W), self.minmax (T, C, 2)."""
         T, C, h, w = self.T, self.C, self.h, self.w
-        if self.mode == "P":
-            for t in range(T):
-                hp.flatfield_stitch(stack[t].view(C, 1, 1, 1, h, w), 0, flatfield, darkfield, out=self.image[t],
-                                    minmax_out=self.minmax[t])
-        else:
-            # single assay: the maxima span the whole stack (preprocess.py:84,86)
-            tiles = stack.view(T * C, 1, 1, 1, h, w)
-            hp.flatfield_stitch(tiles, 0, flatfield, darkfield, out=self.image, minmax_out=self.minmax, max2=max2)
+        tiles = stack.view(T * C, 1, 1, 1, h, w)
+        # mode P: every time slice is its own assay -> its own pair of maxima (n_groups = T);
+        # mode R: single assay, the maxima span the whole stack (preprocess.py:84,86)
+        hp.flatfield_stitch(tiles, 0, flatfield, darkfield, out=self.image, minmax_out=self.minmax, max2=max2,
+                            n_groups=T if self.mode == "P" else 1)
         return self.image
 
     def detect(self, seed=0):

@@ -251,14 +251,26 @@ def filter_neighbors(circles: np.ndarray, min_dist: int) -> np.ndarray:
 # --------------------------------------------------------------------------------------
 
 
-def canonical_order(circles: np.ndarray, scores: np.ndarray) -> np.ndarray:
-    """The build's canonical total order for score ties: score descending, then
-    radius, row, col ascending.  The reference uses an unstable argsort
-    (utils.py:195), so any tie order is a legal outcome of it; duplicates of one
-    integer circle always tie, and dropping them does not change the survivors
-    of ``filter_neighbors`` (a duplicate of a kept circle hits its own ring, a
-    duplicate of a dropped circle is dropped for the same reason)."""
-    return np.lexsort((circles[:, 1], circles[:, 0], circles[:, 2], -scores.astype(np.float64)))
+CANON_TILE = 64  # side of the centre tiles of the build's canonical circle order
+
+
+def canonical_key(circles: np.ndarray, max_radius: int):
+    """Sort keys (minor first, for np.lexsort) of the build's canonical circle order: centres are
+    binned into 64 x 64 tiles of the padded centre grid (row + max_radius, col + max_radius); order is
+    (tile_row, tile_col, r, row, col).  This is the order in which the GPU emits unique circles."""
+    c = np.asarray(circles, dtype=np.int64)
+    tr = (c[:, 0] + max_radius) // CANON_TILE
+    tc = (c[:, 1] + max_radius) // CANON_TILE
+    return (c[:, 1], c[:, 0], c[:, 2], tc, tr)
+
+
+def canonical_order(circles: np.ndarray, scores: np.ndarray, max_radius: int) -> np.ndarray:
+    """The build's canonical total order for score ties: score descending, then the tile-major
+    circle order of ``canonical_key``.  The reference uses an unstable argsort (utils.py:195), so
+    any tie order is a legal outcome of it; duplicates of one integer circle always tie, and
+    dropping them does not change the survivors of ``filter_neighbors`` (a duplicate of a kept
+    circle hits its own ring, a duplicate of a dropped circle is dropped for the same reason)."""
+    return np.lexsort(canonical_key(circles, max_radius) + (-scores.astype(np.float64),))
 
 
 def filter_circles(all_circles, edges, dx, dy, min_radius, max_radius, min_roundness, min_dist,
@@ -292,7 +304,7 @@ def filter_circles(all_circles, edges, dx, dy, min_radius, max_radius, min_round
         start = end
     good = scores >= min_roundness
     c, scores = c[good], scores[good]
-    perm = canonical_order(c, scores)
+    perm = canonical_order(c, scores, max_radius)
     c, scores = c[perm], scores[perm]
     if min_dist > 0:
         keep = filter_neighbors(c, min_dist)
