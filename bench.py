@@ -31,9 +31,9 @@ def algorithmic_bytes(stage, p):
         "mg_flatfield_apply_stitch": 4 * c * n * p["n_t"],   # read u16 + write u16
         "mg_to_uint8_blur": 3 * planes * n,                 # read u16, write blurred u8
         "mg_scharr_hist": 1 * planes * n,                   # read u8
-        "mg_canny_nms": 2 * planes * n,                     # read u8, write map u8
-        "mg_canny_hysteresis": 2 * planes * n,              # read + write map (per sweep)
-        "mg_edges_finalize": (1 + 1 / 8) * planes * n,      # read map, write edge bitmap
+        "mg_canny_nms": (1 + 2 / 8) * planes * n,           # read u8, write weak + strong bitmaps
+        "mg_canny_hysteresis": (3 / 8) * planes * n,        # read weak + strong bits, write strong (per sweep)
+        "mg_edge_angles": p["edges"] * (8 + 9 + 4),          # coordinate, 3x3 blurred neighbourhood, angle
         "mg_edge_grid": planes * n / 8 + 8 * p["edges"],    # read bitmap (twice: count, fill), write coords
         "mg_candidate_circles": 28 * planes * p["num_iter"],  # 3 coordinate reads (8 B) + bitmap word
         "mg_bitmap_to_circles": 2 * 4 * p["bitmap_words"] * planes + 12 * p["unique"],  # bitmap read twice + list
@@ -167,7 +167,7 @@ def main():
                     "share_of_kernel_time": dom_ms / total_ms}
         # the streaming part alone (everything that is not RANSAC scoring / suppression)
         stream_stages = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_to_uint8_blur", "mg_scharr_hist",
-                         "mg_canny_nms", "mg_canny_hysteresis", "mg_edges_finalize", "mg_edge_grid",
+                         "mg_canny_nms", "mg_canny_hysteresis", "mg_edge_grid", "mg_edge_angles", "mg_circle_labels",
                          "mg_roi_gather_reduce_batched"]
         stream_ms = sum(stages[s][0] for s in stream_stages if s in stages) / args.steps
         n_all, n_s = T * C * S * S, f.P * S * S

@@ -109,35 +109,37 @@ int mg_to_uint8_blur(const void* d_src, int dtype, int n_planes, int64_t plane_s
 
 /* Scharr gradients of the blurred image and a histogram of the integer squared
  * magnitude m = dx^2 + dy^2 (the float32 gradient of utils.py:120 is sqrt(float(m)), a
- * monotone function of m, so np.quantile's order statistics are recovered exactly):
- * d_hist[n_planes][n_bins] += 1 at bin (m - d_base[plane]) >> shift when that is in
- * [0, n_bins).  d_base NULL means base 0.  n_bins <= 8192. */
-int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w, const uint32_t* d_base, int shift,
-                   int n_bins, uint32_t* d_hist, void* stream);
+ * monotone function of m, so np.quantile's order statistics are recovered exactly).
+ * mode 0 (combined, 12288 bins per plane): bins [0, 8192) count m exactly, bin 8192 + (m >> 13)
+ *   counts the rest coarsely -- one pass suffices whenever both quantile ranks fall below 8192;
+ * mode 1 (window, 8192 bins per plane): bin m - d_base[plane] for m in [base, base + 8192).
+ * d_hist must be pre-zeroed. */
+int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w, int mode, const uint32_t* d_base,
+                   uint32_t* d_hist, void* stream);
+
+/* Bitmaps over pixels use the linear layout bit i of word k <-> pixel 32 k + i (i = y * w + x);
+ * words_per_plane >= ceil(h w / 32) + 1. */
 
 /* cv.Canny(dx, dy, L2gradient=True) non-maximum suppression + double threshold with the
- * already prepared integer thresholds d_thresh[n_planes][2] = {low, high}; writes
- * OpenCV's map values {0 weak, 1 none, 2 strong} to d_map[n_planes][h][w]. */
-int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_thresh, uint8_t* d_map,
-                 void* stream);
+ * already prepared integer thresholds d_thresh[n_planes][2] = {low, high}.  Output: two bitmaps,
+ * d_weak (local maxima with m > low: OpenCV map values 0 and 2) and d_strong (m > high: value 2). */
+int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_thresh, uint32_t* d_weak,
+                 uint32_t* d_strong, int64_t words_per_plane, void* stream);
 
-/* One sweep of 8-connected hysteresis (tile-local fixed point + halo exchange through
- * global memory).  d_changed[n_planes] is incremented for planes that changed; call until
- * a sweep leaves it at zero.  Optional active-tile tracking: d_flags_in / d_flags_out are
- * uint8[n_planes][tiles_y][tiles_x] (mg_hysteresis_tiles); a tile is skipped unless it or one of
- * its 8 neighbours set its flag in the previous sweep; d_flags_out (pre-zeroed) receives this
- * sweep's flags.  Pass d_flags_in = NULL for the first sweep. */
-int mg_canny_hysteresis(uint8_t* d_map, int n_planes, int h, int w, uint32_t* d_changed,
-                        const uint8_t* d_flags_in, uint8_t* d_flags_out, void* stream);
+/* One sweep of 8-connected hysteresis, bit-parallel on the bitmaps: every 256 x 64 tile grows its
+ * strong set into its weak set to a fixed point in LDS (halo from global memory) and ORs the new
+ * bits into d_strong.  d_changed[n_planes] is incremented for planes that changed; call until a
+ * sweep leaves it at zero: d_strong is then the edge map of utils.py:142.  Active-tile tracking:
+ * d_flags_in / d_flags_out are uint8[n_planes][tiles_y][tiles_x] (mg_hysteresis_tiles); a tile is
+ * skipped unless it or one of its 8 neighbours set its flag in the previous sweep; d_flags_out
+ * (pre-zeroed) receives this sweep's flags.  Pass d_flags_in = NULL for the first sweep. */
+int mg_canny_hysteresis(const uint32_t* d_weak, uint32_t* d_strong, int64_t words_per_plane, int n_planes, int h,
+                        int w, uint32_t* d_changed, const uint8_t* d_flags_in, uint8_t* d_flags_out, void* stream);
 int mg_hysteresis_tiles(int h, int w, int* tiles_x, int* tiles_y);
 
-/* Finalise the Canny map (edge = value 2, utils.py:142) into the edge bitmap
- * d_edge_bits[n_planes][words_per_plane] (bit i of word k <-> linear pixel 32 k + i;
- * words_per_plane even, >= ceil(h w / 32)).  write_bytes != 0 also rewrites d_map in place as the
- * {0,1} byte map; d_angle (optional) gets MG_NO_EDGE at non-edge pixels -- both only needed by
- * tests/inspection (edge pixels of the angle map are written by mg_edge_angles). */
-int mg_edges_finalize(uint8_t* d_map, const uint8_t* d_blur, int n_planes, int h, int w, uint32_t* d_edge_bits,
-                      int64_t words_per_plane, int write_bytes, float* d_angle, void* stream);
+/* Inspection helper: bitmap -> {0,1} bytes, d_out[n_planes][n_bits]. */
+int mg_unpack_bits(const uint32_t* d_bits, int64_t words_per_plane, int n_planes, int64_t n_bits, uint8_t* d_out,
+                   void* stream);
 
 /* grid_array (utils.py:347-377) from the bitmap, in two phases so that the caller can size the
  * coordinate list: d_coords == NULL computes d_cell_counts / d_cell_starts [n_planes][gr*gc]

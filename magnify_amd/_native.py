@@ -35,11 +35,11 @@ PROTOTYPES = {
     "mg_flatfield_apply_stitch": [_p, _i, _l, _i, _i, _i, _i, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p, _p, _p],
     "mg_plane_minmax": [_p, _i, _i, _l, _i, _i, _l, _p, _p],
     "mg_to_uint8_blur": [_p, _i, _i, _l, _i, _i, _l, _p, _p, _p, _p],
-    "mg_scharr_hist": [_p, _i, _i, _i, _p, _i, _i, _p, _p],
-    "mg_canny_nms": [_p, _i, _i, _i, _p, _p, _p],
-    "mg_canny_hysteresis": [_p, _i, _i, _i, _p, _p, _p, _p],
+    "mg_scharr_hist": [_p, _i, _i, _i, _i, _p, _p, _p],
+    "mg_canny_nms": [_p, _i, _i, _i, _p, _p, _p, _l, _p],
+    "mg_canny_hysteresis": [_p, _p, _l, _i, _i, _i, _p, _p, _p, _p],
+    "mg_unpack_bits": [_p, _l, _i, _l, _p, _p],
     "mg_hysteresis_tiles": [_i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
-    "mg_edges_finalize": [_p, _p, _i, _i, _i, _p, _l, _i, _p, _p],
     "mg_edge_grid": [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p],
     "mg_candidate_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _p, _p],
     "mg_bitmap_to_circles": [_p, _l, _i, _i, _i, _i, _i, _p, _p, _l, _p, _p],

@@ -1,22 +1,27 @@
 // A3-A7: edge stage of find_circles (utils.py:20-27, 115-142) and grid_array (utils.py:347-377).
 //
-//   to_uint8 + GaussianBlur 5x5  ->  Scharr + |grad|^2 histogram (x2: coarse, fine)  ->
-//   Canny NMS + double threshold ->  hysteresis sweeps -> finalise (edge map, angle map,
-//   cell counts) -> CSR edge grid.
+//   K1 to_uint8 + GaussianBlur 5x5            u16 -> blurred u8          (read 2, write 1 B/px)
+//   K2 Scharr + histogram of m = dx^2+dy^2    (exact np.quantile)        (read 1 B/px)
+//   K3 Canny NMS + double threshold           -> weak / strong BITMAPS   (read 1, write 1/4 B/px)
+//   K4 hysteresis, bit-parallel in LDS, active tiles only                (bits only)
+//   K5 grid_array from the strong bitmap, K6 gradient angle per edge pixel
 //
-// All stencils stage a tile (+halo, BORDER_REFLECT_101) through LDS; every kernel is batched
-// over planes.  Roofline: HBM (bytes per pixel in DESIGN.md); integer arithmetic throughout,
-// so results are bit-exact against the oracle.
+// Stencil kernels stage a 256 x 64 tile (+halo, BORDER_REFLECT_101) through LDS with 16-byte
+// loads; every lane owns 4 adjacent pixels (one dword) of 16 rows.  Integer arithmetic throughout:
+// bit-exact against the oracle.  Roofline: HBM.
 #include <math.h>
 
 #include "mg_common.h"
 
 namespace {
 
-constexpr int TW = 128;  // tile width  (pixels)
-constexpr int TH = 32;   // tile height (pixels)
-constexpr int NT = 256;  // threads per block
-constexpr int ROWS_PER_THREAD = TH / (NT / TW);  // 16
+constexpr int TW = 256;   // tile width  (pixels) = 64 lanes x 4 px
+constexpr int TH = 64;    // tile height (pixels) = 4 waves x 16 rows
+constexpr int NT = 256;   // threads per block
+constexpr int RPW = 16;   // rows per wave
+constexpr int LPAD = 16;  // halo chunk on each side of a tile row (one 16-byte chunk)
+constexpr int LS = TW + 2 * LPAD;        // LDS row stride in bytes (288)
+constexpr int CHUNKS = LS / 16;          // 16-byte chunks per LDS row (18)
 
 // ---- to_uint8 -------------------------------------------------------------------------
 struct U8Scale {
@@ -58,106 +63,166 @@ __device__ __forceinline__ uint8_t to_u8<double>(double x, const U8Scale& s) {
   return (uint8_t)(int)(255.0 * a / s.top);
 }
 
+// 16 consecutive elements of a row starting at column gx0 (may be outside the image: reflect-101).
+template <typename T>
+__device__ __forceinline__ void fetch16(const T* __restrict__ rowp, int gx0, int w, const U8Scale& sc, uint8_t (&v)[16]) {
+  const T* p = rowp + gx0;
+  if (gx0 >= 0 && gx0 + 16 <= w && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    constexpr int PER = 16 / sizeof(T);  // elements per 16-byte load
+#pragma unroll
+    for (int q = 0; q < 16 / PER; ++q) {
+      T e[PER];
+      const uint4 raw = reinterpret_cast<const uint4*>(p)[q];
+      __builtin_memcpy(e, &raw, 16);
+#pragma unroll
+      for (int j = 0; j < PER; ++j) v[q * PER + j] = to_u8<T>(e[j], sc);
+    }
+  } else {
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) v[j] = to_u8<T>(rowp[mg_reflect101(gx0 + j, w)], sc);
+  }
+}
+
+// Stage tile rows [ty0 - HALO, ty0 + TH + HALO) x cols [tx0 - 16, tx0 + TW + 16) into LDS.
+template <typename T, int HALO>
+__device__ __forceinline__ void load_tile(const T* __restrict__ base, int64_t row_stride, int h, int w, int tx0, int ty0,
+                                          const U8Scale& sc, uint8_t (*tile)[LS]) {
+  for (int i = threadIdx.x; i < (TH + 2 * HALO) * CHUNKS; i += NT) {
+    const int j = i / CHUNKS, k = i - j * CHUNKS;
+    const int gy = mg_reflect101(ty0 - HALO + j, h);
+    uint8_t v[16];
+    fetch16<T>(base + (int64_t)gy * row_stride, tx0 - LPAD + 16 * k, w, sc, v);
+    uint4 raw;
+    __builtin_memcpy(&raw, v, 16);
+    *reinterpret_cast<uint4*>(&tile[j][16 * k]) = raw;
+  }
+}
+
+// Bytes c0-4 .. c0+7 of a tile row as three dwords (c0 = 4 * lane is the lane's first pixel).
+struct Row12 {
+  uint32_t d0, d1, d2;
+  __device__ __forceinline__ int at(int off) const {  // off in [-4, 8): pixel c0 + off
+    const int b = off + 4;
+    const uint32_t d = b < 4 ? d0 : (b < 8 ? d1 : d2);
+    return (int)((d >> (8 * (b & 3))) & 0xFFu);
+  }
+};
+__device__ __forceinline__ Row12 read_row(const uint8_t (*tile)[LS], int r, int c0) {
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(&tile[r][LPAD + c0 - 4]);
+  return Row12{p[0], p[1], p[2]};
+}
+
 // ---- K1: to_uint8 + 5x5 Gaussian ([1 4 6 4 1] x [1 4 6 4 1], (sum + 128) >> 8) ----------
 template <typename T>
 __global__ __launch_bounds__(NT) void k_u8_blur(const T* __restrict__ src, int64_t plane_stride, int h, int w,
                                                 int64_t row_stride, const double* __restrict__ d_minmax,
                                                 uint8_t* __restrict__ d_blur, uint8_t* __restrict__ d_u8) {
-  constexpr int LW = TW + 4, LH = TH + 4, LS = TW + 8;
-  __shared__ uint8_t tile[LH][LS];
+  __shared__ __attribute__((aligned(16))) uint8_t tile[TH + 4][LS];
   const int plane = blockIdx.z;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-  const T* base = src + (int64_t)plane * plane_stride;
   const U8Scale sc = make_scale(d_minmax, plane);
-  for (int i = threadIdx.x; i < LH * LW; i += NT) {
-    const int r = i / LW, c = i - r * LW;
-    const int gy = mg_reflect101(ty0 + r - 2, h), gx = mg_reflect101(tx0 + c - 2, w);
-    const uint8_t v = to_u8<T>(base[(int64_t)gy * row_stride + gx], sc);
-    tile[r][c] = v;
-    if (d_u8 && r >= 2 && r < TH + 2 && c >= 2 && c < TW + 2 && ty0 + r - 2 < h && tx0 + c - 2 < w)
-      d_u8[((int64_t)plane * h + (ty0 + r - 2)) * w + (tx0 + c - 2)] = v;
-  }
+  load_tile<T, 2>(src + (int64_t)plane * plane_stride, row_stride, h, w, tx0, ty0, sc, tile);
   __syncthreads();
-  const int c = threadIdx.x % TW;             // output column inside the tile
-  const int r0 = (threadIdx.x / TW) * ROWS_PER_THREAD;  // first output row of this thread
-  if (tx0 + c >= w) return;
-  int hsum[5];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = 4 * lane, gx = tx0 + c0;
+  if (gx >= w) return;
+  int hs[5][4];
+  uint8_t* outp = d_blur + (int64_t)plane * h * w;
+  uint8_t* rawp = d_u8 ? d_u8 + (int64_t)plane * h * w : nullptr;
+  const bool full = (gx + 4 <= w) && ((w & 3) == 0);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint8_t* p = &tile[r0 + k][c];
-    hsum[k + 1] = p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4];
-  }
-  uint8_t* out = d_blur + ((int64_t)plane * h) * w + tx0 + c;
-  for (int rr = 0; rr < ROWS_PER_THREAD; ++rr) {
+  for (int jr = 0; jr < RPW + 4; ++jr) {
+    const Row12 r = read_row(tile, wave * RPW + jr, c0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hsum[k] = hsum[k + 1];
-    const uint8_t* p = &tile[r0 + rr + 4][c];
-    hsum[4] = p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4];
-    const int gy = ty0 + r0 + rr;
-    if (gy < h) {
-      const int v = hsum[0] + 4 * hsum[1] + 6 * hsum[2] + 4 * hsum[3] + hsum[4];
-      out[(int64_t)gy * w] = (uint8_t)((v + 128) >> 8);
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hs[k][q] = hs[k + 1][q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hs[4][q] = r.at(q - 2) + 4 * r.at(q - 1) + 6 * r.at(q) + 4 * r.at(q + 1) + r.at(q + 2);
+    if (rawp && jr >= 2 && jr < RPW + 2) {
+      const int gy = ty0 + wave * RPW + jr - 2;
+      if (gy < h) {
+        if (full) *reinterpret_cast<uint32_t*>(rawp + (int64_t)gy * w + gx) = r.d1;
+        else
+          for (int q = 0; q < 4 && gx + q < w; ++q) rawp[(int64_t)gy * w + gx + q] = (uint8_t)r.at(q);
+      }
+    }
+    if (jr >= 4) {
+      const int gy = ty0 + wave * RPW + jr - 4;
+      if (gy < h) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int v = hs[0][q] + 4 * hs[1][q] + 6 * hs[2][q] + 4 * hs[3][q] + hs[4][q];
+          packed |= (uint32_t)((v + 128) >> 8) << (8 * q);
+        }
+        if (full) *reinterpret_cast<uint32_t*>(outp + (int64_t)gy * w + gx) = packed;
+        else
+          for (int q = 0; q < 4 && gx + q < w; ++q) outp[(int64_t)gy * w + gx + q] = (uint8_t)(packed >> (8 * q));
+      }
     }
   }
 }
 
-// ---- shared loader: blurred tile with halo HALO (reflect-101) into LDS -------------------
-template <int HALO, int LS>
-__device__ __forceinline__ void load_blur_tile(const uint8_t* __restrict__ plane_ptr, int h, int w, int tx0, int ty0,
-                                               uint8_t (*tile)[LS]) {
-  constexpr int LW = TW + 2 * HALO, LH = TH + 2 * HALO;
-  for (int i = threadIdx.x; i < LH * LW; i += NT) {
-    const int r = i / LW, c = i - r * LW;
-    const int gy = mg_reflect101(ty0 + r - HALO, h), gx = mg_reflect101(tx0 + c - HALO, w);
-    tile[r][c] = plane_ptr[(int64_t)gy * w + gx];
+// Scharr of 4 adjacent pixels from three rows (bytes c0-1 .. c0+4 of each).
+__device__ __forceinline__ void scharr4(const Row12& a, const Row12& b, const Row12& c, int (&dx)[4], int (&dy)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    dx[q] = 3 * (a.at(q + 1) - a.at(q - 1)) + 10 * (b.at(q + 1) - b.at(q - 1)) + 3 * (c.at(q + 1) - c.at(q - 1));
+    dy[q] = 3 * (c.at(q - 1) - a.at(q - 1)) + 10 * (c.at(q) - a.at(q)) + 3 * (c.at(q + 1) - a.at(q + 1));
   }
-}
-
-// Scharr at LDS position (r, c): dx = right - left, dy = below - above, weights 3/10/3.
-template <int LS>
-__device__ __forceinline__ void scharr_at(const uint8_t (*t)[LS], int r, int c, int& dx, int& dy) {
-  const int a = t[r - 1][c - 1], b = t[r - 1][c], cc = t[r - 1][c + 1];
-  const int d = t[r][c - 1], f = t[r][c + 1];
-  const int g = t[r + 1][c - 1], hh = t[r + 1][c], i = t[r + 1][c + 1];
-  dx = 3 * (cc - a) + 10 * (f - d) + 3 * (i - g);
-  dy = 3 * (g - a) + 10 * (hh - b) + 3 * (i - cc);
 }
 
 // ---- K2: histogram of m = dx^2 + dy^2 ------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ d_blur, int h, int w,
-                                                    const uint32_t* __restrict__ d_base, int shift, int n_bins,
+// mode 0 (combined): bins [0, 8192) hold m exactly, bins 8192 + (m >> 13) hold the rest coarsely;
+// mode 1 (window):   bin m - base for m in [base, base + 8192).
+// m == 0 (flat background, by far the most frequent value) is counted in registers.
+constexpr int FINE = 8192;
+constexpr int COARSE = 4096;
+
+__global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ d_blur, int h, int w, int mode,
+                                                    const uint32_t* __restrict__ d_base, int n_bins,
                                                     uint32_t* __restrict__ d_hist) {
-  constexpr int LS = TW + 4;
-  __shared__ uint8_t tile[TH + 2][LS];
-  extern __shared__ uint32_t hist[];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t (*tile)[LS] = reinterpret_cast<uint8_t (*)[LS]>(smem);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (TH + 2) * LS);
   const int plane = blockIdx.z;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
   for (int i = threadIdx.x; i < n_bins; i += NT) hist[i] = 0;
-  load_blur_tile<1, LS>(d_blur + (int64_t)plane * h * w, h, w, tx0, ty0, tile);
+  U8Scale sc;
+  sc.passthrough = 1;
+  load_tile<uint8_t, 1>(d_blur + (int64_t)plane * h * w, w, h, w, tx0, ty0, sc, tile);
   __syncthreads();
-  const uint32_t base = d_base ? d_base[plane] : 0u;
-  const int c = threadIdx.x % TW;
-  const int r0 = (threadIdx.x / TW) * ROWS_PER_THREAD;
-  constexpr uint32_t NONE = 0xFFFFFFFFu;
-  for (int rr = 0; rr < ROWS_PER_THREAD; ++rr) {
-    uint32_t bin = NONE;
-    if (tx0 + c < w && ty0 + r0 + rr < h) {
-      int dx, dy;
-      scharr_at<LS>(tile, r0 + rr + 1, c + 1, dx, dy);
-      const uint32_t m = (uint32_t)(dx * dx + dy * dy);
-      if (m >= base) {
-        const uint32_t b = (m - base) >> shift;
-        if (b < (uint32_t)n_bins) bin = b;
+  const uint32_t base = (mode == 1 && d_base) ? d_base[plane] : 0u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = 4 * lane, gx = tx0 + c0;
+  uint32_t zeros = 0;
+  Row12 ra = read_row(tile, wave * RPW, c0), rb = read_row(tile, wave * RPW + 1, c0);
+#pragma unroll 4
+  for (int jr = 2; jr < RPW + 2; ++jr) {
+    const Row12 rc = read_row(tile, wave * RPW + jr, c0);
+    const int gy = ty0 + wave * RPW + jr - 2;
+    if (gy < h && gx < w) {
+      int dx[4], dy[4];
+      scharr4(ra, rb, rc, dx, dy);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (gx + q >= w) continue;
+        const uint32_t m = (uint32_t)(dx[q] * dx[q] + dy[q] * dy[q]);
+        if (mode == 0) {
+          if (m == 0) ++zeros;
+          else atomicAdd(&hist[m < FINE ? m : FINE + (m >> 13)], 1u);
+        } else if (m >= base && m - base < (uint32_t)n_bins) {
+          if (m == base) ++zeros;
+          else atomicAdd(&hist[m - base], 1u);
+        }
       }
     }
-    // Flat regions put a whole wave into one bin: add 64 once instead of 64 colliding atomics.
-    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
-    if (__all(bin == first)) {
-      if ((threadIdx.x & 63) == 0 && first != NONE) atomicAdd(&hist[first], 64u);
-    } else if (bin != NONE) {
-      atomicAdd(&hist[bin], 1u);
-    }
+    ra = rb;
+    rb = rc;
   }
+  zeros = (uint32_t)mg_wave_sum_i32((int)zeros);
+  if (lane == 0 && zeros) atomicAdd(&hist[0], zeros);
   __syncthreads();
   uint32_t* out = d_hist + (int64_t)plane * n_bins;
   for (int i = threadIdx.x; i < n_bins; i += NT) {
@@ -166,73 +231,138 @@ __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ 
   }
 }
 
-// ---- K3: Canny non-maximum suppression + double threshold ------------------------------------
+// ---- bit helpers on the linear (y * w + x) bitmaps --------------------------------------------
+__device__ __forceinline__ uint32_t bits_at(const uint32_t* __restrict__ bits, int64_t bit0, int n) {
+  // n (1..32) consecutive bits starting at linear bit index bit0
+  const int64_t wi = bit0 >> 5;
+  const int sh = (int)(bit0 & 31);
+  uint64_t two = bits[wi];
+  if (sh + n > 32) two |= (uint64_t)bits[wi + 1] << 32;
+  const uint32_t v = (uint32_t)(two >> sh);
+  return n >= 32 ? v : (v & ((1u << n) - 1u));
+}
+__device__ __forceinline__ void bits_or(uint32_t* __restrict__ bits, int64_t bit0, uint32_t v) {
+  // OR a 32-bit group whose bit 0 sits at linear bit index bit0
+  if (!v) return;
+  const int64_t wi = bit0 >> 5;
+  const int sh = (int)(bit0 & 31);
+  atomicOr(&bits[wi], v << sh);
+  if (sh && (v >> (32 - sh))) atomicOr(&bits[wi + 1], v >> (32 - sh));
+}
+// Row segment [x0, x0 + 32) of image row y, zero outside the image.
+__device__ __forceinline__ uint32_t row_word(const uint32_t* __restrict__ bits, int h, int w, int y, int x0) {
+  if (y < 0 || y >= h) return 0u;
+  const int lo = max(x0, 0), hi = min(x0 + 32, w);
+  if (lo >= hi) return 0u;
+  return bits_at(bits, (int64_t)y * w + lo, hi - lo) << (lo - x0);
+}
+
+// ---- K3: Canny non-maximum suppression + double threshold -> weak / strong bitmaps --------------
 __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_blur, int h, int w,
-                                                  const int32_t* __restrict__ d_thresh, uint8_t* __restrict__ d_map) {
-  constexpr int LS = TW + 4;
-  constexpr int MW = TW + 2, MH = TH + 2, MS = TW + 3;
-  __shared__ uint8_t tile[TH + 4][LS];
-  __shared__ int mag[MH][MS];
+                                                  const int32_t* __restrict__ d_thresh, int64_t words_per_plane,
+                                                  uint32_t* __restrict__ d_weak, uint32_t* __restrict__ d_strong) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[TH + 4][LS];
   const int plane = blockIdx.z;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-  load_blur_tile<2, LS>(d_blur + (int64_t)plane * h * w, h, w, tx0, ty0, tile);
-  __syncthreads();
-  // Magnitudes on the tile + 1 halo; zero outside the image (OpenCV's zeroed border rows/cols).
-  for (int i = threadIdx.x; i < MH * MW; i += NT) {
-    const int r = i / MW, c = i - r * MW;
-    const int gy = ty0 + r - 1, gx = tx0 + c - 1;
-    int m = 0;
-    if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
-      int dx, dy;
-      scharr_at<LS>(tile, r + 1, c + 1, dx, dy);
-      m = dx * dx + dy * dy;
-    }
-    mag[r][c] = m;
-  }
+  U8Scale sc;
+  sc.passthrough = 1;
+  load_tile<uint8_t, 2>(d_blur + (int64_t)plane * h * w, w, h, w, tx0, ty0, sc, tile);
   __syncthreads();
   const int low = d_thresh[2 * plane], high = d_thresh[2 * plane + 1];
-  const int c = threadIdx.x % TW;
-  const int r0 = (threadIdx.x / TW) * ROWS_PER_THREAD;
-  if (tx0 + c >= w) return;
-  uint8_t* out = d_map + ((int64_t)plane * h) * w + tx0 + c;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = 4 * lane, gx = tx0 + c0;
+  uint32_t* weak = d_weak + plane * words_per_plane;
+  uint32_t* strong = d_strong + plane * words_per_plane;
   constexpr int TG22 = 13573;
-  for (int rr = 0; rr < ROWS_PER_THREAD; ++rr) {
-    const int gy = ty0 + r0 + rr;
-    if (gy >= h) break;
-    const int mr = r0 + rr + 1, mc = c + 1;
-    const int m = mag[mr][mc];
-    uint8_t v = 1;
-    if (m > low) {
-      int xs, ys;
-      scharr_at<LS>(tile, mr + 1, mc + 1, xs, ys);
-      const int x = abs(xs);
-      const int y = abs(ys) << 15;
-      const int tg22x = x * TG22;
-      bool is_max;
-      if (y < tg22x) {
-        is_max = m > mag[mr][mc - 1] && m >= mag[mr][mc + 1];
-      } else {
-        const int tg67x = tg22x + (x << 16);
-        if (y > tg67x) {
-          is_max = m > mag[mr - 1][mc] && m >= mag[mr + 1][mc];
+  // mag rows: 6 magnitudes (cols c0-1 .. c0+4) of image rows y-1, y, y+1; zero outside the image
+  int mg[3][6];
+  int cdx[2][4], cdy[2][4];  // gradients of the lane's 4 pixels for the two newest mag rows
+  Row12 ra = read_row(tile, wave * RPW, c0), rb = read_row(tile, wave * RPW + 1, c0);
+#pragma unroll
+  for (int jr = 2; jr < RPW + 4; ++jr) {
+    const Row12 rc = read_row(tile, wave * RPW + jr, c0);
+    // magnitudes of image row ym (centre row of tile rows jr-2, jr-1, jr)
+    const int ym = ty0 - 2 + wave * RPW + jr - 1;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) mg[0][k] = mg[1][k], mg[1][k] = mg[2][k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cdx[0][q] = cdx[1][q], cdy[0][q] = cdy[1][q];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int q = k - 1;  // pixel c0 + q
+      const int ddx = 3 * (ra.at(q + 1) - ra.at(q - 1)) + 10 * (rb.at(q + 1) - rb.at(q - 1)) + 3 * (rc.at(q + 1) - rc.at(q - 1));
+      const int ddy = 3 * (rc.at(q - 1) - ra.at(q - 1)) + 10 * (rc.at(q) - ra.at(q)) + 3 * (rc.at(q + 1) - ra.at(q + 1));
+      const int x = gx + q;
+      mg[2][k] = (ym >= 0 && ym < h && x >= 0 && x < w) ? ddx * ddx + ddy * ddy : 0;
+      if (k >= 1 && k <= 4) {
+        cdx[1][k - 1] = ddx;
+        cdy[1][k - 1] = ddy;
+      }
+    }
+    ra = rb;
+    rb = rc;
+    if (jr < 4) continue;
+    // NMS of image row yo = ym - 1 (mag rows 0, 1, 2 = yo - 1, yo, yo + 1; gradients in cd*[0])
+    const int yo = ym - 1;
+    uint32_t wb = 0, sb = 0;
+    if (yo < h) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (gx + q >= w) continue;
+        const int m = mg[1][q + 1];
+        if (m <= low) continue;
+        const int xs = cdx[0][q], ys = cdy[0][q];
+        const int x = abs(xs), y = abs(ys) << 15;
+        const int tg22x = x * TG22;
+        bool is_max;
+        if (y < tg22x) {
+          is_max = m > mg[1][q] && m >= mg[1][q + 2];
         } else {
-          const int s = (xs ^ ys) < 0 ? -1 : 1;
-          is_max = m > mag[mr - 1][mc - s] && m > mag[mr + 1][mc + s];
+          const int tg67x = tg22x + (x << 16);
+          if (y > tg67x) {
+            is_max = m > mg[0][q + 1] && m >= mg[2][q + 1];
+          } else {
+            const int s = (xs ^ ys) < 0 ? -1 : 1;
+            is_max = m > mg[0][q + 1 - s] && m > mg[2][q + 1 + s];
+          }
+        }
+        if (is_max) {
+          wb |= 1u << q;
+          if (m > high) sb |= 1u << q;
         }
       }
-      if (is_max) v = m > high ? 2 : 0;
     }
-    out[(int64_t)gy * w] = v;
+    // 8 lanes x 4 bits -> one 32-bit word
+    wb <<= 4 * (lane & 7);
+    sb <<= 4 * (lane & 7);
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+      wb |= (uint32_t)__shfl_xor((int)wb, off);
+      sb |= (uint32_t)__shfl_xor((int)sb, off);
+    }
+    if ((lane & 7) == 0 && yo < h && gx < w) {
+      const int64_t bit0 = (int64_t)yo * w + gx;
+      if ((bit0 & 31) == 0 && gx + 32 <= w) {  // the word belongs to this lane group alone
+        weak[bit0 >> 5] = wb;
+        strong[bit0 >> 5] = sb;
+      } else {
+        bits_or(weak, bit0, wb);
+        bits_or(strong, bit0, sb);
+      }
+    }
   }
 }
 
-// ---- K4: hysteresis sweep ------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_hysteresis(uint8_t* __restrict__ d_map, int h, int w,
+// ---- K4: hysteresis sweep, bit-parallel ---------------------------------------------------------
+constexpr int HW = TW / 32;  // interior words per tile row (8)
+
+__global__ __launch_bounds__(NT) void k_hysteresis(const uint32_t* __restrict__ d_weak, uint32_t* __restrict__ d_strong,
+                                                   int64_t words_per_plane, int h, int w,
                                                    uint32_t* __restrict__ d_changed,
                                                    const uint8_t* __restrict__ d_flags_in,
                                                    uint8_t* __restrict__ d_flags_out) {
-  constexpr int LS = TW + 4;
-  __shared__ uint8_t t[TH + 2][LS];
+  __shared__ uint32_t st[TH + 2][HW + 2];
+  __shared__ uint32_t wk[TH][HW];
   const int plane = blockIdx.z;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
   const int ntx = gridDim.x, nty = gridDim.y;
@@ -247,109 +377,79 @@ __global__ __launch_bounds__(NT) void k_hysteresis(uint8_t* __restrict__ d_map, 
       }
     if (!active) return;
   }
-  uint8_t* pm = d_map + (int64_t)plane * h * w;
-  int has_weak = 0, has_strong = 0;
-  for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += NT) {
-    const int r = i / (TW + 2), c = i - r * (TW + 2);
-    const int gy = ty0 + r - 1, gx = tx0 + c - 1;
-    uint8_t v = 1;
-    if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = pm[(int64_t)gy * w + gx];
-    t[r][c] = v;
-    has_weak |= (v == 0);
-    has_strong |= (v == 2);
+  const uint32_t* weak = d_weak + plane * words_per_plane;
+  uint32_t* strong = d_strong + plane * words_per_plane;
+  int pending = 0;
+  for (int i = threadIdx.x; i < (TH + 2) * (HW + 2); i += NT) {
+    const int r = i / (HW + 2), k = i - r * (HW + 2);
+    st[r][k] = row_word(strong, h, w, ty0 - 1 + r, tx0 - 32 + 32 * k);
   }
-  const int any_weak = __syncthreads_or(has_weak);
-  const int any_strong = __syncthreads_or(has_strong);
-  if (!any_weak || !any_strong) return;
-  const int c = threadIdx.x % TW + 1;
-  const int r0 = (threadIdx.x / TW) * ROWS_PER_THREAD + 1;
-  uint32_t mine = 0;  // bit rr set: pixel promoted by this thread
+  for (int i = threadIdx.x; i < TH * HW; i += NT) {
+    const int r = i / HW, k = i - r * HW;
+    wk[r][k] = row_word(weak, h, w, ty0 + r, tx0 + 32 * k);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TH * HW; i += NT) {
+    const int r = i / HW, k = i - r * HW;
+    pending |= (wk[r][k] & ~st[r + 1][k + 1]) != 0;
+  }
+  if (!__syncthreads_or(pending)) return;
+  uint32_t first[TH * HW / NT];  // this thread's strong words before the sweep
+#pragma unroll
+  for (int j = 0; j < TH * HW / NT; ++j) {
+    const int i = threadIdx.x + j * NT;
+    first[j] = st[i / HW + 1][i % HW + 1];
+  }
   int again;
   do {
     int changed = 0;
-    for (int rr = 0; rr < ROWS_PER_THREAD; ++rr) {
-      const int r = r0 + rr;
-      if (t[r][c] == 0) {
-        const bool nb = t[r - 1][c - 1] == 2 || t[r - 1][c] == 2 || t[r - 1][c + 1] == 2 || t[r][c - 1] == 2 ||
-                        t[r][c + 1] == 2 || t[r + 1][c - 1] == 2 || t[r + 1][c] == 2 || t[r + 1][c + 1] == 2;
-        if (nb) {
-          t[r][c] = 2;
-          mine |= 1u << rr;
-          changed = 1;
-        }
+#pragma unroll
+    for (int j = 0; j < TH * HW / NT; ++j) {
+      const int i = threadIdx.x + j * NT;
+      const int r = i / HW + 1, k = i % HW + 1;
+      const uint32_t cand = wk[r - 1][k - 1] & ~st[r][k];
+      if (!cand) continue;
+      uint32_t dil = 0;
+#pragma unroll
+      for (int dr = -1; dr <= 1; ++dr) {
+        const uint32_t c = st[r + dr][k], l = st[r + dr][k - 1], rt = st[r + dr][k + 1];
+        dil |= c | (c << 1) | (c >> 1) | (l >> 31) | (rt << 31);
+      }
+      const uint32_t nw = cand & dil;
+      if (nw) {
+        st[r][k] |= nw;
+        changed = 1;
       }
     }
     again = __syncthreads_or(changed);
   } while (again);
-  for (int rr = 0; rr < ROWS_PER_THREAD; ++rr)
-    if (mine & (1u << rr)) pm[(int64_t)(ty0 + r0 - 1 + rr) * w + (tx0 + c - 1)] = 2;
-  if (__syncthreads_or(mine != 0) && threadIdx.x == 0) {
+  int wrote = 0;
+#pragma unroll
+  for (int j = 0; j < TH * HW / NT; ++j) {
+    const int i = threadIdx.x + j * NT;
+    const int r = i / HW, k = i % HW;
+    const uint32_t diff = st[r + 1][k + 1] & ~first[j];
+    if (diff) {
+      bits_or(strong, (int64_t)(ty0 + r) * w + tx0 + 32 * k, diff);  // only in-image bits can be set
+      wrote = 1;
+    }
+  }
+  if (__syncthreads_or(wrote) && threadIdx.x == 0) {
     atomicAdd(&d_changed[plane], 1u);
     if (d_flags_out) d_flags_out[(int64_t)plane * ntx * nty + blockIdx.y * ntx + blockIdx.x] = 1;
   }
 }
 
-// ---- K5: finalise: edge bitmap (+ optional {0,1} byte map and angle map) ----------------------
-// One thread owns 16 consecutive pixels (one 16-byte load of the Canny map); a pair of lanes
-// forms one 32-bit word of the bitmap (bit i of word k <-> linear pixel 32 k + i).
-__global__ __launch_bounds__(NT) void k_edges_finalize(uint8_t* __restrict__ d_map, const uint8_t* __restrict__ d_blur,
-                                                       int h, int w, int64_t words_per_plane,
-                                                       uint32_t* __restrict__ d_bits, int write_bytes,
-                                                       float* __restrict__ d_angle) {
+// ---- inspection: bitmap -> {0,1} bytes ------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_unpack_bits(const uint32_t* __restrict__ d_bits, int64_t words_per_plane,
+                                                    int64_t npix, uint8_t* __restrict__ d_out) {
   const int plane = blockIdx.y;
-  const int64_t npix = (int64_t)h * w;
-  uint8_t* pm = d_map + plane * npix;
-  uint32_t* bits = d_bits + plane * words_per_plane;
-  float* pa = d_angle ? d_angle + plane * npix : nullptr;
-  const int64_t n_chunks = (npix + 15) / 16;
-  const int64_t n_iter = (n_chunks + (int64_t)gridDim.x * NT - 1) / ((int64_t)gridDim.x * NT);
-  for (int64_t it = 0; it < n_iter; ++it) {
-    const int64_t chunk = (it * gridDim.x + blockIdx.x) * NT + threadIdx.x;  // all lanes stay in the loop
-    const int64_t i0 = chunk * 16;
-    uint32_t m16 = 0;
-    if (i0 < npix) {
-      uint8_t v[16];
-      if (i0 + 16 <= npix && ((reinterpret_cast<uintptr_t>(pm + i0) & 15) == 0)) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(pm + i0);
-        __builtin_memcpy(v, &raw, 16);
-      } else {
-        for (int j = 0; j < 16; ++j) v[j] = (i0 + j < npix) ? pm[i0 + j] : 1;
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) m16 |= (uint32_t)(v[j] == 2) << j;
-      if (write_bytes) {
-        uint8_t o[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) o[j] = (m16 >> j) & 1;
-        if (i0 + 16 <= npix && ((reinterpret_cast<uintptr_t>(pm + i0) & 15) == 0)) {
-          uint4 raw;
-          __builtin_memcpy(&raw, o, 16);
-          *reinterpret_cast<uint4*>(pm + i0) = raw;
-        } else {
-          for (int j = 0; j < 16 && i0 + j < npix; ++j) pm[i0 + j] = o[j];
-        }
-      }
-      if (pa) {  // inspection only: mark non-edge pixels (edge pixels are written by mg_edge_angles)
-        for (int j = 0; j < 16 && i0 + j < npix; ++j)
-          if (!((m16 >> j) & 1)) pa[i0 + j] = MG_NO_EDGE;
-      }
-    }
-    const uint32_t hi = (uint32_t)__shfl_down((int)m16, 1);
-    if ((threadIdx.x & 1) == 0 && i0 < npix) bits[chunk >> 1] = m16 | (hi << 16);
-  }
+  const uint32_t* bits = d_bits + plane * words_per_plane;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < npix; i += (int64_t)gridDim.x * NT)
+    d_out[plane * npix + i] = (bits[i >> 5] >> (i & 31)) & 1u;
 }
 
-// ---- K6: grid_array from the bitmap: per-cell counts, scan, ordered coordinate fill -------------
-__device__ __forceinline__ uint32_t row_bits(const uint32_t* __restrict__ bits, int64_t bit0, int n) {
-  // n (<= 32) consecutive bits starting at linear bit index bit0
-  const int64_t wi = bit0 >> 5;
-  const int sh = (int)(bit0 & 31);
-  uint64_t two = bits[wi];
-  if (sh + n > 32) two |= (uint64_t)bits[wi + 1] << 32;
-  const uint32_t v = (uint32_t)(two >> sh);
-  return n >= 32 ? v : (v & ((1u << n) - 1u));
-}
-
+// ---- K5: grid_array from the bitmap: per-cell counts, scan, ordered coordinate fill -------------
 __global__ __launch_bounds__(NT) void k_cell_count(const uint32_t* __restrict__ d_bits, int64_t words_per_plane, int h,
                                                    int w, int grid, int gc, int n_cells,
                                                    int32_t* __restrict__ d_counts) {
@@ -363,7 +463,7 @@ __global__ __launch_bounds__(NT) void k_cell_count(const uint32_t* __restrict__ 
   int cnt = 0;
   for (int r = 0; r < ch; ++r)
     for (int c0 = 0; c0 < cw; c0 += 32)
-      cnt += __popc(row_bits(bits, (int64_t)(y0 + r) * w + x0 + c0, min(32, cw - c0)));
+      cnt += __popc(bits_at(bits, (int64_t)(y0 + r) * w + x0 + c0, min(32, cw - c0)));
   d_counts[(int64_t)plane * n_cells + cell] = cnt;
 }
 
@@ -399,7 +499,7 @@ __global__ __launch_bounds__(NT) void k_cell_fill(const uint32_t* __restrict__ d
   int64_t pos = d_starts[(int64_t)plane * n_cells + cell];
   for (int r = 0; r < ch; ++r)
     for (int c0 = 0; c0 < cw; c0 += 32) {
-      uint32_t v = row_bits(bits, (int64_t)(y0 + r) * w + x0 + c0, min(32, cw - c0));
+      uint32_t v = bits_at(bits, (int64_t)(y0 + r) * w + x0 + c0, min(32, cw - c0));
       while (v) {
         const int b = __ffs(v) - 1;
         v &= v - 1;
@@ -409,7 +509,7 @@ __global__ __launch_bounds__(NT) void k_cell_fill(const uint32_t* __restrict__ d
     }
 }
 
-// ---- K6b: gradient angle at every edge pixel (thread per entry of the compact edge list) --------
+// ---- K6: gradient angle at every edge pixel (thread per entry of the compact edge list) ---------
 __global__ __launch_bounds__(NT) void k_edge_angles(const uint8_t* __restrict__ d_blur, int h, int w,
                                                     const int32_t* __restrict__ d_coords, int64_t coord_cap,
                                                     const int32_t* __restrict__ d_num_edges,
@@ -426,6 +526,9 @@ __global__ __launch_bounds__(NT) void k_edge_angles(const uint8_t* __restrict__ 
 }
 
 inline dim3 tile_grid(int h, int w, int n_planes) { return dim3((w + TW - 1) / TW, (h + TH - 1) / TH, n_planes); }
+inline bool words_ok(int64_t words_per_plane, int h, int w) {
+  return words_per_plane * 32 >= (((int64_t)h * w + 31) / 32) * 32 + 32;  // one spare word: bits_at reads wi + 1
+}
 
 }  // namespace
 
@@ -462,37 +565,53 @@ extern "C" int mg_to_uint8_blur(const void* d_src, int dtype, int n_planes, int6
   return MG_OK;
 }
 
-extern "C" int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w, const uint32_t* d_base, int shift,
-                              int n_bins, uint32_t* d_hist, void* stream) {
-  if (!d_blur || !d_hist || n_planes < 0 || h < 0 || w < 0 || shift < 0 || shift > 31 || n_bins <= 0 || n_bins > 8192)
-    return MG_EINVAL;
+extern "C" int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w, int mode, const uint32_t* d_base,
+                              uint32_t* d_hist, void* stream) {
+  if (!d_blur || !d_hist || n_planes < 0 || h < 0 || w < 0 || (mode != 0 && mode != 1)) return MG_EINVAL;
+  if (mode == 1 && !d_base) return MG_EINVAL;
   if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
   const dim3 g = tile_grid(h, w, n_planes);
   if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
-  hipLaunchKernelGGL(k_scharr_hist, g, dim3(NT), n_bins * sizeof(uint32_t), mg_stream(stream), d_blur, h, w, d_base,
-                     shift, n_bins, d_hist);
+  const int n_bins = mode == 0 ? FINE + COARSE : FINE;
+  const size_t lds = (size_t)(TH + 2) * LS + (size_t)n_bins * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_scharr_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            96 * 1024) != hipSuccess)
+      return MG_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_scharr_hist, g, dim3(NT), lds, mg_stream(stream), d_blur, h, w, mode, d_base, n_bins, d_hist);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
 
-extern "C" int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_thresh, uint8_t* d_map,
-                            void* stream) {
-  if (!d_blur || !d_thresh || !d_map || n_planes < 0 || h < 0 || w < 0) return MG_EINVAL;
+extern "C" int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_thresh,
+                            uint32_t* d_weak, uint32_t* d_strong, int64_t words_per_plane, void* stream) {
+  if (!d_blur || !d_thresh || !d_weak || !d_strong || n_planes < 0 || h < 0 || w < 0) return MG_EINVAL;
   if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
+  if (!words_ok(words_per_plane, h, w)) return MG_EINVAL;
   const dim3 g = tile_grid(h, w, n_planes);
   if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
-  hipLaunchKernelGGL(k_canny_nms, g, dim3(NT), 0, mg_stream(stream), d_blur, h, w, d_thresh, d_map);
+  hipStream_t s = mg_stream(stream);
+  const size_t bytes = (size_t)n_planes * words_per_plane * 4;
+  if (hipMemsetAsync(d_weak, 0, bytes, s) != hipSuccess || hipMemsetAsync(d_strong, 0, bytes, s) != hipSuccess)
+    return MG_ELAUNCH;
+  hipLaunchKernelGGL(k_canny_nms, g, dim3(NT), 0, s, d_blur, h, w, d_thresh, words_per_plane, d_weak, d_strong);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
 
-extern "C" int mg_canny_hysteresis(uint8_t* d_map, int n_planes, int h, int w, uint32_t* d_changed,
-                                   const uint8_t* d_flags_in, uint8_t* d_flags_out, void* stream) {
-  if (!d_map || !d_changed || n_planes < 0 || h < 0 || w < 0) return MG_EINVAL;
+extern "C" int mg_canny_hysteresis(const uint32_t* d_weak, uint32_t* d_strong, int64_t words_per_plane, int n_planes,
+                                   int h, int w, uint32_t* d_changed, const uint8_t* d_flags_in, uint8_t* d_flags_out,
+                                   void* stream) {
+  if (!d_weak || !d_strong || !d_changed || n_planes < 0 || h < 0 || w < 0) return MG_EINVAL;
   if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
+  if (!words_ok(words_per_plane, h, w)) return MG_EINVAL;
   const dim3 g = tile_grid(h, w, n_planes);
   if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
-  hipLaunchKernelGGL(k_hysteresis, g, dim3(NT), 0, mg_stream(stream), d_map, h, w, d_changed, d_flags_in, d_flags_out);
+  hipLaunchKernelGGL(k_hysteresis, g, dim3(NT), 0, mg_stream(stream), d_weak, d_strong, words_per_plane, h, w,
+                     d_changed, d_flags_in, d_flags_out);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -504,17 +623,14 @@ extern "C" int mg_hysteresis_tiles(int h, int w, int* tiles_x, int* tiles_y) {
   return MG_OK;
 }
 
-extern "C" int mg_edges_finalize(uint8_t* d_map, const uint8_t* d_blur, int n_planes, int h, int w,
-                                 uint32_t* d_edge_bits, int64_t words_per_plane, int write_bytes, float* d_angle,
-                                 void* stream) {
-  if (!d_map || !d_blur || !d_edge_bits || n_planes < 0 || h < 0 || w < 0 || n_planes > 65535) return MG_EINVAL;
-  const int64_t npix = (int64_t)h * w;
-  if (words_per_plane * 32 < ((npix + 31) / 32) * 32 || (words_per_plane & 1)) return MG_EINVAL;
-  if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
-  const int64_t n_chunks = (npix + 15) / 16;
-  const int bx = (int)std::min<int64_t>((n_chunks + NT - 1) / NT, 2048);
-  hipLaunchKernelGGL(k_edges_finalize, dim3(bx, n_planes), dim3(NT), 0, mg_stream(stream), d_map, d_blur, h, w,
-                     words_per_plane, d_edge_bits, write_bytes, d_angle);
+extern "C" int mg_unpack_bits(const uint32_t* d_bits, int64_t words_per_plane, int n_planes, int64_t n_bits,
+                              uint8_t* d_out, void* stream) {
+  if (!d_bits || !d_out || n_planes < 0 || n_planes > 65535 || n_bits < 0 || words_per_plane * 32 < n_bits)
+    return MG_EINVAL;
+  if (n_planes == 0 || n_bits == 0) return MG_OK;
+  const int bx = (int)std::min<int64_t>((n_bits + NT - 1) / NT, 4096);
+  hipLaunchKernelGGL(k_unpack_bits, dim3(bx, n_planes), dim3(NT), 0, mg_stream(stream), d_bits, words_per_plane, n_bits,
+                     d_out);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -526,6 +642,7 @@ extern "C" int mg_edge_grid(const uint32_t* d_edge_bits, int64_t words_per_plane
       n_planes > 65535)
     return MG_EINVAL;
   if (n_planes == 0) return MG_OK;
+  if (!words_ok(words_per_plane, h, w)) return MG_EINVAL;
   const int gr = (h + grid - 1) / grid, gc = (w + grid - 1) / grid, n_cells = gr * gc;
   hipStream_t s = mg_stream(stream);
   if (!d_coords) {  // phase 1: counts + scan (the caller sizes the coordinate list from d_num_edges)

@@ -239,6 +239,7 @@ def canny_int_thresholds(lo: float, hi: float):
 COARSE_SHIFT = 13
 COARSE_BINS = 4096  # covers m < 2**25 (max 2 * 4080**2 = 33 292 800)
 FINE_BINS = 1 << COARSE_SHIFT
+COMBINED_BINS = FINE_BINS + COARSE_BINS
 
 
 # --------------------------------------------------------------------------------------
@@ -267,17 +268,18 @@ class CircleFinder:
         self.n_cells = self.gr * self.gc
         i32, u8 = torch.int32, torch.uint8
         self.blur = torch.empty((P, h, w), dtype=u8, device=dev)
-        self.edges = torch.empty((P, h, w), dtype=u8, device=dev)  # Canny map, then {0,1} edges
+        self.edges = None  # {0,1} byte map, only with keep_debug_maps
         self.angle = torch.empty((P, h, w), dtype=torch.float32, device=dev)  # valid at edge pixels
-        self.hist = torch.zeros((P, FINE_BINS), dtype=i32, device=dev)
+        self.hist = torch.zeros((P, COMBINED_BINS), dtype=i32, device=dev)
         self.hist_base = torch.zeros((P,), dtype=i32, device=dev)
         self.thresh = torch.zeros((P, 2), dtype=i32, device=dev)
         self.changed = torch.zeros((P,), dtype=i32, device=dev)
         tx, ty = nat.C.c_int(0), nat.C.c_int(0)
         nat.check(nat.lib().mg_hysteresis_tiles(h, w, nat.C.byref(tx), nat.C.byref(ty)), "mg_hysteresis_tiles")
         self.tile_flags = torch.zeros((2, P, ty.value, tx.value), dtype=u8, device=dev)
-        self.words = 2 * ((h * w + 63) // 64)  # edge bitmap words per plane (even)
-        self.edge_bits = torch.zeros((P, self.words), dtype=i32, device=dev)
+        self.words = 2 * ((h * w + 63) // 64) + 2  # bitmap words per plane (even, one spare)
+        self.edge_bits = torch.zeros((P, self.words), dtype=i32, device=dev)  # strong bits = edges
+        self.weak_bits = torch.zeros((P, self.words), dtype=i32, device=dev)
         self.keep_debug_maps = False  # True: also produce the {0,1} byte map and the angle map (tests)
         self.cell_counts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
         self.cell_starts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
@@ -321,36 +323,37 @@ class CircleFinder:
         self.u8 = torch.empty((P, h, w), dtype=torch.uint8, device=self.dev) if keep_u8 else None
         _call("mg_to_uint8_blur", planes.data_ptr(), code, P, planes.stride(0), h, w, planes.stride(1),
                                      _ptr(minmax), self.blur.data_ptr(), _ptr(self.u8), s)
-        # coarse histogram of m = dx^2 + dy^2
+        # one-pass combined histogram of m = dx^2 + dy^2: exact below 8192, coarse (m >> 13) above
         self.hist.zero_()
-        _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 0, COARSE_SHIFT, COARSE_BINS, self.hist.data_ptr(), s)
-        # NB: rows of self.hist are FINE_BINS wide; the coarse pass used the first COARSE_BINS of a
-        # COARSE_BINS-strided view, so read it back through the same flat layout.
-        flat = self.hist.view(-1)[: P * COARSE_BINS].view(P, COARSE_BINS)
-        ccum = torch.cumsum(flat.to(torch.int64), dim=1).cpu().numpy()
+        _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 0, 0, self.hist.data_ptr(), s)
+        ccum = torch.cumsum(self.hist.to(torch.int64), dim=1).cpu().numpy()
         n = h * w
-        want = []  # per plane: the order-statistic ranks needed
+        want = []
         for q in (low_q, high_q):
             a, b, _ = quantile_indexes(n, q)
             want += [a, b]
         ranks = sorted(set(want))
-        # coarse bin of every needed rank, per plane
+        # bin of every needed rank, per plane: fine bins give the order statistic directly
         bins = np.stack([np.array([np.searchsorted(ccum[p], r, side="right") for r in ranks]) for p in range(P)])
-        order_stat = np.zeros((P, len(ranks)), dtype=np.int64)
-        todo = [sorted(set(bins[p].tolist())) for p in range(P)]
+        order_stat = np.where(bins < FINE_BINS, bins, -1).astype(np.int64)
+        todo = [sorted({int(b) - FINE_BINS for b in bins[p] if b >= FINE_BINS}) for p in range(P)]
         n_pass = max(len(t) for t in todo)
+        self.stats["hist_passes"] = 1 + n_pass
         for k in range(n_pass):
-            base_bins = np.array([t[min(k, len(t) - 1)] for t in todo], dtype=np.int64)
+            # window pass(es): resolve ranks that fell into a coarse bin (rare: strong gradients)
+            base_bins = np.array([t[min(k, len(t) - 1)] if t else 0 for t in todo], dtype=np.int64)
             self.hist_base.copy_(torch.from_numpy((base_bins << COARSE_SHIFT).astype(np.int32)))
-            self.hist.zero_()
-            _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, self.hist_base.data_ptr(), 0, FINE_BINS,
-                                       self.hist.data_ptr(), s)
-            fcum = torch.cumsum(self.hist.to(torch.int64), dim=1).cpu().numpy()
+            fine = self.hist.view(-1)[: P * FINE_BINS].view(P, FINE_BINS)
+            fine.zero_()
+            _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 1, self.hist_base.data_ptr(), fine.data_ptr(), s)
+            fcum = torch.cumsum(fine.to(torch.int64), dim=1).cpu().numpy()
             for p in range(P):
+                if not todo[p]:
+                    continue
                 b = base_bins[p]
-                below = ccum[p, b - 1] if b > 0 else 0
+                below = ccum[p, FINE_BINS + b - 1]
                 for j, r in enumerate(ranks):
-                    if bins[p, j] == b:
+                    if bins[p, j] == FINE_BINS + b:
                         order_stat[p, j] = (b << COARSE_SHIFT) + np.searchsorted(fcum[p], r - below, side="right")
         thresh = np.zeros((P, 2), dtype=np.int32)
         self.quantiles = np.zeros((P, 2), dtype=np.float32)
@@ -364,21 +367,23 @@ class CircleFinder:
             self.quantiles[p] = vals
             thresh[p] = canny_int_thresholds(vals[0], vals[1])
         self.thresh.copy_(torch.from_numpy(thresh))
-        _call("mg_canny_nms", self.blur.data_ptr(), P, h, w, self.thresh.data_ptr(), self.edges.data_ptr(), s)
+        _call("mg_canny_nms", self.blur.data_ptr(), P, h, w, self.thresh.data_ptr(), self.weak_bits.data_ptr(),
+              self.edge_bits.data_ptr(), self.words, s)
         sweeps = 0
         while True:
             self.changed.zero_()
             cur = self.tile_flags[sweeps & 1]
             cur.zero_()
             prev = self.tile_flags[(sweeps + 1) & 1] if sweeps > 0 else None
-            _call("mg_canny_hysteresis", self.edges.data_ptr(), P, h, w, self.changed.data_ptr(), _ptr(prev),
-                  cur.data_ptr(), s)
+            _call("mg_canny_hysteresis", self.weak_bits.data_ptr(), self.edge_bits.data_ptr(), self.words, P, h, w,
+                  self.changed.data_ptr(), _ptr(prev), cur.data_ptr(), s)
             sweeps += 1
             if int(self.changed.sum().item()) == 0:
                 break
         self.stats["hysteresis_sweeps"] = sweeps
-        _call("mg_edges_finalize", self.edges.data_ptr(), self.blur.data_ptr(), P, h, w, self.edge_bits.data_ptr(),
-              self.words, int(self.keep_debug_maps), _ptr(self.angle if self.keep_debug_maps else None), s)
+        if self.keep_debug_maps:
+            self.edges = torch.empty((P, h, w), dtype=torch.uint8, device=self.dev)
+            _call("mg_unpack_bits", self.edge_bits.data_ptr(), self.words, P, h * w, self.edges.data_ptr(), s)
         _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, P, h, w, self.grid, self.cell_counts.data_ptr(),
               self.cell_starts.data_ptr(), self.num_edges.data_ptr(), 0, 0, s)
         n_edges = self.num_edges.cpu().numpy()
@@ -468,6 +473,25 @@ class CircleFinder:
 # --------------------------------------------------------------------------------------
 
 _HALF_CACHE = {}
+_POOL = {}
+
+
+def pooled(name, count, tail, dtype, device):
+    """A (count, *tail) view of a grow-only device buffer.  Output sizes depend on the number of
+    markers found, which varies from call to call; re-using one buffer (grown by 25 % when needed)
+    keeps hipMalloc out of the steady state.  The view is valid until the next call with ``name``."""
+    key = (name, tuple(tail), dtype, str(device))
+    buf = _POOL.get(key)
+    if buf is None or buf.shape[0] < count:
+        _POOL[key] = None  # release the old block before growing
+        buf = torch.empty((int(count * 1.25) + 1,) + tuple(tail), dtype=dtype, device=device)
+        _POOL[key] = buf
+    return buf[:count]
+
+
+def release_pool():
+    _POOL.clear()
+
 
 
 def _halfwidth_table(max_r: int, device):
@@ -505,11 +529,12 @@ def circle_labels(beads_per_assay, h, w, device="cuda"):
 
 
 def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, labels: torch.Tensor | None,
-                      want_roi=True, want_masks=True, want_sums=True):
+                      want_roi=True, want_masks=True, want_sums=True, reuse_buffers=False):
     """images (A, C, T, h, w); centers_per_assay: list of (M_a, >=2) int arrays [row, col, ...].
 
     Returns dict: roi (M, C, T, L, L), fg/bg (M, L, L) uint8, sums (M, C, T, 2) float64
-    [fg sum, bg sum], counts (M, 2) int32, offsets (A+1,) numpy."""
+    [fg sum, bg sum], counts (M, 2) int32, offsets (A+1,) numpy.  ``reuse_buffers`` returns views of
+    pooled buffers that the next call overwrites (steady-state streaming use)."""
     require_gpu()
     a, c, t, h, w = images.shape
     images = images.contiguous()
@@ -519,11 +544,12 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
     offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     res = {"offsets": offsets}
     L = int(roi_len)
-    res["roi"] = torch.empty((m, c, t, L, L), dtype=images.dtype, device=dev) if want_roi else None
-    res["fg"] = torch.empty((m, L, L), dtype=torch.uint8, device=dev) if want_masks else None
-    res["bg"] = torch.empty((m, L, L), dtype=torch.uint8, device=dev) if want_masks else None
-    res["sums"] = torch.empty((m, c, t, 2), dtype=torch.float64, device=dev) if want_sums else None
-    res["counts"] = torch.empty((m, 2), dtype=torch.int32, device=dev) if want_sums else None
+    alloc = pooled if reuse_buffers else (lambda name, n, tail, dt, d: torch.empty((n,) + tuple(tail), dtype=dt, device=d))
+    res["roi"] = alloc("roi", m, (c, t, L, L), images.dtype, dev) if want_roi else None
+    res["fg"] = alloc("fg", m, (L, L), torch.uint8, dev) if want_masks else None
+    res["bg"] = alloc("bg", m, (L, L), torch.uint8, dev) if want_masks else None
+    res["sums"] = alloc("sums", m, (c, t, 2), torch.float64, dev) if want_sums else None
+    res["counts"] = alloc("counts", m, (2,), torch.int32, dev) if want_sums else None
     if m == 0:
         return res
     beads = np.zeros((m, 3), dtype=np.int32)

@@ -83,7 +83,7 @@ class StackProcessor:
             images = self.image.view(T, C, 1, h, w)
         else:
             images = self.image.permute(1, 0, 2, 3).contiguous().view(1, C, T, h, w)
-        return hp.roi_gather_reduce(images, beads, self.L, labels, want_roi=want_roi)
+        return hp.roi_gather_reduce(images, beads, self.L, labels, want_roi=want_roi, reuse_buffers=True)
 
     def __call__(self, stack, flatfield=1.0, darkfield=0.0, seed=0, want_roi=True):
         self.flatfield(stack, flatfield, darkfield)
