@@ -112,49 +112,82 @@ __device__ __forceinline__ void max_step(double t, double fl, bool fast_m2, doub
   m2 = mg_nanmax(m2, t / fl);
 }
 
+// N consecutive dark/flat operands as float64 (image of float32/float64, or the scalar).
+template <int N>
+__device__ __forceinline__ void load_field(const void* __restrict__ img, int dt, int64_t p, double scalar,
+                                           double (&out)[N]) {
+  if (!img) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) out[j] = scalar;
+  } else if (dt == MG_F32) {
+    const float* f = (const float*)img + p;
+    if ((N % 4) == 0 && (reinterpret_cast<uintptr_t>(f) & 15) == 0) {
+#pragma unroll
+      for (int q = 0; q < N / 4; ++q) {
+        const float4 v = reinterpret_cast<const float4*>(f)[q];
+        out[4 * q] = v.x;
+        out[4 * q + 1] = v.y;
+        out[4 * q + 2] = v.z;
+        out[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) out[j] = f[j];
+    }
+  } else {
+    const double* d = (const double*)img + p;
+#pragma unroll
+    for (int j = 0; j < N; ++j) out[j] = d[j];
+  }
+}
+
+// Thread = one chunk of N pixels of the tile grid; it walks over the tiles of its group, so the
+// dark/flat operands are loaded once per chunk and reused for every tile (channel) of the group.
 template <typename T>
-__global__ __launch_bounds__(256) void k_flatfield_max(const T* __restrict__ tiles, int64_t n_per_group,
+__global__ __launch_bounds__(256) void k_flatfield_max(const T* __restrict__ tiles, int64_t tiles_per_group,
                                                         int64_t tile_elems, double dark,
                                                         const void* __restrict__ d_dark, int dark_dt, double flat,
                                                         const void* __restrict__ d_flat, int flat_dt,
                                                         double* __restrict__ out) {
   constexpr int N = VecOf<T>::N;
   const int group = blockIdx.y;
-  tiles += (int64_t)group * n_per_group;
+  tiles += (int64_t)group * tiles_per_group * tile_elems;
   out += 2 * group;
-  const int64_t n = n_per_group;
   const bool fast_m2 = (d_flat == nullptr) && (flat > 0.0);  // x / flat is monotone: M2 = M1 / flat
   double m1 = -INFINITY, m2 = -INFINITY;
-  const int64_t nvec = n / N;
+  const int64_t nvec = tile_elems / N;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
-    T x[N];
-    load_vec<T, N>(tiles + v * N, x);
-    int64_t p = (d_dark || d_flat) ? (v * N) % tile_elems : 0;
+    double dk[N], fl[N];
+    load_field<N>(d_dark, dark_dt, v * N, dark, dk);
+    load_field<N>(d_flat, flat_dt, v * N, flat, fl);
+    for (int64_t g = 0; g < tiles_per_group; ++g) {
+      T x[N];
+      load_vec<T, N>(tiles + g * tile_elems + v * N, x);
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const double dk = d_dark ? mg_load_f64(d_dark, dark_dt, p) : dark;
-      const double fl = d_flat ? mg_load_f64(d_flat, flat_dt, p) : flat;
-      double t = (double)x[j] - dk;
-      t = t < 0.0 ? 0.0 : t;
-      max_step(t, fl, fast_m2, m1, m2);
-      if (++p == tile_elems) p = 0;
+      for (int j = 0; j < N; ++j) {
+        double t = (double)x[j] - dk[j];
+        t = t < 0.0 ? 0.0 : t;
+        max_step(t, fl[j], fast_m2, m1, m2);
+      }
     }
   }
-  for (int64_t i = nvec * N + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int64_t p = i % tile_elems;
+  // tail pixels of every tile (tile_elems not a multiple of N)
+  for (int64_t p = nvec * N + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < tile_elems; p += stride) {
     const double dk = d_dark ? mg_load_f64(d_dark, dark_dt, p) : dark;
     const double fl = d_flat ? mg_load_f64(d_flat, flat_dt, p) : flat;
-    double t = (double)tiles[i] - dk;
-    t = t < 0.0 ? 0.0 : t;
-    max_step(t, fl, fast_m2, m1, m2);
+    for (int64_t g = 0; g < tiles_per_group; ++g) {
+      double t = (double)tiles[g * tile_elems + p] - dk;
+      t = t < 0.0 ? 0.0 : t;
+      max_step(t, fl, fast_m2, m1, m2);
+    }
   }
   if (fast_m2) m2 = (m1 == -INFINITY) ? m1 : m1 / flat;
   block_atomic_max2(m1, m2, out);
 }
 
 // ---- pass 2: apply + stitch (+ output min/max) ----------------------------------------
-constexpr int ROWS_PER_BLOCK = 8;
+constexpr int ROWS_PER_BLOCK = 32;
 
 // out = trunc(((t / fl) * m1) / m2) for an integer output type without the two float64 divisions:
 // v = t * rcp(fl) * (m1 / m2) with a Newton-refined reciprocal agrees with the reference's three
@@ -191,27 +224,39 @@ __device__ __forceinline__ T correct_pixel(double t, double fl, double m1, doubl
   return cast_trunc<T>(e);
 }
 
+constexpr int PLANES_PER_BLOCK = 4;
+
+// Block = 256 lanes x N pixels of ROWS_PER_BLOCK output rows, for PLANES_PER_BLOCK consecutive
+// planes: the dark/flat operands of a pixel chunk are loaded once and reused across those planes.
 template <typename T, bool APPLY>
-__global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tiles, int n_tr, int n_tc, int ty, int tx,
-                                                       int clip, int hy, int hx, int planes_per_group, double dark,
-                                                       const void* __restrict__ d_dark, int dark_dt, double flat,
-                                                       const void* __restrict__ d_flat, int flat_dt,
+__global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tiles, int n_planes, int n_tr, int n_tc,
+                                                       int ty, int tx, int clip, int hy, int hx, int planes_per_group,
+                                                       double dark, const void* __restrict__ d_dark, int dark_dt,
+                                                       double flat, const void* __restrict__ d_flat, int flat_dt,
                                                        const double* __restrict__ d_max2, T* __restrict__ image,
                                                        double* __restrict__ d_minmax) {
   constexpr int N = VecOf<T>::N;
-  const int plane = blockIdx.z;
+  constexpr int PB = PLANES_PER_BLOCK;
+  const int plane0 = blockIdx.z * PB;
+  const int np = min(PB, n_planes - plane0);
   const int h_out = n_tr * hy, w_out = n_tc * hx;
   const int ox0 = (blockIdx.x * blockDim.x + threadIdx.x) * N;
-  double m1 = 0.0, m2 = 1.0, kk = 1.0;
-  bool fast_ok = false;
-  if (APPLY) {
-    const int group = plane / planes_per_group;
-    m1 = d_max2[2 * group];
-    m2 = d_max2[2 * group + 1];
-    kk = m1 / m2;
-    fast_ok = kk > 0.0 && kk < 1e30 && m1 > 0.0 && m1 < 1e300 && m2 > 0.0 && m2 < 1e300;
+  double m1[PB], m2[PB], kk[PB];
+  bool fast_ok[PB];
+#pragma unroll
+  for (int b = 0; b < PB; ++b) {
+    m1[b] = 0.0, m2[b] = 1.0, kk[b] = 1.0, fast_ok[b] = false;
+    if (APPLY && b < np) {
+      const int group = (plane0 + b) / planes_per_group;
+      m1[b] = d_max2[2 * group];
+      m2[b] = d_max2[2 * group + 1];
+      kk[b] = m1[b] / m2[b];
+      fast_ok[b] = kk[b] > 0.0 && kk[b] < 1e30 && m1[b] > 0.0 && m1[b] < 1e300 && m2[b] > 0.0 && m2[b] < 1e300;
+    }
   }
-  double vmin = INFINITY, vmax = -INFINITY;
+  double vmin[PB], vmax[PB];
+#pragma unroll
+  for (int b = 0; b < PB; ++b) vmin[b] = INFINITY, vmax[b] = -INFINITY;
   const int64_t tile_elems = (int64_t)ty * tx;
   const int row_end = min((int)(blockIdx.y + 1) * ROWS_PER_BLOCK, h_out);
   if (ox0 < w_out) {
@@ -221,71 +266,86 @@ __global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tile
     for (int oy = blockIdx.y * ROWS_PER_BLOCK; oy < row_end; ++oy) {
       const int tr = oy / hy;
       const int y = oy - tr * hy + clip;
-      T* dst = image + ((int64_t)plane * h_out + oy) * w_out + ox0;
-      T x[N], o[N];
-      int64_t pix[N];
-      int cnt = N;
-      if (one_tile) {
-        const int64_t tile_base = (((int64_t)plane * n_tr + tr) * n_tc + tc0) * tile_elems;
-        const int64_t p0 = (int64_t)y * tx + x0;
-        load_vec<T, N>(tiles + tile_base + p0, x);
+      int64_t pix[N], toff[N];  // pixel index inside the tile, element offset of the tile in a plane
+      const int cnt = one_tile ? N : min(N, w_out - ox0);
 #pragma unroll
-        for (int j = 0; j < N; ++j) pix[j] = p0 + j;
-      } else {
-        cnt = min(N, w_out - ox0);
-        for (int j = 0; j < cnt; ++j) {
-          const int ox = ox0 + j;
-          const int tc = ox / hx;
-          const int xx = ox - tc * hx + clip;
-          const int64_t tile_base = (((int64_t)plane * n_tr + tr) * n_tc + tc) * tile_elems;
-          pix[j] = (int64_t)y * tx + xx;
-          x[j] = tiles[tile_base + pix[j]];
+      for (int j = 0; j < N; ++j) {
+        const int ox = ox0 + (one_tile ? j : min(j, cnt - 1));
+        const int tc = one_tile ? tc0 : ox / hx;
+        const int xx = one_tile ? x0 + j : ox - tc * hx + clip;
+        pix[j] = (int64_t)y * tx + xx;
+        toff[j] = ((int64_t)tr * n_tc + tc) * tile_elems;
+      }
+      double dk[N], fl[N];
+      if (APPLY) {
+        if (one_tile) {
+          load_field<N>(d_dark, dark_dt, pix[0], dark, dk);
+          load_field<N>(d_flat, flat_dt, pix[0], flat, fl);
+        } else {
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            dk[j] = d_dark ? mg_load_f64(d_dark, dark_dt, pix[j]) : dark;
+            fl[j] = d_flat ? mg_load_f64(d_flat, flat_dt, pix[j]) : flat;
+          }
         }
       }
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
-        if (j < cnt) {
+      for (int b = 0; b < PB; ++b) {
+        if (b >= np) break;
+        const int64_t plane_base = (int64_t)(plane0 + b) * n_tr * n_tc * tile_elems;
+        T x[N], o[N];
+        if (one_tile) {
+          load_vec<T, N>(tiles + plane_base + toff[0] + pix[0], x);
+        } else {
+#pragma unroll
+          for (int j = 0; j < N; ++j) x[j] = tiles[plane_base + toff[j] + pix[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
           if (APPLY) {
-            const double dk = d_dark ? mg_load_f64(d_dark, dark_dt, pix[j]) : dark;
-            const double fl = d_flat ? mg_load_f64(d_flat, flat_dt, pix[j]) : flat;
-            double t = (double)x[j] - dk;
+            double t = (double)x[j] - dk[j];
             t = t < 0.0 ? 0.0 : t;
-            o[j] = correct_pixel<T>(t, fl, m1, m2, kk, fast_ok);
+            o[j] = correct_pixel<T>(t, fl[j], m1[b], m2[b], kk[b], fast_ok[b]);
           } else {
             o[j] = x[j];
           }
-          if (d_minmax) {
+          if (d_minmax && j < cnt) {
             const double ov = (double)o[j];
-            vmin = mg_nanmin(vmin, ov);
-            vmax = mg_nanmax(vmax, ov);
+            vmin[b] = IsIntegral<T>::value ? fmin(vmin[b], ov) : mg_nanmin(vmin[b], ov);
+            vmax[b] = IsIntegral<T>::value ? fmax(vmax[b], ov) : mg_nanmax(vmax[b], ov);
           }
         }
-      }
-      if (cnt == N) {
-        store_vec<T, N>(dst, o);
-      } else {
-        for (int j = 0; j < cnt; ++j) dst[j] = o[j];
+        T* dst = image + ((int64_t)(plane0 + b) * h_out + oy) * w_out + ox0;
+        if (cnt == N) {
+          store_vec<T, N>(dst, o);
+        } else {
+          for (int j = 0; j < cnt; ++j) dst[j] = o[j];
+        }
       }
     }
   }
   if (d_minmax) {
-    __shared__ double smin[4], smax[4];
-    vmin = mg_wave_nanmin(vmin);
-    vmax = mg_wave_nanmax(vmax);
+    __shared__ double smin[PB][4], smax[PB][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-      smin[wave] = vmin;
-      smax[wave] = vmax;
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      const double a = mg_wave_nanmin(vmin[b]), c = mg_wave_nanmax(vmax[b]);
+      if (lane == 0) {
+        smin[b][wave] = a;
+        smax[b][wave] = c;
+      }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < np) {
+      const int b = threadIdx.x;
+      double a = smin[b][0], c = smax[b][0];
       for (int i = 1; i < 4; ++i) {
-        vmin = mg_nanmin(vmin, smin[i]);
-        vmax = mg_nanmax(vmax, smax[i]);
+        a = mg_nanmin(a, smin[b][i]);
+        c = mg_nanmax(c, smax[b][i]);
       }
-      if (!(vmin == INFINITY && vmax == -INFINITY)) {
-        mg_atomic_nanmin(d_minmax + 2 * plane, vmin);
-        mg_atomic_nanmax(d_minmax + 2 * plane + 1, vmax);
+      if (!(a == INFINITY && c == -INFINITY)) {
+        mg_atomic_nanmin(d_minmax + 2 * (plane0 + b), a);
+        mg_atomic_nanmax(d_minmax + 2 * (plane0 + b) + 1, c);
       }
     }
   }
@@ -342,14 +402,14 @@ __global__ __launch_bounds__(256) void k_plane_minmax(const T* __restrict__ src,
 }
 
 template <typename T>
-int launch_max(const void* d_tiles, int64_t n_per_group, int n_groups, int64_t tile_elems, double dark,
+int launch_max(const void* d_tiles, int64_t tiles_per_group, int n_groups, int64_t tile_elems, double dark,
                const void* d_dark, int dark_dt, double flat, const void* d_flat, int flat_dt, double* d_max2,
                hipStream_t s) {
-  if (n_per_group == 0 || n_groups == 0) return MG_OK;
-  const int64_t nvec = n_per_group / VecOf<T>::N + 1;
-  const int per_group = std::max(1, 2048 / n_groups);
+  if (tiles_per_group == 0 || n_groups == 0 || tile_elems == 0) return MG_OK;
+  const int64_t nvec = tile_elems / VecOf<T>::N + 1;
+  const int per_group = std::max(1, 4096 / n_groups);
   int blocks = (int)std::min<int64_t>((nvec + 255) / 256, per_group);
-  hipLaunchKernelGGL((k_flatfield_max<T>), dim3(blocks, n_groups), dim3(256), 0, s, (const T*)d_tiles, n_per_group,
+  hipLaunchKernelGGL((k_flatfield_max<T>), dim3(blocks, n_groups), dim3(256), 0, s, (const T*)d_tiles, tiles_per_group,
                      tile_elems, dark, d_dark, dark_dt, flat, d_flat, flat_dt, d_max2);
   MG_CHECK_LAUNCH();
   return MG_OK;
@@ -364,16 +424,18 @@ int launch_apply(const void* d_tiles, int64_t n_planes, int n_tr, int n_tc, int 
   const int h_out = n_tr * hy, w_out = n_tc * hx;
   if (n_planes == 0 || h_out == 0 || w_out == 0) return MG_OK;
   constexpr int N = VecOf<T>::N;
-  dim3 grid((w_out + 256 * N - 1) / (256 * N), (h_out + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, (unsigned)n_planes);
+  if (n_planes > 0x7FFFFFF0) return MG_EINVAL;
+  dim3 grid((w_out + 256 * N - 1) / (256 * N), (h_out + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK,
+            (unsigned)((n_planes + PLANES_PER_BLOCK - 1) / PLANES_PER_BLOCK));
   if (grid.y > 65535 || grid.z > 65535) return MG_EINVAL;
   if (apply)
-    hipLaunchKernelGGL((k_apply_stitch<T, true>), grid, dim3(256), 0, s, (const T*)d_tiles, n_tr, n_tc, ty, tx, clip,
-                       hy, hx, planes_per_group, dark, d_dark, dark_dt, flat, d_flat, flat_dt, d_max2, (T*)d_image,
-                       d_minmax);
+    hipLaunchKernelGGL((k_apply_stitch<T, true>), grid, dim3(256), 0, s, (const T*)d_tiles, (int)n_planes, n_tr, n_tc,
+                       ty, tx, clip, hy, hx, planes_per_group, dark, d_dark, dark_dt, flat, d_flat, flat_dt, d_max2,
+                       (T*)d_image, d_minmax);
   else
-    hipLaunchKernelGGL((k_apply_stitch<T, false>), grid, dim3(256), 0, s, (const T*)d_tiles, n_tr, n_tc, ty, tx, clip,
-                       hy, hx, planes_per_group, dark, d_dark, dark_dt, flat, d_flat, flat_dt, d_max2, (T*)d_image,
-                       d_minmax);
+    hipLaunchKernelGGL((k_apply_stitch<T, false>), grid, dim3(256), 0, s, (const T*)d_tiles, (int)n_planes, n_tr, n_tc,
+                       ty, tx, clip, hy, hx, planes_per_group, dark, d_dark, dark_dt, flat, d_flat, flat_dt, d_max2,
+                       (T*)d_image, d_minmax);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -402,10 +464,10 @@ extern "C" int mg_flatfield_max(const void* d_tiles, int dtype, int64_t n_tiles,
   if (!d_tiles || !d_max2 || n_tiles < 0 || ty <= 0 || tx <= 0 || n_groups <= 0 || n_groups > 65535) return MG_EINVAL;
   if (n_tiles % n_groups) return MG_EINVAL;
   if (!df_dtype_ok(d_dark, dark_dtype) || !df_dtype_ok(d_flat, flat_dtype)) return MG_EINVAL;
-  const int64_t tile_elems = (int64_t)ty * tx, n = (n_tiles / n_groups) * tile_elems;
+  const int64_t tile_elems = (int64_t)ty * tx, tpg = n_tiles / n_groups;
   hipStream_t s = mg_stream(stream);
 #define MG_MAX(T) \
-  return launch_max<T>(d_tiles, n, n_groups, tile_elems, dark, d_dark, dark_dtype, flat, d_flat, flat_dtype, d_max2, s)
+  return launch_max<T>(d_tiles, tpg, n_groups, tile_elems, dark, d_dark, dark_dtype, flat, d_flat, flat_dtype, d_max2, s)
   switch (dtype) {
     case MG_U8: MG_MAX(uint8_t);
     case MG_U16: MG_MAX(uint16_t);

@@ -131,6 +131,100 @@ __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64
   }
 }
 
+// ---- fast path: uint16 image, even window length <= 126, even image width -------------------------
+// One wave per window row, one dword (2 pixels) per lane: aligned 4-byte loads (odd source offsets
+// are funnel-shifted from two neighbouring dwords), 4-byte roi stores, 2-byte mask stores.
+__global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict__ d_image, int64_t assay_stride,
+                                                     int n_c, int n_t, int h, int w,
+                                                     const int32_t* __restrict__ d_beads,
+                                                     const int32_t* __restrict__ d_marker_assay,
+                                                     const int32_t* __restrict__ d_marker_local, int len,
+                                                     const int32_t* __restrict__ d_labels,
+                                                     uint16_t* __restrict__ d_roi, uint8_t* __restrict__ d_fg,
+                                                     uint8_t* __restrict__ d_bg, double* __restrict__ d_sums,
+                                                     int32_t* __restrict__ d_counts) {
+  extern __shared__ uint8_t flags[];  // [len][len]: bit 0 fg, bit 1 bg
+  __shared__ long long s_red[2][NT / 64];
+  __shared__ int s_cnt[2][NT / 64];
+  const int g = blockIdx.x;
+  const int assay = d_marker_assay ? d_marker_assay[g] : 0;
+  const int local = d_marker_local ? d_marker_local[g] : g;
+  int top, left;
+  window(d_beads[3 * (int64_t)g], len, h, top);
+  window(d_beads[3 * (int64_t)g + 1], len, w, left);
+  const int n = len * len, half = len >> 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = 2 * lane;
+  const bool act = lane < half;
+  const int32_t* lab = d_labels ? d_labels + (int64_t)assay * h * w : nullptr;
+  int cf = 0, cb = 0;
+  for (int ry = wave; ry < len; ry += NT / 64) {
+    if (!act) continue;
+    uint32_t f0 = 0, f1 = 0, b0 = 0, b1 = 0;
+    if (lab) {
+      const int32_t* lp = lab + (int64_t)(top + ry) * w + left + x;
+      const int v0 = lp[0], v1 = lp[1];
+      f0 = v0 == local, f1 = v1 == local, b0 = v0 == -1, b1 = v1 == -1;
+    }
+    *reinterpret_cast<uint16_t*>(&flags[ry * len + x]) = (uint16_t)((f0 | (b0 << 1)) | ((f1 | (b1 << 1)) << 8));
+    if (d_fg) *reinterpret_cast<uint16_t*>(&d_fg[(int64_t)g * n + ry * len + x]) = (uint16_t)(f0 | (f1 << 8));
+    if (d_bg) *reinterpret_cast<uint16_t*>(&d_bg[(int64_t)g * n + ry * len + x]) = (uint16_t)(b0 | (b1 << 8));
+    cf += f0 + f1;
+    cb += b0 + b1;
+  }
+  cf = mg_wave_sum_i32(cf);
+  cb = mg_wave_sum_i32(cb);
+  if (lane == 0) {
+    s_cnt[0][wave] = cf;
+    s_cnt[1][wave] = cb;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && d_counts) {
+    d_counts[2 * (int64_t)g] = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+    d_counts[2 * (int64_t)g + 1] = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+  }
+  const uint16_t* img = d_image + (int64_t)assay * assay_stride;
+  for (int ct = 0; ct < n_c * n_t; ++ct) {
+    const uint16_t* plane = img + (int64_t)ct * h * w;
+    uint16_t* out = d_roi ? d_roi + ((int64_t)g * n_c * n_t + ct) * n : nullptr;
+    long long sf = 0, sb = 0;
+    for (int ry = wave; ry < len; ry += NT / 64) {
+      const int64_t e0 = (int64_t)(top + ry) * w + left;  // element offset of the row start in the plane
+      const int odd = (int)(e0 & 1);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(plane + (e0 - odd));
+      uint32_t d = 0;
+      if (lane < half) d = src[lane];
+      else if (lane == half && odd) d = plane[e0 + len - 1];  // last pixel of the row, no over-read
+      const uint32_t nx = (uint32_t)__shfl_down((int)d, 1);
+      const uint32_t v = odd ? ((d >> 16) | (nx << 16)) : d;
+      if (act) {
+        if (out) *reinterpret_cast<uint32_t*>(&out[ry * len + x]) = v;
+        const uint32_t fl = *reinterpret_cast<const uint16_t*>(&flags[ry * len + x]);
+        const long long p0 = v & 0xFFFFu, p1 = v >> 16;
+        if (fl & 0x0001u) sf += p0;
+        if (fl & 0x0100u) sf += p1;
+        if (fl & 0x0002u) sb += p0;
+        if (fl & 0x0200u) sb += p1;
+      }
+    }
+    if (d_sums) {
+      sf = mg_wave_sum_i64(sf);
+      sb = mg_wave_sum_i64(sb);
+      __syncthreads();
+      if (lane == 0) {
+        s_red[0][wave] = sf;
+        s_red[1][wave] = sb;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double* o = d_sums + ((int64_t)g * n_c * n_t + ct) * 2;
+        o[0] = (double)(s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3]);
+        o[1] = (double)(s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]);
+      }
+    }
+  }
+}
+
 // ---- masked median (u16): two-level radix select in LDS --------------------------------------------
 __device__ int select_kth_u16(const uint16_t* __restrict__ v, const uint8_t* __restrict__ mask, int n, int k,
                               uint32_t* hist) {
@@ -230,6 +324,15 @@ extern "C" int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int6
   if (roi_len > h || roi_len > w || (int64_t)roi_len * roi_len > 60000) return MG_EINVAL;
   if (m == 0) return MG_OK;
   hipStream_t s = mg_stream(stream);
+  if (dtype == MG_U16 && (roi_len & 1) == 0 && roi_len <= 126 && (w & 1) == 0 && (assay_stride & 1) == 0 &&
+      (reinterpret_cast<uintptr_t>(d_image) & 3) == 0 && (!d_roi || (reinterpret_cast<uintptr_t>(d_roi) & 3) == 0) &&
+      (!d_fg || (reinterpret_cast<uintptr_t>(d_fg) & 1) == 0) && (!d_bg || (reinterpret_cast<uintptr_t>(d_bg) & 1) == 0)) {
+    hipLaunchKernelGGL(k_roi_u16_even, dim3(m), dim3(NT), (size_t)roi_len * roi_len, s, (const uint16_t*)d_image,
+                       assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, roi_len, d_labels,
+                       (uint16_t*)d_roi, d_fg, d_bg, d_sums, d_counts);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+  }
   switch (dtype) {
     case MG_U8:
       return launch_roi<uint8_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,

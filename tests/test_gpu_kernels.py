@@ -351,7 +351,8 @@ def test_roi_gather_reduce(hp, dtype):
     rng = np.random.default_rng(21)
     c, t, h, w, L = 3, 2, 160, 200, 40
     image = rng.integers(0, 4000, size=(c, t, h, w)).astype(dtype)
-    beads = np.array([[20, 20, 8], [5, 190, 6], [150, 100, 10], [80, 80, 9], [84, 92, 9], [159, 0, 5]])
+    beads = np.array([[20, 20, 8], [5, 190, 6], [150, 100, 10], [80, 80, 9], [84, 92, 9], [159, 0, 5], [33, 57, 6],
+                      [121, 143, 7]])  # odd and even window offsets
     labels = hp.circle_labels([beads], h, w)
     res = hp.roi_gather_reduce(dev(image)[None], [beads], L, labels)
     lab = rn.circle_labels(beads, h, w)
