@@ -187,7 +187,8 @@ def main():
                                "achieved_GBs": stream_bytes / (stream_ms / 1e3) / 1e9 if stream_ms else None,
                                "frac_of_peak": stream_bytes / (stream_ms / 1e3) / 1e9 / HBM_PEAK_GBS if stream_ms else None},
             "stages": breakdown,
-            "stats": {"unique_circles": unique, "alive_circles": alive, "edges": p["edges"],
+            "stats": {"unique_circles": unique, "scored_exactly": int(f.num_scored.sum().item()),
+                      "alive_circles": alive, "edges": p["edges"],
                       "hysteresis_sweeps": f.stats.get("hysteresis_sweeps"), "nms_rounds": f.stats.get("nms_rounds"),
                       "kernel_ms_per_step": total_ms / args.steps},
         }

@@ -168,8 +168,10 @@ int mg_dedup_layout(int h, int w, int min_r, int max_r, int* n_tile_rows, int* n
 
 /* candidate_circles (utils.py:295-344) with the build's counter-based RNG (the reference
  * is unseeded): iteration i of plane p draws three 32-bit uniforms from
- * splitmix64(seed[p] + (3 i + k + 1) * golden) >> 32, p0 = coords[u0 * E >> 32],
- * p1, p2 = p0's cell list[u * count >> 32].  Then steps 4 of filter_circles
+ * splitmix64(seed[p] + (3 i + k + 1) * golden) >> 32.  p0 is a jittered stratified draw: iteration i
+ * owns the slice [a, b) = [floor(i E / K), floor((i + 1) E / K)) of the cell-major edge list and
+ * takes p0 = coords[a + (u0 * max(b - a, 1) >> 32)] (every edge equally likely, consecutive
+ * iterations spatially coherent); p1, p2 = p0's cell list[u * count >> 32].  Then steps 4 of filter_circles
  * (utils.py:157-166): radius window, round-half-even, off-image rejection.  Survivors set
  * their bit in d_bitmap[n_planes][bitmap_words] (mg_dedup_layout), which de-duplicates them:
  * a circle's score depends only on (row, col, r).
@@ -199,12 +201,13 @@ int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, int n_planes,
  * Circles with score >= min_roundness (float32 compare, utils.py:191) are appended (unordered) to
  * d_alive[n_planes][circle_cap] (indices into d_circles), d_num_alive[n_planes] pre-zeroed;
  * d_max_rc[n_planes][2] (pre-set to INT32_MIN) receives max row / max col of the alive circles
- * (the claim-grid extent of utils.py:268-270). */
+ * (the claim-grid extent of utils.py:268-270).  d_num_scored (optional, [n_planes], pre-zeroed)
+ * counts the circles that reached pass B. */
 int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, int64_t words_per_plane, int n_planes, int h,
                      int w, const int32_t* d_circles, int64_t circle_cap, const int32_t* d_layer_offsets, int min_r,
                      int max_r, const int32_t* d_per_rc, const double* d_per_expected, const int32_t* d_per_starts,
                      int per_total, float min_roundness, int write_skipped, float* d_scores, int32_t* d_alive,
-                     int32_t* d_num_alive, int32_t* d_max_rc, void* stream);
+                     int32_t* d_num_alive, int32_t* d_max_rc, int32_t* d_num_scored, void* stream);
 
 /* One round of the parallel-but-equivalent greedy suppression of filter_neighbors
  * (utils.py:254-292).  Priority = (score desc, index in d_circles asc) -- the build's

@@ -28,6 +28,18 @@ __device__ __forceinline__ uint32_t draw32(uint64_t seed, uint64_t it, uint32_t 
   return (uint32_t)(z >> 32);
 }
 
+// floor(n / d) for n < 2^52 via a float64 reciprocal and one correction step (exact).
+__device__ __forceinline__ uint64_t div_u64(uint64_t n, uint64_t d, double inv_d) {
+  uint64_t q = (uint64_t)((double)n * inv_d);
+  int64_t r = (int64_t)(n - q * d);
+  if (r < 0) {
+    --q;
+    r += (int64_t)d;
+  }
+  if (r >= (int64_t)d) ++q;
+  return q;
+}
+
 // ---- K7: candidate circles --------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_candidates(const int32_t* __restrict__ d_coords, int64_t coord_cap,
                                                    const int32_t* __restrict__ d_starts,
@@ -47,8 +59,13 @@ __global__ __launch_bounds__(NT) void k_candidates(const int32_t* __restrict__ d
   const int ntc = (w + 2 * max_r + 63) >> 6, nr = max_r - min_r + 1;
   uint32_t* bitmap = d_bitmap + (int64_t)plane * bitmap_words;
   const double eps = (double)1e-20f;
+  const double inv_iter = 1.0 / (double)num_iter;
   for (int64_t it = (int64_t)blockIdx.x * NT + threadIdx.x; it < num_iter; it += (int64_t)gridDim.x * NT) {
-    const uint32_t u0 = (uint32_t)(((uint64_t)draw32(seed, (uint64_t)it, 0) * n_edges) >> 32);
+    // jittered stratified p0: iteration it owns the slice [a, b) of the cell-major edge list
+    const uint64_t sa = div_u64((uint64_t)it * n_edges, (uint64_t)num_iter, inv_iter);
+    const uint64_t sb = div_u64(((uint64_t)it + 1) * n_edges, (uint64_t)num_iter, inv_iter);
+    const uint64_t width = sb > sa ? sb - sa : 1;
+    const uint32_t u0 = (uint32_t)(sa + (((uint64_t)draw32(seed, (uint64_t)it, 0) * width) >> 32));
     const int p0r = coords[2 * (int64_t)u0], p0c = coords[2 * (int64_t)u0 + 1];
     const int cell = (p0r / grid) * gc + (p0c / grid);
     const uint32_t cnt = (uint32_t)counts[cell];
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
                                                     const int32_t* __restrict__ d_per_starts, float min_roundness,
                                                     int write_skipped, float* __restrict__ d_scores,
                                                     int32_t* __restrict__ d_alive, int32_t* __restrict__ d_num_alive,
-                                                    int32_t* __restrict__ d_max_rc) {
+                                                    int32_t* __restrict__ d_max_rc, int32_t* __restrict__ d_num_scored) {
   extern __shared__ uint32_t lds[];
   __shared__ int n_surv;
   const int plane = blockIdx.y, tile = blockIdx.x;
@@ -236,12 +253,24 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
       // need: hits >= min_roundness * len - 1e-3 (margin far above any rounding of the real sum)
       const int need = (int)ceil((double)min_roundness * len - 1e-3);
       const int by = row - wy0, bx = col - wx0;
-      int hits = 0;
-      for (int p = p0; p < p1; ++p) {
+#define MG_BIT(yy, xx) ((win[(by + (yy)) * wpr + ((bx + (xx)) >> 5)] >> ((bx + (xx)) & 31)) & 1u)
+      // The midpoint circle is emitted as 4 axis points, groups of 8 symmetric points sharing one
+      // (x, y), and possibly 4 diagonal points (utils.py:441-464): one table read per group.
+      int hits = MG_BIT(0, -rad) + MG_BIT(-rad, 0) + MG_BIT(0, rad) + MG_BIT(rad, 0);
+      int p = p0 + 4;
+      for (; p + 8 <= p1; p += 8) {
         const int v = tab[p];
-        const int y = by + (v >> 16), x = bx + (int)(int16_t)(v & 0xFFFF);
-        hits += (win[y * wpr + (x >> 5)] >> (x & 31)) & 1u;
+        const int x = v >> 16, y = (int)(int16_t)(v & 0xFFFF);  // entry (dr, dc) = (x, y)
+        hits += MG_BIT(x, y) + MG_BIT(y, x) + MG_BIT(-x, y) + MG_BIT(-y, x) + MG_BIT(x, -y) + MG_BIT(y, -x) +
+                MG_BIT(-x, -y) + MG_BIT(-y, -x);
+        if (hits + (p1 - p - 8) < need) break;  // cannot get there any more
       }
+      if (p + 4 == p1) {
+        const int v = tab[p];
+        const int x = v >> 16, y = (int)(int16_t)(v & 0xFFFF);
+        hits += MG_BIT(x, y) + MG_BIT(-x, -y) + MG_BIT(-x, y) + MG_BIT(x, -y);
+      }
+#undef MG_BIT
       if (hits >= need) {
         list[atomicAdd(&n_surv, 1)] = (int32_t)(i - chunk);
       } else if (write_skipped) {
@@ -250,6 +279,7 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
     }
     __syncthreads();
     const int ns = n_surv;
+    if (threadIdx.x == 0 && d_num_scored) atomicAdd(&d_num_scored[plane], ns);
     for (int a = threadIdx.x; a < ns; a += NT) {
       const int64_t i = chunk + list[a];
       const int row = circles[3 * i], col = circles[3 * i + 1], rad = circles[3 * i + 2];
@@ -409,6 +439,7 @@ extern "C" int mg_candidate_circles(const int32_t* d_coords, int64_t coord_cap, 
   if (!d_coords || !d_cell_starts || !d_cell_counts || !d_num_edges || !d_seeds || !d_bitmap) return MG_EINVAL;
   if (n_planes < 0 || n_planes > 65535 || h <= 0 || w <= 0 || grid <= 0 || num_iter < 0 || min_r < 0 || max_r < min_r)
     return MG_EINVAL;
+  if ((double)num_iter * (double)h * (double)w >= 4.0e15) return MG_EINVAL;  // exact-division range of the strata
   int ntr_, ntc_;
   int64_t n_layers_, need_words_;
   if (mg_dedup_layout(h, w, min_r, max_r, &ntr_, &ntc_, &n_layers_, &need_words_) != MG_OK) return MG_EINVAL;
@@ -463,7 +494,7 @@ extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bit
                                 const int32_t* d_layer_offsets, int min_r, int max_r, const int32_t* d_per_rc,
                                 const double* d_per_expected, const int32_t* d_per_starts, int per_total,
                                 float min_roundness, int write_skipped, float* d_scores, int32_t* d_alive,
-                                int32_t* d_num_alive, int32_t* d_max_rc, void* stream) {
+                                int32_t* d_num_alive, int32_t* d_max_rc, int32_t* d_num_scored, void* stream) {
   if (!d_angle || !d_edge_bits || !d_circles || !d_layer_offsets || !d_per_rc || !d_per_expected || !d_per_starts ||
       !d_scores || !d_alive || !d_num_alive || !d_max_rc)
     return MG_EINVAL;
@@ -485,7 +516,7 @@ extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bit
   hipLaunchKernelGGL(k_score_tiles, dim3(ntr * ntc, n_planes), dim3(NT), lds_bytes, mg_stream(stream), d_angle,
                      d_edge_bits, words_per_plane, h, w, d_circles, circle_cap, d_layer_offsets, (int)n_layers,
                      max_r - min_r + 1, ntc, min_r, max_r, d_per_rc, per_total, d_per_expected, d_per_starts,
-                     min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc);
+                     min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc, d_num_scored);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

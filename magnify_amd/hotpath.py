@@ -294,6 +294,7 @@ class CircleFinder:
         self.scores = torch.empty((P, self.cap), dtype=torch.float32, device=dev)
         self.alive = torch.empty((P, self.cap), dtype=i32, device=dev)
         self.num_alive = torch.zeros((P,), dtype=i32, device=dev)
+        self.num_scored = torch.zeros((P,), dtype=i32, device=dev)
         self.max_rc = torch.zeros((P, 2), dtype=i32, device=dev)
         self.state = torch.zeros((P, self.cap), dtype=u8, device=dev)
         self.undecided = torch.zeros((P,), dtype=i32, device=dev)
@@ -412,12 +413,13 @@ class CircleFinder:
                                          self.layer_offsets.data_ptr(), self.circles.data_ptr(), self.cap,
                                          self.num_circles.data_ptr(), s)
         self.num_alive.zero_()
+        self.num_scored.zero_()
         self.max_rc.fill_(-(2**31))
         _call("mg_score_circles", self.angle.data_ptr(), self.edge_bits.data_ptr(), self.words, P, h, w,
               self.circles.data_ptr(), self.cap, self.layer_offsets.data_ptr(), self.min_r, self.max_r,
               self.per_rc.data_ptr(), self.per_exp.data_ptr(), self.per_starts.data_ptr(), int(self.per_rc.shape[0]),
               float(min_roundness), int(self.keep_debug_maps), self.scores.data_ptr(), self.alive.data_ptr(),
-              self.num_alive.data_ptr(), self.max_rc.data_ptr(), s)
+              self.num_alive.data_ptr(), self.max_rc.data_ptr(), self.num_scored.data_ptr(), s)
 
     # -- stage 3: greedy suppression + ordered output -------------------------------------------
     def nms_stage(self, min_dist: int):

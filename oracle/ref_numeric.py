@@ -338,20 +338,34 @@ def draw_uniform32(seed: int, it: np.ndarray, k: int) -> np.ndarray:
         return _mix64(z) >> np.uint64(32)
 
 
+def stratum(it: np.ndarray, n_edges: int, num_iter: int):
+    """Iteration ``it`` owns the slice [a, b) of the cell-major edge list, a = floor(it * E / K),
+    b = floor((it + 1) * E / K) (width at least 1)."""
+    it = np.asarray(it, dtype=np.uint64)
+    a = (it * np.uint64(n_edges)) // np.uint64(num_iter)
+    b = ((it + np.uint64(1)) * np.uint64(n_edges)) // np.uint64(num_iter)
+    return a, np.maximum(b - a, np.uint64(1))
+
+
 def draw_picks(seed: int, num_iter: int, edges: np.ndarray, grid_length: int):
     """Map the RNG stream to the three picks of every iteration.
 
-    Definition shared with the HIP kernel: p0 = cell-major edge list[u0 * E >> 32];
-    p1, p2 = that cell's list[u * count >> 32].  Returns picks in the *reference's*
-    indexing (i0 into the row-major list, j1/j2 into the cell list) so that they
-    can be replayed through ``candidate_circles_from_picks``."""
+    Definition shared with the HIP kernel.  p0 is a jittered stratified draw over the cell-major
+    edge list: iteration i picks p0 = list[a + (u0 * width >> 32)] inside its own slice
+    ``stratum(i)`` -- every edge pixel is equally likely, as with the reference's iid
+    ``np.random.choice`` (utils.py:311), and any such set of draws is a possible outcome of the
+    unseeded reference, but consecutive iterations are spatially coherent.  p1, p2 = that cell's
+    list[u * count >> 32] (utils.py:318-321).  Returns picks in the *reference's* indexing (i0 into
+    the row-major list, j1/j2 into the cell list) so that they can be replayed through
+    ``candidate_circles_from_picks``."""
     gcoords, starts, counts = grid_array(edges, grid_length)
     n_edges = len(gcoords)
     it = np.arange(num_iter, dtype=np.uint64)
     if n_edges == 0:
         z = np.zeros(0, dtype=np.int64)
         return z, z, z
-    u0 = (draw_uniform32(seed, it, 0) * np.uint64(n_edges)) >> np.uint64(32)
+    a, width = stratum(it, n_edges, num_iter)
+    u0 = a + ((draw_uniform32(seed, it, 0) * width) >> np.uint64(32))
     p0 = gcoords[u0.astype(np.int64)].astype(np.int64)
     cnt = counts[p0[:, 0] // grid_length, p0[:, 1] // grid_length].astype(np.uint64)
     j1 = ((draw_uniform32(seed, it, 1) * cnt) >> np.uint64(32)).astype(np.int64)
