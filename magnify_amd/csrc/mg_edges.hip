@@ -84,10 +84,51 @@ __device__ __forceinline__ void fetch16(const T* __restrict__ rowp, int gx0, int
 }
 
 // Stage tile rows [ty0 - HALO, ty0 + TH + HALO) x cols [tx0 - 16, tx0 + TW + 16) into LDS.
+// Interior tiles (the block-uniform common case) take a branch-free path whose loads are all
+// issued before the first conversion; border tiles go through the reflecting per-chunk path.
 template <typename T, int HALO>
 __device__ __forceinline__ void load_tile(const T* __restrict__ base, int64_t row_stride, int h, int w, int tx0, int ty0,
                                           const U8Scale& sc, uint8_t (*tile)[LS]) {
-  for (int i = threadIdx.x; i < (TH + 2 * HALO) * CHUNKS; i += NT) {
+  constexpr int TOTAL = (TH + 2 * HALO) * CHUNKS;
+  constexpr int ITER = (TOTAL + NT - 1) / NT;
+  constexpr int PER = 16 / sizeof(T);   // elements per 16-byte load
+  constexpr int NLD = 16 / PER;         // 16-byte loads per 16-element chunk
+  const bool interior = tx0 >= LPAD && tx0 + TW + LPAD <= w && ty0 >= HALO && ty0 + TH + HALO <= h &&
+                        ((row_stride * sizeof(T)) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(base + (int64_t)(ty0 - HALO) * row_stride + tx0 - LPAD) & 15) == 0;
+  if (interior) {
+    uint4 raw[ITER][NLD];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int i = threadIdx.x + it * NT;
+      if (i < TOTAL) {
+        const int j = i / CHUNKS, k = i - j * CHUNKS;
+        const uint4* p = reinterpret_cast<const uint4*>(base + (int64_t)(ty0 - HALO + j) * row_stride + tx0 - LPAD + 16 * k);
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) raw[it][q] = p[q];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int i = threadIdx.x + it * NT;
+      if (i < TOTAL) {
+        const int j = i / CHUNKS, k = i - j * CHUNKS;
+        uint8_t v[16];
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+          T e[PER];
+          __builtin_memcpy(e, &raw[it][q], 16);
+#pragma unroll
+          for (int m = 0; m < PER; ++m) v[q * PER + m] = to_u8<T>(e[m], sc);
+        }
+        uint4 out;
+        __builtin_memcpy(&out, v, 16);
+        *reinterpret_cast<uint4*>(&tile[j][16 * k]) = out;
+      }
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < TOTAL; i += NT) {
     const int j = i / CHUNKS, k = i - j * CHUNKS;
     const int gy = mg_reflect101(ty0 - HALO + j, h);
     uint8_t v[16];
@@ -185,10 +226,11 @@ __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ 
                                                     uint32_t* __restrict__ d_hist) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t (*tile)[LS] = reinterpret_cast<uint8_t (*)[LS]>(smem);
+  // 16-bit counters, two per word (a tile holds 16384 pixels, so a bin cannot overflow its half)
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (TH + 2) * LS);
   const int plane = blockIdx.z;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-  for (int i = threadIdx.x; i < n_bins; i += NT) hist[i] = 0;
+  for (int i = threadIdx.x; i < n_bins / 2; i += NT) hist[i] = 0;
   U8Scale sc;
   sc.passthrough = 1;
   load_tile<uint8_t, 1>(d_blur + (int64_t)plane * h * w, w, h, w, tx0, ty0, sc, tile);
@@ -211,10 +253,16 @@ __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ 
         const uint32_t m = (uint32_t)(dx[q] * dx[q] + dy[q] * dy[q]);
         if (mode == 0) {
           if (m == 0) ++zeros;
-          else atomicAdd(&hist[m < FINE ? m : FINE + (m >> 13)], 1u);
+          else {
+            const uint32_t b = m < FINE ? m : FINE + (m >> 13);
+            atomicAdd(&hist[b >> 1], 1u << (16 * (b & 1)));
+          }
         } else if (m >= base && m - base < (uint32_t)n_bins) {
           if (m == base) ++zeros;
-          else atomicAdd(&hist[m - base], 1u);
+          else {
+            const uint32_t b = m - base;
+            atomicAdd(&hist[b >> 1], 1u << (16 * (b & 1)));
+          }
         }
       }
     }
@@ -222,12 +270,13 @@ __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ 
     rb = rc;
   }
   zeros = (uint32_t)mg_wave_sum_i32((int)zeros);
-  if (lane == 0 && zeros) atomicAdd(&hist[0], zeros);
-  __syncthreads();
   uint32_t* out = d_hist + (int64_t)plane * n_bins;
-  for (int i = threadIdx.x; i < n_bins; i += NT) {
+  if (lane == 0 && zeros) atomicAdd(&out[0], zeros);  // bin 0 goes straight to global memory
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_bins / 2; i += NT) {
     const uint32_t v = hist[i];
-    if (v) atomicAdd(&out[i], v);
+    if (v & 0xFFFFu) atomicAdd(&out[2 * i], v & 0xFFFFu);
+    if (v >> 16) atomicAdd(&out[2 * i + 1], v >> 16);
   }
 }
 
@@ -573,7 +622,7 @@ extern "C" int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w,
   const dim3 g = tile_grid(h, w, n_planes);
   if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
   const int n_bins = mode == 0 ? FINE + COARSE : FINE;
-  const size_t lds = (size_t)(TH + 2) * LS + (size_t)n_bins * 4;
+  const size_t lds = (size_t)(TH + 2) * LS + (size_t)n_bins * 2;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_scharr_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
