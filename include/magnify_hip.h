@@ -264,6 +264,30 @@ int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int64_t assay_s
 int mg_roi_masked_median_u16(const uint16_t* d_roi, const uint8_t* d_mask, int m, int n_c, int n_t, int roi_len,
                              double* d_median, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * A16 / A17 ButtonFinder helpers (find.py:205-402, 632-677)
+ * ---------------------------------------------------------------------------------- */
+
+/* cluster_1d (find.py:632-677): the cost of every integer offset in [0, n_offsets) for
+ * n_clusters equal-width clusters over the ascending d_sorted_points (float64):
+ * sum_k var_k * sqrt(ideal_k) + penalty * (ideal_k - n_k)^2, empty clusters take the largest
+ * var.  The caller takes the first minimum (strict <, find.py:666).  d_costs double[n_offsets]. */
+int mg_cluster1d_costs(const double* d_sorted_points, int n_points, int n_offsets, int n_clusters,
+                       double cluster_length, const double* d_ideal, double penalty, double* d_costs, void* stream);
+
+/* fg / bg masks of find_rois (find.py:383-400): fg[g] = cv.circle(filled, radius d_radii[g]),
+ * bg[g] = annulus(outer_r, inner_r), centred at d_centers[g] = (row, col) inside the
+ * roi_len x roi_len window.  d_cv_halfwidths[(max_table_r + 1)][hw_stride]: row r holds
+ * mg_cv_disk_halfwidths(r).  Outputs uint8 [m][roi_len][roi_len]. */
+int mg_button_masks(const int32_t* d_centers, const int32_t* d_radii, int m, int roi_len, int outer_r, int inner_r,
+                    const int32_t* d_cv_halfwidths, int hw_stride, int max_table_r, uint8_t* d_fg, uint8_t* d_bg,
+                    void* stream);
+
+/* Masked sums with explicit masks: roi (m, n_ct, L, L), fg / bg (m, L, L) uint8 ->
+ * d_sums double[m][n_ct][2] = {fg sum, bg sum}, d_counts int32[m][2] (optional). */
+int mg_masked_sums(const void* d_roi, int dtype, const uint8_t* d_fg, const uint8_t* d_bg, int m, int n_ct,
+                   int roi_len, double* d_sums, int32_t* d_counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,9 @@ PROTOTYPES = {
     "mg_roi_gather_reduce": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mg_roi_gather_reduce_batched": [_p, _i, _l, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mg_roi_masked_median_u16": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "mg_cluster1d_costs": [_p, _i, _i, _i, _d, _p, _d, _p, _p],
+    "mg_button_masks": [_p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p],
+    "mg_masked_sums": [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p],
 }
 
 _lib = None

@@ -112,3 +112,220 @@ class BeadFinder:
                           low_edge_quantile=low_edge_quantile, high_edge_quantile=high_edge_quantile,
                           num_iter=num_iter, min_roundness=min_roundness, roi_length=roi_length,
                           search_channel=search_channel, interactive=interactive)
+
+
+# --------------------------------------------------------------------------------------
+# ButtonFinder (find.py:13-442)
+# --------------------------------------------------------------------------------------
+
+
+def _linregress(x, y):
+    """slope, intercept as scipy.stats.linregress (find.py:710,719,735): ssxym / ssxm, ymean - slope * xmean."""
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    ssxm, ssxym, _, _ = np.cov(x, y, bias=1).flat
+    slope = ssxym / ssxm
+    return slope, np.mean(y) - slope * np.mean(x)
+
+
+def label_clusters(points, offset, num_clusters, cluster_length, cluster_gap):
+    """find.py:680-695."""
+    points = np.asarray(points, dtype=np.float64)
+    perm = np.argsort(points)
+    pts = points[perm]
+    labels = -np.ones(len(pts), dtype=int)
+    steps = [offset] + ([cluster_length, cluster_gap] * num_clusters)[:-1]
+    spans = np.searchsorted(pts, np.cumsum(steps))
+    for i in range(num_clusters):
+        labels[spans[2 * i] : spans[2 * i + 1]] = i
+    return labels[np.argsort(perm)]
+
+
+def regress_clusters(x, y, labels, num_clusters, ideal_num_points):
+    """find.py:698-748: per-cluster lines, shared median slope, intercepts blended with an evenly
+    spaced global estimate."""
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    if num_clusters == 1:
+        if len(x) == 1:
+            return 0, y
+        return _linregress(x, y)
+    slopes = np.full(num_clusters, np.nan)
+    intercepts = np.full(num_clusters, np.nan)
+    groups = [(x[labels == i], y[labels == i]) for i in range(num_clusters)]
+    for i, (gx, gy) in enumerate(groups):
+        if len(gx) > 1:
+            slopes[i], intercepts[i] = _linregress(gx, gy)
+        elif (i == 0 or i == num_clusters - 1) and ideal_num_points[i] >= 2:
+            print("Boundary cluster has fewer than 2 points.The chip is unlikely to be segmented correctly.")
+    slope = np.nanmedian(slopes)
+    for i, (gx, gy) in enumerate(groups):
+        if len(gx) > 0:
+            intercepts[i] = np.median(gy - slope * gx)
+    ok = ~np.isnan(intercepts)
+    idx = np.arange(num_clusters)
+    g_m, g_b = _linregress(idx[ok], intercepts[ok])
+    for i, (gx, _) in enumerate(groups):
+        if ideal_num_points[i] != 0 and ok[i]:
+            wgt = min(len(gx), ideal_num_points[i]) / ideal_num_points[i]
+            intercepts[i] = wgt * intercepts[i] + (1 - wgt) * (g_m * i + g_b)
+        else:
+            intercepts[i] = g_m * i + g_b
+    return slope, intercepts
+
+
+def chamber_seed(seed: int, chamber: int, k: int) -> int:
+    """RNG stream id of the per-chamber refinement (chamber = i * n_cols + j, k = search channel)."""
+    return (seed + 0x51ED270B * (chamber + 1) + 0x2545F491 * (k + 1)) & 0xFFFFFFFFFFFFFFFF
+
+
+class ButtonFinder:
+    def __init__(self, row_dist, col_dist, min_button_diameter, max_button_diameter, chamber_diameter, top_chamber,
+                 left_chamber, low_edge_quantile, high_edge_quantile, num_iter, min_roundness, cluster_penalty,
+                 roi_length, progress_bar, search_timestep, search_channel, interactive):
+        if min_button_diameter > max_button_diameter:
+            raise ValueError("min_button_diameter must be <= max_button_diameter.")
+        if interactive:
+            raise NotImplementedError("the napari tuning GUI is outside the MI355X hot path")
+        self.row_dist, self.col_dist = row_dist, col_dist
+        self.min_button_radius = math.floor(min_button_diameter / 2)
+        self.max_button_radius = math.ceil(max_button_diameter / 2)
+        self.chamber_radius = round(chamber_diameter / 2)
+        self.top_chamber, self.left_chamber = top_chamber, left_chamber
+        self.low_edge_quantile, self.high_edge_quantile = low_edge_quantile, high_edge_quantile
+        self.num_iter, self.min_roundness, self.cluster_penalty = num_iter, min_roundness, cluster_penalty
+        self.roi_length = roi_length if roi_length is not None else round(1.2 * chamber_diameter)
+        self.progress_bar = progress_bar
+        self.search_timesteps = sorted(utils.to_list(search_timestep))
+        self.search_channels = utils.to_list(search_channel)
+
+    # -- find.py:205-306 ---------------------------------------------------------------------------
+    def find_centers(self, planes: torch.Tensor, tag: np.ndarray, seeds):
+        """planes (n_search, H, W) on the device -> mark_x, mark_y (R, Cc) float64."""
+        n_s, h, w = planes.shape
+        finder = _finder(1, h, w, self.min_button_radius, self.max_button_radius, self.num_iter, planes.device)
+        points = np.empty((0, 2))
+        for k in range(n_s):
+            res, _ = finder.find(planes[k : k + 1], None, self.low_edge_quantile, self.high_edge_quantile,
+                                 self.min_roundness, self.chamber_radius, [seeds[k]])
+            new = res[0][0][:, :2].astype(np.float64)
+            if len(points) > 0 and len(new) > 0:
+                dist = np.linalg.norm(points[np.newaxis] - new[:, np.newaxis], axis=2)
+                new = new[np.min(dist, axis=1) > self.chamber_radius]
+            points = np.concatenate([points, new])
+        x, y = points[:, 1], points[:, 0]
+        per_row, per_col = (tag != "").sum(axis=1), (tag != "").sum(axis=0)
+        n_rows, n_cols = tag.shape
+        if self.top_chamber is None:
+            row_labels = hotpath.cluster_1d(y, h, n_rows, self.row_dist, per_row, self.cluster_penalty, planes.device)
+        else:
+            row_labels = label_clusters(y, self.top_chamber, n_rows, 2 * self.chamber_radius,
+                                        self.row_dist - 2 * self.chamber_radius)
+        if self.left_chamber is None:
+            col_labels = hotpath.cluster_1d(x, w, n_cols, self.col_dist, per_col, self.cluster_penalty, planes.device)
+        else:
+            col_labels = label_clusters(x, self.left_chamber, n_cols, 2 * self.chamber_radius,
+                                        self.col_dist - 2 * self.chamber_radius)
+        inside = (row_labels >= 0) & (col_labels >= 0)
+        x, y, row_labels, col_labels = x[inside], y[inside], row_labels[inside], col_labels[inside]
+        row_slope, row_b = regress_clusters(x, y, row_labels, n_rows, per_row)
+        col_slope, col_b = regress_clusters(y, x, col_labels, n_cols, per_col)
+        row_b, col_b = np.atleast_1d(row_b), np.atleast_1d(col_b)
+        mark_y = (row_slope * col_b[np.newaxis] + row_b[:, np.newaxis]) / (1 - row_slope * col_slope)
+        mark_x = mark_y * col_slope + col_b[np.newaxis]
+        return mark_x, mark_y
+
+    # -- find.py:308-402 (refinement part) ---------------------------------------------------------
+    def refine(self, image_t: torch.Tensor, x, y, tag, search_idx, seed):
+        """image_t (C, H, W); grid estimate x, y (R, Cc) -> refined x, y and button radii (R, Cc)."""
+        n_c, h, w = image_t.shape
+        n_rows, n_cols = tag.shape
+        m, L = n_rows * n_cols, self.roi_length
+        x, y = x.copy(), y.copy()
+        radius = np.full((n_rows, n_cols), self.max_button_radius, dtype=np.int64)
+        centers = np.array([[round(float(y[i, j])), round(float(x[i, j]))] for i in range(n_rows) for j in range(n_cols)],
+                           dtype=np.int32)
+        tiles = hotpath.roi_gather_reduce(image_t.view(1, n_c, 1, h, w), [centers], L, None, want_masks=False,
+                                          want_sums=False)["roi"]  # (m, C, 1, L, L)
+        per_iter = self.num_iter // m
+        best_score = np.full(m, -np.inf)
+        best = np.full((m, 3), -1, dtype=np.int64)
+        if per_iter > 0:
+            finder = _finder(m, L, L, self.min_button_radius, self.max_button_radius, per_iter, image_t.device)
+            hi_q = 1 - np.pi * self.min_button_radius / L**2
+            for k, ch in enumerate(search_idx):
+                seeds = [chamber_seed(seed, c, k) for c in range(m)]
+                res, _ = finder.find(tiles[:, ch, 0], None, self.low_edge_quantile, hi_q, self.min_roundness, 0, seeds)
+                for c in range(m):
+                    circles, scores = res[c]
+                    if len(circles) > 0 and scores[0] > best_score[c]:  # sorted by score: [0] is np.argmax
+                        best[c], best_score[c] = circles[0], scores[0]
+        for c in range(m):
+            i, j = divmod(c, n_cols)
+            if tag[i, j] == "" or best[c, 2] < 0:
+                continue
+            top, _, left, _ = utils.bounding_box(int(centers[c, 1]), int(centers[c, 0]), L, w, h)
+            y[i, j], x[i, j] = best[c, 0] + top, best[c, 1] + left
+            radius[i, j] = best[c, 2]
+        return x, y, radius
+
+    def __call__(self, assay):
+        """find.py:55-203."""
+        image = _image_tensor(assay)
+        n_c, n_t, h, w = image.shape
+        if not self.search_channels:
+            self.search_channels = (assay.coords["channel"].values.tolist() if "channel" in assay.coords
+                                    else list(range(n_c)))
+        search_idx = [_channel_index(assay, c) for c in self.search_channels]
+        tag = assay.coords["tag"].values
+        n_rows, n_cols = tag.shape
+        m, L = n_rows * n_cols, self.roi_length
+        img_t = image.permute(1, 0, 2, 3).contiguous()  # (T, C, H, W): one assay-like block per timestep
+        x = np.empty((n_rows, n_cols, n_t))
+        y = np.empty((n_rows, n_cols, n_t))
+        radius = np.empty((n_rows, n_cols, n_t), dtype=np.int64)
+        valid = assay.coords["valid"].values.copy()
+        for t in self.search_timesteps:
+            planes = torch.stack([img_t[t, c] for c in search_idx])
+            gx, gy = self.find_centers(planes, tag, [utils.next_seed() for _ in search_idx])
+            x[..., t], y[..., t], radius[..., t] = self.refine(img_t[t], gx, gy, tag, search_idx, utils.next_seed())
+        for t in range(n_t):
+            if t in self.search_timesteps:
+                continue
+            src = self.search_timesteps[0] if t < self.search_timesteps[0] else t - 1
+            x[..., t], y[..., t], radius[..., t], valid[..., t] = x[..., src], y[..., src], radius[..., src], valid[..., src]
+        # final windows, masks and sums for every (timestep, chamber)
+        centers = [np.array([[round(float(y[i, j, t])), round(float(x[i, j, t]))] for i in range(n_rows)
+                             for j in range(n_cols)], dtype=np.int32) for t in range(n_t)]
+        out = hotpath.roi_gather_reduce(img_t.view(n_t, n_c, 1, h, w), centers, L, None, want_masks=False,
+                                        want_sums=False)
+        roi = out["roi"].view(n_t, m, n_c, L, L).permute(1, 2, 0, 3, 4).contiguous()  # (M, C, T, L, L)
+        rel = np.empty((n_t * m, 2), dtype=np.int32)
+        for t in range(n_t):
+            for c in range(m):
+                top, _, left, _ = utils.bounding_box(int(centers[t][c, 1]), int(centers[t][c, 0]), L, w, h)
+                rel[t * m + c] = (centers[t][c, 0] - top, centers[t][c, 1] - left)
+        radii_tm = np.ascontiguousarray(radius.reshape(m, n_t).T).reshape(-1)
+        fg, bg = hotpath.button_masks(rel, radii_tm, L, self.chamber_radius, self.max_button_radius, image.device)
+        fg = fg.view(n_t, m, L, L).permute(1, 0, 2, 3).contiguous()  # (M, T, L, L)
+        bg = bg.view(n_t, m, L, L).permute(1, 0, 2, 3).contiguous()
+        grid = (n_rows, n_cols)
+        assay["roi"] = DataArray(roi.view(grid + (n_c, n_t, L, L)),
+                                 ("mark_row", "mark_col", "channel", "time", "roi_y", "roi_x"))
+        assay = assay.assign_coords(
+            fg=(("mark_row", "mark_col", "time", "roi_y", "roi_x"), fg.view(grid + (n_t, L, L)).bool()),
+            bg=(("mark_row", "mark_col", "time", "roi_y", "roi_x"), bg.view(grid + (n_t, L, L)).bool()),
+            x=(("mark_row", "mark_col", "time"), x), y=(("mark_row", "mark_col", "time"), y),
+            valid=(("mark_row", "mark_col", "time"), valid),
+        )
+        assay._cache["radius"] = radius
+        return assay.stack_mark()
+
+    @registry.components.register("find_buttons")
+    def make(row_dist, col_dist, min_button_diameter, max_button_diameter, chamber_diameter, top_chamber, left_chamber,
+             low_edge_quantile, high_edge_quantile, num_iter, min_roundness, cluster_penalty, roi_length, progress_bar,
+             search_timestep, search_channel, interactive):
+        return ButtonFinder(row_dist=row_dist, col_dist=col_dist, min_button_diameter=min_button_diameter,
+                            max_button_diameter=max_button_diameter, chamber_diameter=chamber_diameter,
+                            top_chamber=top_chamber, left_chamber=left_chamber, low_edge_quantile=low_edge_quantile,
+                            high_edge_quantile=high_edge_quantile, num_iter=num_iter, min_roundness=min_roundness,
+                            cluster_penalty=cluster_penalty, roi_length=roi_length, progress_bar=progress_bar,
+                            search_timestep=search_timestep, search_channel=search_channel, interactive=interactive)

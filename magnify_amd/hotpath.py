@@ -582,3 +582,74 @@ def masked_median_u16(roi: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     _call("mg_roi_masked_median_u16", roi.contiguous().data_ptr(), mask.contiguous().data_ptr(), m, c, t, L,
                                                  out.data_ptr(), _stream())
     return out
+
+
+# --------------------------------------------------------------------------------------
+# A16 / A17: ButtonFinder helpers
+# --------------------------------------------------------------------------------------
+
+_CV_CACHE = {}
+
+
+def _cv_table(max_r: int, device):
+    """Rows r = 0..max_r of cv.circle's filled-disk half widths (utils.py:38 call site)."""
+    key = (max_r, str(device))
+    if key not in _CV_CACHE:
+        tab = np.full((max_r + 1, max_r + 1), -1, dtype=np.int32)
+        for r in range(max_r + 1):
+            tab[r, : r + 1] = nat.cv_disk_halfwidths(r)
+        _CV_CACHE[key] = torch.from_numpy(tab).to(device)
+    return _CV_CACHE[key]
+
+
+def cluster_1d(points, total_length, num_clusters, cluster_length, ideal_num_points, penalty, device="cuda"):
+    """find.py:632-677: brute-force search over integer offsets (costs on the GPU, one thread per
+    offset), first minimum wins; returns the cluster label of every point (-1 outside)."""
+    require_gpu()
+    points = np.asarray(points, dtype=np.float64)
+    perm = np.argsort(points)
+    pts = points[perm]
+    n_off = int(total_length - round(num_clusters * cluster_length))
+    if n_off <= 0:
+        raise ValueError("cluster_1d: the clusters do not fit into total_length")  # reference: best_spans is None
+    d_pts = torch.from_numpy(pts).to(device) if len(pts) else torch.zeros(1, dtype=torch.float64, device=device)
+    d_ideal = torch.from_numpy(np.asarray(ideal_num_points, dtype=np.float64)).to(device)
+    costs = torch.empty(n_off, dtype=torch.float64, device=device)
+    _call("mg_cluster1d_costs", d_pts.data_ptr(), len(pts), n_off, int(num_clusters), float(cluster_length),
+          d_ideal.data_ptr(), float(penalty), costs.data_ptr(), _stream())
+    best = int(np.argmin(costs.cpu().numpy()))  # first occurrence == strict "<" update rule
+    bounds = np.arange(num_clusters + 1) * cluster_length + best
+    spans = np.searchsorted(pts, bounds)
+    labels = -np.ones(len(pts), dtype=int)
+    labels[spans[0] : spans[-1]] = np.repeat(np.arange(num_clusters), spans[1:] - spans[:-1])
+    return labels[np.argsort(perm)]
+
+
+def button_masks(centers_rc, radii, roi_len, outer_r, inner_r, device="cuda"):
+    """fg = filled cv.circle(radius_i), bg = annulus(outer_r, inner_r) about centers (row, col) in
+    window coordinates (find.py:383-400).  Returns uint8 tensors (M, L, L)."""
+    require_gpu()
+    centers_rc = np.ascontiguousarray(np.asarray(centers_rc, dtype=np.int32).reshape(-1, 2))
+    radii = np.ascontiguousarray(np.asarray(radii, dtype=np.int32).reshape(-1))
+    m = len(radii)
+    max_r = int(max([outer_r, inner_r] + radii.tolist())) if m else max(outer_r, inner_r)
+    tab = _cv_table(max_r, device)
+    fg = torch.empty((m, roi_len, roi_len), dtype=torch.uint8, device=device)
+    bg = torch.empty((m, roi_len, roi_len), dtype=torch.uint8, device=device)
+    if m:
+        d_c, d_r = torch.from_numpy(centers_rc).to(device), torch.from_numpy(radii).to(device)
+        _call("mg_button_masks", d_c.data_ptr(), d_r.data_ptr(), m, int(roi_len), int(outer_r), int(inner_r),
+              tab.data_ptr(), tab.shape[1], max_r, fg.data_ptr(), bg.data_ptr(), _stream())
+    return fg, bg
+
+
+def masked_sums(roi: torch.Tensor, fg: torch.Tensor, bg: torch.Tensor):
+    """roi (M, C, T, L, L), fg/bg (M, L, L) uint8 -> sums (M, C, T, 2) float64, counts (M, 2) int32."""
+    require_gpu()
+    m, c, t, L, _ = roi.shape
+    sums = torch.empty((m, c, t, 2), dtype=torch.float64, device=roi.device)
+    counts = torch.empty((m, 2), dtype=torch.int32, device=roi.device)
+    if m:
+        _call("mg_masked_sums", roi.contiguous().data_ptr(), nat.dtype_code(roi.dtype), fg.contiguous().data_ptr(),
+              bg.contiguous().data_ptr(), m, c * t, L, sums.data_ptr(), counts.data_ptr(), _stream())
+    return sums, counts

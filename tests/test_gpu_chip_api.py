@@ -1,0 +1,210 @@
+"""Chip / button path: the scenarios and tolerances of the reference's tests/test_chip.py driven
+through ``mg.microfluidic_chip`` of this build, plus seeded parity of ButtonFinder's two stages
+against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import ref_numeric as rn
+from oracle import ref_opencv as rcv
+from oracle import ref_pipeline as rp
+from synth import draw_chip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import magnify_amd
+    from magnify_amd import hotpath
+
+    hotpath.require_gpu()
+    magnify_amd.seed(4321)
+    return magnify_amd
+
+
+KW = dict(min_button_diameter=16, max_button_diameter=32, overlap=0, row_dist=100, col_dist=100)
+
+
+def chip(mg, data, dims=("y", "x"), **coords):
+    return mg.DataArray(data=data, dims=dims, coords=coords or None)
+
+
+def test_one_by_one_chip(mg):
+    # tests/test_chip.py:54-73
+    xp = mg.microfluidic_chip(data=chip(mg, draw_chip((1, 1), 20)), shape=(1, 1), num_iter=100, **KW)
+    assert isinstance(xp, mg.Dataset)
+    xp = xp.unstack().transpose("mark_row", "mark_col", ...)
+    assert xp.roi.sizes["mark_row"] == 1 and xp.roi.sizes["mark_col"] == 1
+    assert 0.95 * 10 < np.sqrt(xp.fg.sum().values.item() / np.pi) < 1.05 * 10
+    assert 0.95 * 100 < xp.x.squeeze().values.item() < 1.05 * 100
+
+
+def test_float_chip(mg):
+    # tests/test_chip.py:76-96
+    xp = mg.microfluidic_chip(data=chip(mg, draw_chip((1, 1), 20).astype(np.float32)), shape=(1, 1), num_iter=100, **KW)
+    assert 0.9 * 10 < np.sqrt(xp.fg.sum().values.item() / np.pi) < 1.1 * 10
+    assert 0.95 * 100 < xp.x.squeeze().values.item() < 1.05 * 100
+
+
+def test_ten_by_ten_chip(mg):
+    # tests/test_chip.py:99-128
+    xp = mg.microfluidic_chip(data=chip(mg, draw_chip((10, 10), 20)), shape=(10, 10), num_iter=10000, **KW)
+    xp = xp.unstack().transpose("mark_row", "mark_col", ...)
+    assert xp.roi.sizes["mark_row"] == 10 and xp.roi.sizes["mark_col"] == 10
+    radii = np.sqrt(xp.fg.sum(["roi_x", "roi_y"]).to_numpy() / np.pi)
+    assert 0.9 * 10 < radii.min() and radii.max() < 1.1 * 10
+    assert 0.95 * 100 < xp.x[0, 0].values.item() < 1.05 * 100
+    assert 0.95 * 100 < xp.y[0, 0].values.item() < 1.05 * 100
+    assert 395 < xp.x[4, 3].values.item() < 405 and 495 < xp.y[4, 3].values.item() < 505
+
+
+@pytest.mark.parametrize("shape", [(3, 5), (5, 3)])
+def test_rectangular_chips(mg, shape):
+    # tests/test_chip.py:135-191
+    xp = mg.microfluidic_chip(data=chip(mg, draw_chip(shape, 20)), shape=shape, num_iter=5000, **KW)
+    xp = xp.unstack().transpose("mark_row", "mark_col", ...)
+    assert (xp.roi.sizes["mark_row"], xp.roi.sizes["mark_col"]) == shape
+    for i in range(shape[0]):
+        for j in range(shape[1]):
+            assert abs(xp.x[i, j].values.item() - 100 * (j + 1)) < 10
+            assert abs(xp.y[i, j].values.item() - 100 * (i + 1)) < 10
+
+
+def test_large_buttons_and_spacing(mg):
+    # tests/test_chip.py:194-256
+    data = draw_chip((3, 3), 40, row_dist=150, col_dist=150)
+    xp = mg.microfluidic_chip(data=chip(mg, data), shape=(3, 3), min_button_diameter=30, max_button_diameter=50,
+                              chamber_diameter=80, overlap=0, row_dist=150, col_dist=150, num_iter=5000)
+    radii = np.sqrt(xp.fg.sum(["roi_x", "roi_y"]).to_numpy() / np.pi)
+    assert 0.85 * 20 < radii.min() and radii.max() < 1.15 * 20
+    data = draw_chip((3, 4), 20, row_dist=80, col_dist=120)
+    xp = mg.microfluidic_chip(data=chip(mg, data), shape=(3, 4), min_button_diameter=16, max_button_diameter=32,
+                              overlap=0, row_dist=80, col_dist=120, num_iter=5000)
+    xp = xp.unstack().transpose("mark_row", "mark_col", ...)
+    assert abs(xp.x[1, 2].values.item() - 360) < 10 and abs(xp.y[1, 2].values.item() - 160) < 10
+
+
+def test_chip_with_blanks(mg):
+    # tests/test_chip.py:286-311
+    blanks = [(0, 0), (1, 2), (2, 1), (3, 3)]
+    xp = mg.microfluidic_chip(data=chip(mg, draw_chip((4, 4), 20, blanks=blanks)), shape=(4, 4), num_iter=5000, **KW)
+    xp = xp.unstack().transpose("mark_row", "mark_col", ...)
+    assert xp.roi.sizes["mark_row"] == 4 and xp.roi.sizes["mark_col"] == 4
+    assert np.sum(xp.fg.sum(["roi_x", "roi_y"]).to_numpy() > 100) >= 12
+
+
+def test_chip_output_structure(mg):
+    # tests/test_chip.py:319-369
+    xp = mg.microfluidic_chip(data=chip(mg, draw_chip((2, 2), 20)), shape=(2, 2), num_iter=1000, **KW)
+    assert "mark_row" in xp.dims and "mark_col" in xp.dims
+    for name in ("x", "y", "fg", "bg", "tag"):
+        assert name in xp.coords
+    assert "roi" in xp.data_vars and "roi_x" in xp.dims and "roi_y" in xp.dims
+    assert xp.roi.shape[-2:] == (72, 72)  # round(1.2 * chamber_diameter), find.py:49
+    assert (xp.tag.values == "default").all()
+    assert xp.roi.dims == ("mark_row", "mark_col", "roi_y", "roi_x")
+
+
+def test_chip_timesteps(mg):
+    # tests/test_chip.py:377-464: geometry is copied to non-searched timesteps
+    img = draw_chip((3, 3), 20)
+    data = chip(mg, np.stack([img] * 4), ("time", "y", "x"), time=[0, 1, 2, 3])
+    xp = mg.microfluidic_chip(data=data, shape=(3, 3), num_iter=5000, search_timestep=0, **KW)
+    assert xp.sizes["time"] == 4
+    xp = xp.unstack().transpose("mark_row", "mark_col", ...)
+    for t in range(1, 4):
+        np.testing.assert_array_almost_equal(xp.x[:, :, 0].values, xp.x[:, :, t].values)
+        np.testing.assert_array_almost_equal(xp.y[:, :, 0].values, xp.y[:, :, t].values)
+    for r in range(3):
+        for c in range(3):
+            assert 0.9 * 100 * (c + 1) < xp.x[r, c, 0].values.item() < 1.1 * 100 * (c + 1)
+            assert 0.9 * 100 * (r + 1) < xp.y[r, c, 0].values.item() < 1.1 * 100 * (r + 1)
+    areas = xp.fg.sum(dim=["roi_x", "roi_y"]).values
+    assert (np.sqrt(areas / np.pi) > 8).all() and (np.sqrt(areas / np.pi) < 12).all()
+
+
+def test_chip_refinding_tracks_shift(mg):
+    # tests/test_chip.py:502-560: searched timesteps follow a 10 px shift
+    a = draw_chip((3, 3), 20)
+    b = draw_chip((3, 3), 20, offset=(10, 10))
+    data = chip(mg, np.stack([a, b]), ("time", "y", "x"), time=[0, 1])
+    xp = mg.microfluidic_chip(data=data, shape=(3, 3), num_iter=5000, search_timestep=[0, 1], **KW)
+    xp = xp.unstack().transpose("mark_row", "mark_col", ...)
+    dx = xp.x[:, :, 1].values - xp.x[:, :, 0].values
+    dy = xp.y[:, :, 1].values - xp.y[:, :, 0].values
+    assert np.all(np.abs(dx - 10) < 5) and np.all(np.abs(dy - 10) < 5)
+    xq = mg.microfluidic_chip(data=data, shape=(3, 3), num_iter=5000, search_timestep=0, **KW)
+    np.testing.assert_array_almost_equal(xq.x.values[..., 0], xq.x.values[..., 1])
+
+
+def test_chip_multichannel(mg):
+    # tests/test_chip.py:618-738
+    img = draw_chip((3, 3), 20)
+    data = chip(mg, np.stack([img, img // 2]), ("channel", "y", "x"), channel=["a", "b"])
+    xp = mg.microfluidic_chip(data=data, shape=(3, 3), num_iter=5000, **KW)
+    assert xp.roi.dims == ("mark_row", "mark_col", "channel", "roi_y", "roi_x")
+    xq = mg.microfluidic_chip(data=data, shape=(3, 3), num_iter=5000, search_channel="b", **KW)
+    assert abs(xq.x.values[1, 1] - 200) < 10
+    np.testing.assert_array_equal(xp.roi.values[:, :, 1] * 2, xp.roi.values[:, :, 0] // 2 * 2)
+
+
+def test_invalid_arguments(mg):
+    with pytest.raises(ValueError):
+        mg.microfluidic_chip(data=chip(mg, draw_chip((1, 1), 20)), shape=(1, 1), min_button_diameter=40,
+                             max_button_diameter=30, overlap=0, num_iter=10)
+    with pytest.raises(ValueError):
+        mg.microfluidic_chip(data=chip(mg, draw_chip((1, 1), 20)), shape=None, overlap=0, num_iter=10)
+
+
+# ---- seeded stage parity against the oracle ----------------------------------------------------
+
+
+def test_cluster_and_masks_kernels(mg, golden):
+    from magnify_amd import hotpath as hp
+
+    g = golden("clusters")
+    rl = hp.cluster_1d(g["y"], 900, 6, float(g["rd"]), g["ideal_r"], 50)
+    cl = hp.cluster_1d(g["x"], 900, 5, float(g["cd"]), g["ideal_c"], 50)
+    np.testing.assert_array_equal(rl, g["row_labels"])  # the reference's own output
+    np.testing.assert_array_equal(cl, g["col_labels"])
+    rng = np.random.default_rng(0)
+    centers = rng.integers(-5, 80, size=(20, 2))
+    radii = rng.integers(0, 16, size=20)
+    fg, bg = hp.button_masks(centers, radii, 72, 30, 15)
+    for i in range(20):
+        np.testing.assert_array_equal(fg[i].cpu().numpy().astype(bool), rcv.filled_circle_mask((72, 72), centers[i], int(radii[i])))
+        want = rcv.filled_circle_mask((72, 72), centers[i], 30) & ~rcv.filled_circle_mask((72, 72), centers[i], 15)
+        np.testing.assert_array_equal(bg[i].cpu().numpy().astype(bool), want)
+    import torch
+
+    roi = torch.from_numpy(rng.integers(0, 4000, size=(20, 2, 3, 72, 72)).astype(np.uint16)).cuda()
+    sums, counts = hp.masked_sums(roi, fg, bg)
+    r, f, b = roi.cpu().numpy().astype(np.int64), fg.cpu().numpy().astype(bool), bg.cpu().numpy().astype(bool)
+    np.testing.assert_array_equal(sums.cpu().numpy()[..., 0], (r * f[:, None, None]).sum(axis=(-1, -2)))
+    np.testing.assert_array_equal(sums.cpu().numpy()[..., 1], (r * b[:, None, None]).sum(axis=(-1, -2)))
+    np.testing.assert_array_equal(counts.cpu().numpy()[:, 0], f.sum(axis=(-1, -2)))
+
+
+def test_button_finder_stages_match_oracle(mg):
+    import torch
+
+    from magnify_amd.find import ButtonFinder
+
+    img = draw_chip((4, 5), 20, row_dist=90, col_dist=110)
+    img[img > 0] += 37
+    tag = np.full((4, 5), "default", dtype="<U200")
+    tag[1, 2] = ""
+    bf = ButtonFinder(row_dist=90, col_dist=110, min_button_diameter=16, max_button_diameter=32, chamber_diameter=60,
+                      top_chamber=None, left_chamber=None, low_edge_quantile=0.1, high_edge_quantile=0.9, num_iter=20000,
+                      min_roundness=0.2, cluster_penalty=50, roi_length=None, progress_bar=False, search_timestep=0,
+                      search_channel=None, interactive=False)
+    d_img = torch.from_numpy(img).cuda()
+    gx, gy = bf.find_centers(d_img[None], tag, [77])
+    ox, oy = rp.find_centers(img[None], tag, 90, 110, 8, 16, 30, 0.1, 0.9, 20000, 0.2, 50, seed=77)
+    np.testing.assert_allclose(gx, ox, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(gy, oy, rtol=0, atol=1e-9)
+    x, y, radius = bf.refine(d_img[None], gx, gy, tag, [0], 99)
+    _, fg_o, bg_o, x_o, y_o = rp.find_rois(img[None], ox, oy, tag, [0], 8, 16, 30, 72, 0.1, 20000, 0.2, seed=99)
+    np.testing.assert_allclose(x, x_o, atol=1e-9)
+    np.testing.assert_allclose(y, y_o, atol=1e-9)
+    assert radius[1, 2] == 16 and (radius[tag != ""] <= 12).all()
