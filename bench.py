@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--num-iter", type=int, default=5_000_000)
     ap.add_argument("--plane-batch", type=int, default=0, help="searched planes per kernel batch (0 = all)")
-    ap.add_argument("--cpu-size", type=int, default=1024)
+    ap.add_argument("--cpu-size", type=int, default=2048)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -161,8 +161,15 @@ def main():
         ab = algorithmic_bytes(dom, p)
         avg_s = dom_ms / dom_n / 1e3
         achieved = ab / avg_s / 1e9 if ab else None
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            if (T, C, S, args.num_iter) == (64, 4, 4096, 5_000_000) and dom in pmc["stages"]:
+                traffic = pmc["stages"][dom]["hbm_bytes_per_step"] / (dom_n / args.steps)
+        except (OSError, KeyError, ValueError):
+            traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                    "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                     "algorithmic_bytes_per_launch": ab, "avg_launch_ms": dom_ms / dom_n,
                     "share_of_kernel_time": dom_ms / total_ms}
         # the streaming part alone (everything that is not RANSAC scoring / suppression)

@@ -286,15 +286,26 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
       const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
       const int by = row - wy0, bx = col - wx0;
       double acc = 0.0;
-      for (int p = p0; p < p1; ++p) {
-        const int v = tab[p];
-        const int dr = v >> 16, dc = (int)(int16_t)(v & 0xFFFF);
-        const int y = by + dr, x = bx + dc;
-        if (!((win[y * wpr + (x >> 5)] >> (x & 31)) & 1u)) continue;
-        const float an = ang[(int64_t)(row + dr) * w + (col + dc)];
-        double d = fabs((double)an - d_per_expected[p]);
-        if (d > PI) d = d - PI;
-        acc += 4.0 * fabs(d - PI / 2.0) / PI - 1.0;
+      // 32 perimeter points at a time: hit mask from LDS, then only the hits (in perimeter order)
+      // pay for the angle gather and the float64 arithmetic
+      for (int base = p0; base < p1; base += 32) {
+        uint32_t mask = 0;
+        const int cnt = min(32, p1 - base);
+        for (int j = 0; j < cnt; ++j) {
+          const int v = tab[base + j];
+          const int y = by + (v >> 16), x = bx + (int)(int16_t)(v & 0xFFFF);
+          mask |= ((win[y * wpr + (x >> 5)] >> (x & 31)) & 1u) << j;
+        }
+        while (mask) {
+          const int j = __ffs(mask) - 1;
+          mask &= mask - 1;
+          const int p = base + j;
+          const int v = tab[p];
+          const float an = ang[(int64_t)(row + (v >> 16)) * w + (col + (int)(int16_t)(v & 0xFFFF))];
+          double d = fabs((double)an - d_per_expected[p]);
+          if (d > PI) d = d - PI;
+          acc += 4.0 * fabs(d - PI / 2.0) / PI - 1.0;
+        }
       }
       const float score = (float)acc / (float)(p1 - p0);
       scores[i] = score;
