@@ -134,7 +134,8 @@ def main():
     hp.set_timer(None)
     stages = timer.summary()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        gloo = torch.distributed.get_backend() == "gloo"
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 

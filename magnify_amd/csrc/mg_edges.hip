@@ -205,12 +205,22 @@ __global__ __launch_bounds__(NT) void k_u8_blur(const T* __restrict__ src, int64
   }
 }
 
-// Scharr of 4 adjacent pixels from three rows (bytes c0-1 .. c0+4 of each).
-__device__ __forceinline__ void scharr4(const Row12& a, const Row12& b, const Row12& c, int (&dx)[4], int (&dy)[4]) {
+// Scharr of N adjacent pixels starting at pixel c0 + FIRST from three rows, via the separable
+// parts S = 3a + 10b + 3c (vertical smooth) and D = c - a (vertical difference):
+//   dx[q] = S[q+1] - S[q-1],  dy[q] = 3 (D[q-1] + D[q+1]) + 10 D[q].
+template <int FIRST, int N>
+__device__ __forceinline__ void scharr_n(const Row12& a, const Row12& b, const Row12& c, int (&dx)[N], int (&dy)[N]) {
+  int S[N + 2], D[N + 2];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    dx[q] = 3 * (a.at(q + 1) - a.at(q - 1)) + 10 * (b.at(q + 1) - b.at(q - 1)) + 3 * (c.at(q + 1) - c.at(q - 1));
-    dy[q] = 3 * (c.at(q - 1) - a.at(q - 1)) + 10 * (c.at(q) - a.at(q)) + 3 * (c.at(q + 1) - a.at(q + 1));
+  for (int j = 0; j < N + 2; ++j) {
+    const int o = FIRST - 1 + j;
+    S[j] = 3 * (a.at(o) + c.at(o)) + 10 * b.at(o);
+    D[j] = c.at(o) - a.at(o);
+  }
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    dx[q] = S[q + 2] - S[q];
+    dy[q] = 3 * (D[q] + D[q + 2]) + 10 * D[q + 1];
   }
 }
 
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ 
     const int gy = ty0 + wave * RPW + jr - 2;
     if (gy < h && gx < w) {
       int dx[4], dy[4];
-      scharr4(ra, rb, rc, dx, dy);
+      scharr_n<0, 4>(ra, rb, rc, dx, dy);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (gx + q >= w) continue;
@@ -336,16 +346,17 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
     for (int k = 0; k < 6; ++k) mg[0][k] = mg[1][k], mg[1][k] = mg[2][k];
 #pragma unroll
     for (int q = 0; q < 4; ++q) cdx[0][q] = cdx[1][q], cdy[0][q] = cdy[1][q];
+    {
+      int ddx[6], ddy[6];  // pixels c0 - 1 .. c0 + 4
+      scharr_n<-1, 6>(ra, rb, rc, ddx, ddy);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const int q = k - 1;  // pixel c0 + q
-      const int ddx = 3 * (ra.at(q + 1) - ra.at(q - 1)) + 10 * (rb.at(q + 1) - rb.at(q - 1)) + 3 * (rc.at(q + 1) - rc.at(q - 1));
-      const int ddy = 3 * (rc.at(q - 1) - ra.at(q - 1)) + 10 * (rc.at(q) - ra.at(q)) + 3 * (rc.at(q + 1) - ra.at(q + 1));
-      const int x = gx + q;
-      mg[2][k] = (ym >= 0 && ym < h && x >= 0 && x < w) ? ddx * ddx + ddy * ddy : 0;
-      if (k >= 1 && k <= 4) {
-        cdx[1][k - 1] = ddx;
-        cdy[1][k - 1] = ddy;
+      for (int k = 0; k < 6; ++k) {
+        const int x = gx + k - 1;
+        mg[2][k] = (ym >= 0 && ym < h && x >= 0 && x < w) ? ddx[k] * ddx[k] + ddy[k] * ddy[k] : 0;
+        if (k >= 1 && k <= 4) {
+          cdx[1][k - 1] = ddx[k];
+          cdy[1][k - 1] = ddy[k];
+        }
       }
     }
     ra = rb;

@@ -21,11 +21,14 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+            backend = os.environ.get("MG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            # MG_SHARE_GPU=1: rehearsal of the multi-rank path on a single-GPU box (all ranks on cuda:0, gloo)
+            local = 0 if os.environ.get("MG_SHARE_GPU") == "1" else local
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
+        local = 0 if os.environ.get("MG_SHARE_GPU") == "1" else local
         torch.cuda.set_device(local)
     return rank, world, local
 
@@ -51,6 +54,9 @@ def gather_marker_table(table: torch.Tensor) -> torch.Tensor:
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return table
     world = dist.get_world_size()
+    out_device = table.device
+    if dist.get_backend() == "gloo":
+        table = table.cpu()  # gloo collectives run on host tensors
     count = torch.tensor([table.shape[0]], dtype=torch.int64, device=table.device)
     counts = [torch.zeros_like(count) for _ in range(world)]
     dist.all_gather(counts, count)
@@ -60,7 +66,7 @@ def gather_marker_table(table: torch.Tensor) -> torch.Tensor:
     padded[: table.shape[0]] = table
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded)
-    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0).to(out_device)
 
 
 def marker_table(out: dict, assay_offset: int, n_channels: int, device) -> torch.Tensor:
