@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--num-iter", type=int, default=5_000_000)
     ap.add_argument("--plane-batch", type=int, default=0, help="searched planes per kernel batch (0 = all)")
-    ap.add_argument("--cpu-size", type=int, default=2048)
+    ap.add_argument("--cpu-size", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

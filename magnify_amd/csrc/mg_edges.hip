@@ -25,7 +25,7 @@ constexpr int CHUNKS = LS / 16;          // 16-byte chunks per LDS row (18)
 
 // ---- to_uint8 -------------------------------------------------------------------------
 struct U8Scale {
-  double mn, top, rcp;
+  double mn, top, scale, offset;
   int passthrough;
 };
 
@@ -35,20 +35,20 @@ __device__ __forceinline__ U8Scale make_scale(const double* d_minmax, int plane)
   s.mn = s.passthrough ? 0.0 : d_minmax[2 * plane];
   const double mx = s.passthrough ? 0.0 : d_minmax[2 * plane + 1];
   s.top = mx - s.mn;  // == max(arr - min) because x -> fl(x - mn) is monotone
-  s.rcp = s.top > 0.0 ? 1.0 / s.top : 0.0;
+  // integer inputs: floor(255 (x - mn) / top) == floor(x * scale + offset), see to_u8
+  s.scale = s.top > 0.0 ? 255.0 / s.top : 0.0;
+  s.offset = s.top > 0.0 ? 0x1p-20 - s.mn * s.scale : 0.0;
   return s;
 }
 
-// utils.py:23-27.  Integer inputs: floor(255 * (x - mn) / top) computed exactly: the true
-// quotient is either an integer or at least 1/top >= 2^-16 away from one, so the float64
-// product with the rounded reciprocal (+2^-20) floors to the same integer as the reference's
-// correctly rounded float64 division.
+// utils.py:23-27.  Integer inputs: the true quotient 255 (x - mn) / top is either an integer or
+// at least 1/top >= 2^-16 away from one, while x * scale + offset carries ~1e-10 of rounding on
+// top of the deliberate +2^-20, so one fused multiply-add floors to the same integer as the
+// reference's correctly rounded float64 division (a constant image gives scale = offset = 0).
 template <typename T>
 __device__ __forceinline__ uint8_t to_u8(T x, const U8Scale& s) {
   if (s.passthrough) return (uint8_t)x;
-  const double a = (double)x - s.mn;
-  if (!(s.top > 0.0)) return (uint8_t)(int)a;
-  return (uint8_t)(unsigned int)(255.0 * a * s.rcp + 0x1p-20);
+  return (uint8_t)(unsigned int)fma((double)x, s.scale, s.offset);
 }
 template <>
 __device__ __forceinline__ uint8_t to_u8<float>(float x, const U8Scale& s) {
