@@ -336,6 +336,13 @@ class Dataset:
         for k, v in (data_vars or {}).items():
             self[k] = v
 
+    @property
+    def mg(self):
+        """``Dataset.mg.cache(vars)`` of the reference (accessor.py:18-35) spills lazy dask arrays to
+        zarr; here arrays are already resident in HBM, so caching only materialises pending
+        (lazy flat-field) operands."""
+        return _Accessor(self)
+
     # -- mapping protocol ---------------------------------------------------------------------
     def __contains__(self, name):
         return name in self.data_vars or name in self.coords
@@ -527,6 +534,17 @@ class Dataset:
         if "mark_shape" in self._cache and "mark" in self.sizes:
             ds = ds.set_index(mark=("mark_row", "mark_col"))
         return ds
+
+
+class _Accessor:
+    def __init__(self, ds):
+        self._ds = ds
+
+    def cache(self, variables=None):
+        names = [variables] if isinstance(variables, str) else list(variables or self._ds.variables)
+        for n in names:
+            self._ds.variables[n].data  # forces a pending operand
+        return self._ds
 
 
 def from_any(obj):

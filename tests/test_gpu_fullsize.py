@@ -1,0 +1,124 @@
+"""Full-size (BASELINE.json shapes) checks through size-independent properties, the C3-style
+stitched chip through the whole pipeline, and the single-assay (mode R) stack path."""
+import numpy as np
+import pytest
+
+from oracle import ref_pipeline as rp
+from synth import draw_chip, vignette
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import magnify_amd
+    from magnify_amd import hotpath
+
+    hotpath.require_gpu()
+    magnify_amd.seed(99)
+    return magnify_amd
+
+
+def test_full_size_stack_properties(mg):
+    """2 timepoints x 4 ch x 4096^2 with the reference-default RANSAC budget."""
+    from magnify_amd.stack import StackProcessor, synthetic_stack
+
+    T, C, S = 2, 4, 4096
+    stack, truth = synthetic_stack(T, C, S, S, seed=123)
+    flat_np = vignette((S, S))
+    flat = torch.from_numpy(flat_np).cuda()
+    proc = StackProcessor(T, C, S, S, num_iter=5_000_000, search_channels=(0,), mode="P")
+    out = proc(stack, flat, 100.0, seed=7, want_roi=True)
+    beads = out["beads"]
+    # (a) flat-field: a random sample of rows against the oracle formula (global maxima per assay)
+    img = proc.image.cpu().numpy()
+    st = stack.cpu().numpy()
+    for t in range(T):
+        want = rp.flatfield_correct(st[t].reshape(C, 1, 1, 1, S, S), flat_np, 100.0).reshape(C, S, S)
+        rows = np.random.default_rng(t).integers(0, S, 16)
+        np.testing.assert_array_equal(img[t][:, rows], want[:, rows])
+    # (b) recall against the drawn beads of timepoint 0 (exact positions known)
+    found = beads[0][:, :2].astype(np.float64)
+    d = np.sqrt(((truth[:, None, :2] - found[None]) ** 2).sum(-1)).min(axis=1)
+    assert (d <= 3).mean() > 0.8  # the reference algorithm at min_roundness 0.3 misses dim beads in noise
+    # (c) masks and reductions are self-consistent: counts == mask sums, sums == sum(roi * mask)
+    roi, fg, bg = out["roi"], out["fg"], out["bg"]
+    counts, sums = out["counts"].cpu().numpy(), out["sums"].cpu().numpy()
+    np.testing.assert_array_equal(counts[:, 0], fg.sum(dim=(-1, -2), dtype=torch.int64).cpu().numpy())
+    np.testing.assert_array_equal(counts[:, 1], bg.sum(dim=(-1, -2), dtype=torch.int64).cpu().numpy())
+    m = roi.shape[0]
+    pick = np.random.default_rng(0).integers(0, m, 200)
+    r = roi.view(torch.int16)[pick].cpu().numpy().view(np.uint16).astype(np.int64)
+    f = fg[pick].cpu().numpy().astype(np.int64)
+    np.testing.assert_array_equal(sums[pick][:, :, 0, 0], (r[:, :, 0] * f[:, None]).sum(axis=(-1, -2)))
+    assert not (fg & bg).any()
+    # (d) same seed -> identical result (the whole chain is deterministic)
+    out2 = proc(stack, flat, 100.0, seed=7, want_roi=False)
+    for a, b in zip(beads, out2["beads"]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_mode_r_matches_oracle_small(mg):
+    """Single-assay semantics (find.py:477, 543-550): detection on time 0, maxima over the stack."""
+    from magnify_amd.stack import StackProcessor
+    from synth import noisy_bead_image
+
+    planes = np.stack([np.stack([noisy_bead_image(50 + 3 * t + c, (256, 256), 6, r_lo=6, r_hi=10)[0] for c in range(2)])
+                       for t in range(3)])  # (T, C, H, W)
+    proc = StackProcessor(3, 2, 256, 256, num_iter=20000, min_bead_diameter=10, max_bead_diameter=24,
+                          search_channels=(0,), mode="R")
+    out = proc(torch.from_numpy(planes).cuda(), 0.9, 90.0, seed=3)
+    want_img = rp.flatfield_correct(planes, 0.9, 90.0)  # maxima over the whole stack
+    np.testing.assert_array_equal(proc.image.cpu().numpy(), want_img)
+    assert len(out["beads"]) == 1 and out["roi"].shape[1:3] == (2, 3)
+    # geometry comes from time 0 only and the windows of every time point are gathered
+    b = out["beads"][0]
+    assert len(b) >= 4
+    from oracle import ref_numeric as rn
+
+    for i in range(len(b)):
+        top, bottom, left, right = rn.bounding_box(int(b[i, 1]), int(b[i, 0]), proc.L, 256, 256)
+        want = want_img[:, :, top:bottom, left:right].transpose(1, 0, 2, 3)  # (C, T, L, L)
+        np.testing.assert_array_equal(out["roi"][i].cpu().numpy(), want)
+
+
+def test_stitched_chip_pipeline(mg):
+    """C3 shape at reduced scale: a chip canvas cut into 4 x 4 overlapping tiles, stitched, grid-fit."""
+    canvas = draw_chip((8, 8), 20, row_dist=250, col_dist=250)  # 2250 x 2250
+    ty = tx = 600
+    overlap = 50
+    step = ty - overlap
+    clip = overlap // 2
+    tiles = np.zeros((4, 4, ty, tx), dtype=np.uint16)
+    for r in range(4):
+        for c in range(4):
+            tiles[r, c] = canvas[r * step : r * step + ty, c * step : c * step + tx]
+    data = mg.DataArray(tiles, ("row", "col", "y", "x"))
+    xp = mg.microfluidic_chip(data=data, shape=(8, 8), overlap=overlap, row_dist=250, col_dist=250,
+                              min_button_diameter=16, max_button_diameter=32, num_iter=200000)
+    assert xp.image.shape == (4 * step, 4 * step)
+    np.testing.assert_array_equal(xp.image.values, canvas[clip : clip + 4 * step, clip : clip + 4 * step])
+    xp = xp.unstack().transpose("mark_row", "mark_col", ...)
+    for i in range(8):
+        for j in range(8):
+            assert abs(xp.x[i, j].values.item() - (250 * (j + 1) - clip)) < 8
+            assert abs(xp.y[i, j].values.item() - (250 * (i + 1) - clip)) < 8
+    radii = np.sqrt(xp.fg.sum(["roi_x", "roi_y"]).to_numpy() / np.pi)
+    assert 0.85 * 10 < radii.min() and radii.max() < 1.15 * 10
+    assert xp.mg.cache(["roi"]) is xp
+
+
+def test_argument_errors(mg):
+    from magnify_amd import hotpath as hp
+
+    img = torch.zeros((1, 1, 1, 32, 32), dtype=torch.uint16, device="cuda")
+    with pytest.raises(ValueError):
+        hp.roi_gather_reduce(img, [np.array([[5, 5, 3]])], 64, None)  # window larger than the image
+    with pytest.raises(ValueError):
+        hp.CircleFinder(1, 32, 32, 10, 5, 100)
+    with pytest.raises(ValueError):
+        mg.beads(mg.DataArray(np.zeros((64, 64), np.uint16), ("y", "x")), min_bead_diameter=30, max_bead_diameter=20,
+                 overlap=0, num_iter=10)
+    with pytest.raises(TypeError):
+        mg.beads(mg.DataArray(np.zeros((64, 64), np.complex64), ("y", "x")), overlap=0, num_iter=10)
