@@ -221,6 +221,13 @@ int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const float* d_sc
                  const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
                  int32_t* d_undecided, void* stream);
 
+/* After the rounds have converged: restore the all-ones claim grid under the rings of all alive
+ * circles, so that the grid needs its full initialisation only once. */
+int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
+                   const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist,
+                   const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
+                   void* stream);
+
 /* Gather the kept circles in priority order (utils.py:195-199 output order):
  * d_out[n_planes][out_cap][3] int32 (row, col, r), d_out_scores, d_num_out[n_planes].
  * keep_all != 0 skips the state test (min_dist == 0: no suppression, utils.py:197). */
@@ -236,9 +243,10 @@ int mg_collect_circles(const int32_t* d_circles, int64_t circle_cap, const float
 
 /* circle_labels as a coverage count: d_labels[n_planes][h][w] int32 pre-set to -1;
  * beads d_beads[n_planes][bead_cap][3] (row, col, r), d_num_beads[n_planes];
- * d_halfwidths[(max_r+1)][2*max_r+1] from mg_disk_halfwidths (row r of the table). */
+ * d_halfwidths[(max_r+1)][2*max_r+1] from mg_disk_halfwidths (row r of the table).
+ * reset != 0 writes -1 back under the same disks instead (the map is clean again for reuse). */
 int mg_circle_labels(const int32_t* d_beads, int64_t bead_cap, const int32_t* d_num_beads, int n_planes, int h,
-                     int w, const int32_t* d_halfwidths, int max_r, int32_t* d_labels, void* stream);
+                     int w, const int32_t* d_halfwidths, int max_r, int32_t* d_labels, int reset, void* stream);
 
 /* ROI gather + masks + reductions for one assay.  image (C, T, h, w) of dtype (u8/u16/f32);
  * beads (m, 3) with labels from time 0; window = bounding_box(col, row, L, w, h).

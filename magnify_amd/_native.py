@@ -48,7 +48,8 @@ PROTOTYPES = {
     "mg_score_circles": [_p, _p, _l, _i, _i, _i, _p, _l, _p, _i, _i, _p, _p, _p, _i, _f, _i, _p, _p, _p, _p, _p, _p],
     "mg_nms_round": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _p],
     "mg_collect_circles": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p],
-    "mg_circle_labels": [_p, _l, _p, _i, _i, _i, _p, _i, _p, _p],
+    "mg_circle_labels": [_p, _l, _p, _i, _i, _i, _p, _i, _p, _i, _p],
+    "mg_nms_cleanup": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p],
     "mg_roi_gather_reduce": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mg_roi_gather_reduce_batched": [_p, _i, _l, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mg_roi_masked_median_u16": [_p, _p, _i, _i, _i, _i, _p, _p],

@@ -361,10 +361,15 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
   uint64_t* grid = d_grid + (int64_t)plane * grid_cap;
   for (int64_t a = (int64_t)blockIdx.x * NT + threadIdx.x; a < n; a += (int64_t)gridDim.x * NT) {
     const int idx = alive[a];
-    if (state[idx] != 0) continue;
+    if (PHASE != 2 && state[idx] != 0) continue;
     const int row = circles[3 * (int64_t)idx], col = circles[3 * (int64_t)idx + 1];
     const uint64_t key = nms_key(scores[idx], (uint32_t)idx);
-    if (PHASE == 0) {  // claim: every undecided circle bids for its ring pixels
+    if (PHASE == 2) {  // cleanup (after convergence): restore the all-ones grid under every ring
+      for (int j = 0; j < ring_len; ++j) {
+        const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
+        grid[(int64_t)rr * n_cols + cc] = ~0ull;
+      }
+    } else if (PHASE == 0) {  // claim: every undecided circle bids for its ring pixels
       for (int j = 0; j < ring_len; ++j) {
         const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
         atomicMin(reinterpret_cast<unsigned long long*>(&grid[(int64_t)rr * n_cols + cc]), (unsigned long long)key);
@@ -555,6 +560,21 @@ extern "C" int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const 
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_nms<1>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
                      min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
+                              const int32_t* d_alive, const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes,
+                              int min_dist, const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap,
+                              uint8_t* d_state, void* stream) {
+  if (!d_circles || !d_scores || !d_alive || !d_num_alive || !d_max_rc || !d_ring_rc || !d_grid || !d_state)
+    return MG_EINVAL;
+  if (n_planes < 0 || n_planes > 65535 || min_dist <= 0 || ring_len <= 0) return MG_EINVAL;
+  if (n_planes == 0 || circle_cap == 0) return MG_OK;
+  hipLaunchKernelGGL((k_nms<2>), dim3(grid_x(circle_cap), n_planes), dim3(NT), 0, mg_stream(stream), d_circles,
+                     circle_cap, d_scores, d_alive, d_num_alive, d_max_rc, min_dist, d_ring_rc, ring_len, d_grid,
+                     grid_cap, d_state, (int32_t*)nullptr);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -15,7 +15,7 @@ constexpr int NT = 256;
 __global__ __launch_bounds__(NT) void k_circle_labels(const int32_t* __restrict__ d_beads, int64_t bead_cap,
                                                       const int32_t* __restrict__ d_num_beads, int h, int w,
                                                       const int32_t* __restrict__ d_halfwidths, int max_r,
-                                                      int32_t* __restrict__ d_labels) {
+                                                      int32_t* __restrict__ d_labels, int reset) {
   const int plane = blockIdx.y;
   const int i = blockIdx.x;
   if (i >= d_num_beads[plane]) return;
@@ -31,6 +31,10 @@ __global__ __launch_bounds__(NT) void k_circle_labels(const int32_t* __restrict_
     const int y = row + dy, x = col + dx;
     if (y < 0 || y >= h || x < 0 || x >= w) continue;
     int32_t* cell = &lab[(int64_t)y * w + x];
+    if (reset) {  // restore the "nobody" value under this disk (lets the caller reuse the map)
+      *cell = -1;
+      continue;
+    }
     const int old = atomicCAS(cell, -1, i);
     if (old != -1 && old != i) *cell = -2;  // a second owner: contested
   }
@@ -304,13 +308,13 @@ int launch_roi(const void* d_image, int64_t assay_stride, int n_c, int n_t, int 
 
 extern "C" int mg_circle_labels(const int32_t* d_beads, int64_t bead_cap, const int32_t* d_num_beads, int n_planes,
                                 int h, int w, const int32_t* d_halfwidths, int max_r, int32_t* d_labels,
-                                void* stream) {
+                                int reset, void* stream) {
   if (!d_beads || !d_num_beads || !d_halfwidths || !d_labels || n_planes < 0 || n_planes > 65535 || bead_cap < 0 ||
       max_r < 0)
     return MG_EINVAL;
   if (n_planes == 0 || bead_cap == 0) return MG_OK;
   hipLaunchKernelGGL(k_circle_labels, dim3((unsigned)bead_cap, n_planes), dim3(NT), 0, mg_stream(stream), d_beads,
-                     bead_cap, d_num_beads, h, w, d_halfwidths, max_r, d_labels);
+                     bead_cap, d_num_beads, h, w, d_halfwidths, max_r, d_labels, reset);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

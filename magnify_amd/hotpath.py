@@ -273,7 +273,7 @@ class CircleFinder:
         self.hist = torch.zeros((P, COMBINED_BINS), dtype=i32, device=dev)
         self.hist_base = torch.zeros((P,), dtype=i32, device=dev)
         self.thresh = torch.zeros((P, 2), dtype=i32, device=dev)
-        self.changed = torch.zeros((P,), dtype=i32, device=dev)
+        self.changed = torch.zeros((4, P), dtype=i32, device=dev)
         tx, ty = nat.C.c_int(0), nat.C.c_int(0)
         nat.check(nat.lib().mg_hysteresis_tiles(h, w, nat.C.byref(tx), nat.C.byref(ty)), "mg_hysteresis_tiles")
         self.tile_flags = torch.zeros((2, P, ty.value, tx.value), dtype=u8, device=dev)
@@ -371,15 +371,19 @@ class CircleFinder:
         _call("mg_canny_nms", self.blur.data_ptr(), P, h, w, self.thresh.data_ptr(), self.weak_bits.data_ptr(),
               self.edge_bits.data_ptr(), self.words, s)
         sweeps = 0
+        group = 4  # sweeps per host check: a sweep after convergence only runs the tile-flag test
+        if self.changed.shape[0] != group:
+            self.changed = torch.zeros((group, P), dtype=torch.int32, device=self.dev)
         while True:
             self.changed.zero_()
-            cur = self.tile_flags[sweeps & 1]
-            cur.zero_()
-            prev = self.tile_flags[(sweeps + 1) & 1] if sweeps > 0 else None
-            _call("mg_canny_hysteresis", self.weak_bits.data_ptr(), self.edge_bits.data_ptr(), self.words, P, h, w,
-                  self.changed.data_ptr(), _ptr(prev), cur.data_ptr(), s)
-            sweeps += 1
-            if int(self.changed.sum().item()) == 0:
+            for g in range(group):
+                cur = self.tile_flags[sweeps & 1]
+                cur.zero_()
+                prev = self.tile_flags[(sweeps + 1) & 1] if sweeps > 0 else None
+                _call("mg_canny_hysteresis", self.weak_bits.data_ptr(), self.edge_bits.data_ptr(), self.words, P, h, w,
+                      self.changed[g].data_ptr(), _ptr(prev), cur.data_ptr(), s)
+                sweeps += 1
+            if int(self.changed[group - 1].sum().item()) == 0:
                 break
         self.stats["hysteresis_sweeps"] = sweeps
         if self.keep_debug_maps:
@@ -432,19 +436,22 @@ class CircleFinder:
             grid_cap = (self.h + self.max_r + 2 * pad) * (self.w + self.max_r + 2 * pad)
             if self.nms_grid is None or self.nms_grid.shape[1] < grid_cap:
                 self.nms_grid = torch.empty((P, grid_cap), dtype=torch.int64, device=self.dev)
-            self.nms_grid.fill_(-1)
+                self.nms_grid.fill_(-1)  # once: every call restores the cells it touched (mg_nms_cleanup)
             self.state.zero_()
             ring = torch.from_numpy(nat.circle_points(min_dist, True)).to(self.dev)
+            group = 2  # rounds per host check (a round with nothing undecided does no work)
             while True:
-                _call("mg_nms_round", self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
-                                         self.alive.data_ptr(), self.num_alive.data_ptr(), self.max_rc.data_ptr(), P,
-                                         min_dist, ring.data_ptr(), ring.shape[0], self.nms_grid.data_ptr(),
-                                         self.nms_grid.shape[1], self.state.data_ptr(), self.undecided.data_ptr(), s)
-                rounds += 1
+                for _ in range(group):
+                    _call("mg_nms_round", self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
+                          self.alive.data_ptr(), self.num_alive.data_ptr(), self.max_rc.data_ptr(), P,
+                          min_dist, ring.data_ptr(), ring.shape[0], self.nms_grid.data_ptr(),
+                          self.nms_grid.shape[1], self.state.data_ptr(), self.undecided.data_ptr(), s)
+                    rounds += 1
                 if int(self.undecided.sum().item()) == 0:
                     break
                 if rounds > 10000:
                     raise RuntimeError("greedy suppression did not converge")
+            self._nms_ring, self._nms_dist = ring, min_dist
         self.stats["nms_rounds"] = rounds
         out = torch.empty((P, out_cap, 3), dtype=torch.int32, device=self.dev)
         out_scores = torch.empty((P, out_cap), dtype=torch.float32, device=self.dev)
@@ -454,6 +461,10 @@ class CircleFinder:
                                        self.num_alive.data_ptr(), self.state.data_ptr(), int(min_dist <= 0), P,
                                        out.data_ptr(), out_scores.data_ptr(), out_cap, num_out.data_ptr(),
                                        scratch.data_ptr(), s)
+        if rounds:
+            _call("mg_nms_cleanup", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
+                  self.num_alive.data_ptr(), self.max_rc.data_ptr(), P, min_dist, self._nms_ring.data_ptr(),
+                  self._nms_ring.shape[0], self.nms_grid.data_ptr(), self.nms_grid.shape[1], self.state.data_ptr(), s)
         return out, out_scores, num_out
 
     def find(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw=False, keep_u8=False,
@@ -506,9 +517,14 @@ def _halfwidth_table(max_r: int, device):
     return _HALF_CACHE[key]
 
 
-def circle_labels(beads_per_assay, h, w, device="cuda"):
+_LABEL_POOL = {}
+
+
+def circle_labels(beads_per_assay, h, w, device="cuda", reuse=False):
     """utils.circle_labels (utils.py:380-395) for a list of (M_a, 3) int bead arrays.
-    Returns labels (A, h, w) int32 on the device."""
+    Returns labels (A, h, w) int32 on the device.  ``reuse=True`` hands out a pooled map that must
+    be given back with ``release_labels`` (which restores -1 under the disks instead of clearing
+    the whole map)."""
     require_gpu()
     a = len(beads_per_assay)
     cap = max(1, max((len(b) for b in beads_per_assay), default=1))
@@ -521,13 +537,26 @@ def circle_labels(beads_per_assay, h, w, device="cuda"):
         counts[k] = len(b)
         if len(b):
             max_r = max(max_r, int(b[:, 2].max()))
-    labels = torch.full((a, h, w), -1, dtype=torch.int32, device=device)
+    key = (a, h, w, str(device))
+    if reuse and key in _LABEL_POOL:
+        labels = _LABEL_POOL.pop(key)
+    else:
+        labels = torch.full((a, h, w), -1, dtype=torch.int32, device=device)
     d_beads = torch.from_numpy(host).to(device)
     d_counts = torch.from_numpy(counts).to(device)
     tab = _halfwidth_table(max_r, device)
     _call("mg_circle_labels", d_beads.data_ptr(), cap, d_counts.data_ptr(), a, h, w, tab.data_ptr(), max_r,
-                                         labels.data_ptr(), _stream())
+          labels.data_ptr(), 0, _stream())
+    labels._mg_state = (d_beads, cap, d_counts, a, h, w, tab, max_r, key)
     return labels
+
+
+def release_labels(labels):
+    """Give a label map back to the pool: -1 is restored under the disks that were drawn."""
+    d_beads, cap, d_counts, a, h, w, tab, max_r, key = labels._mg_state
+    _call("mg_circle_labels", d_beads.data_ptr(), cap, d_counts.data_ptr(), a, h, w, tab.data_ptr(), max_r,
+          labels.data_ptr(), 1, _stream(), stage="mg_circle_labels_reset")
+    _LABEL_POOL[key] = labels
 
 
 def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, labels: torch.Tensor | None,

@@ -78,12 +78,14 @@ class StackProcessor:
     def segment_reduce(self, beads, want_roi=True):
         """Labels, fg/bg masks, ROI gather and masked sums for every marker."""
         T, C, h, w = self.T, self.C, self.h, self.w
-        labels = hp.circle_labels(beads, h, w, device=self.dev)
+        labels = hp.circle_labels(beads, h, w, device=self.dev, reuse=True)
         if self.mode == "P":
             images = self.image.view(T, C, 1, h, w)
         else:
             images = self.image.permute(1, 0, 2, 3).contiguous().view(1, C, T, h, w)
-        return hp.roi_gather_reduce(images, beads, self.L, labels, want_roi=want_roi, reuse_buffers=True)
+        out = hp.roi_gather_reduce(images, beads, self.L, labels, want_roi=want_roi, reuse_buffers=True)
+        hp.release_labels(labels)
+        return out
 
     def __call__(self, stack, flatfield=1.0, darkfield=0.0, seed=0, want_roi=True):
         self.flatfield(stack, flatfield, darkfield)
