@@ -369,6 +369,7 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
         const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
         grid[(int64_t)rr * n_cols + cc] = ~0ull;
       }
+      state[idx] = 0;
     } else if (PHASE == 0) {  // claim: every undecided circle bids for its ring pixels
       for (int j = 0; j < ring_len; ++j) {
         const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);

@@ -71,6 +71,19 @@ __device__ __forceinline__ double cast_trunc<double>(double v) {
   return v;
 }
 
+template <typename T>
+struct IsIntegral {
+  static constexpr bool value = false;
+};
+template <>
+struct IsIntegral<uint8_t> {
+  static constexpr bool value = true;
+};
+template <>
+struct IsIntegral<uint16_t> {
+  static constexpr bool value = true;
+};
+
 __device__ __forceinline__ void block_atomic_max2(double m1, double m2, double* out) {
   __shared__ double s1[16], s2[16];
   m1 = mg_wave_nanmax(m1);
@@ -186,6 +199,61 @@ __global__ __launch_bounds__(256) void k_flatfield_max(const T* __restrict__ til
   block_atomic_max2(m1, m2, out);
 }
 
+// Fast path of pass 1 for integer pixels, scalar dark and a float32 flat image: the test "can this
+// pixel beat the running maximum of t / flat?" runs in float32 (reciprocal + multiply, error
+// < 1e-6 relative against a 1e-5 margin); only pixels that pass pay for the exact float64 division,
+// so the result is still the exact maximum of the exact quotients.  M1 comes from the integer max.
+template <typename T>
+__global__ __launch_bounds__(256) void k_flatfield_max_fast(const T* __restrict__ tiles, int64_t tiles_per_group,
+                                                             int64_t tile_elems, double dark,
+                                                             const float* __restrict__ d_flat,
+                                                             double* __restrict__ out) {
+  constexpr int N = VecOf<T>::N;
+  const int group = blockIdx.y;
+  tiles += (int64_t)group * tiles_per_group * tile_elems;
+  out += 2 * group;
+  const float dk_f = (float)dark;
+  uint32_t xmax = 0;
+  bool any = false;
+  double m2 = -INFINITY;
+  float thr = -INFINITY;
+  const int64_t nvec = tile_elems / N;  // the launcher guarantees tile_elems % N == 0
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+    float fl[N], rc[N];
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+      const float4 f = reinterpret_cast<const float4*>(d_flat + v * N)[q];
+      fl[4 * q] = f.x, fl[4 * q + 1] = f.y, fl[4 * q + 2] = f.z, fl[4 * q + 3] = f.w;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) rc[j] = __builtin_amdgcn_rcpf(fl[j]);
+    any = true;
+    for (int64_t g = 0; g < tiles_per_group; ++g) {
+      T x[N];
+      load_vec<T, N>(tiles + g * tile_elems + v * N, x);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const uint32_t xi = (uint32_t)x[j];
+        xmax = max(xmax, xi);
+        const float t_f = fmaxf((float)xi - dk_f, 0.0f);
+        const bool in_range = fl[j] > 1e-30f && fl[j] < 1e30f;
+        if (in_range && t_f * rc[j] <= thr) continue;  // provably below the running maximum
+        double t = (double)xi - dark;
+        t = t < 0.0 ? 0.0 : t;
+        m2 = mg_nanmax(m2, t / (double)fl[j]);
+        thr = (m2 == m2 && m2 < 1e30) ? (float)m2 * (1.0f - 1e-5f) : -INFINITY;
+      }
+    }
+  }
+  double m1 = -INFINITY;
+  if (any) {
+    m1 = (double)xmax - dark;
+    m1 = m1 < 0.0 ? 0.0 : m1;
+  }
+  block_atomic_max2(m1, m2, out);
+}
+
 // ---- pass 2: apply + stitch (+ output min/max) ----------------------------------------
 constexpr int ROWS_PER_BLOCK = 32;
 
@@ -193,19 +261,6 @@ constexpr int ROWS_PER_BLOCK = 32;
 // v = t * rcp(fl) * (m1 / m2) with a Newton-refined reciprocal agrees with the reference's three
 // roundings to ~1e-15 relative, so the truncation is the same unless v lies within 1e-6 of an
 // integer -- those (rare) pixels take the exact path.
-template <typename T>
-struct IsIntegral {
-  static constexpr bool value = false;
-};
-template <>
-struct IsIntegral<uint8_t> {
-  static constexpr bool value = true;
-};
-template <>
-struct IsIntegral<uint16_t> {
-  static constexpr bool value = true;
-};
-
 template <typename T>
 __device__ __forceinline__ T correct_pixel(double t, double fl, double m1, double m2, double k, bool fast_ok) {
   if (IsIntegral<T>::value && fast_ok && flat_in_range(fl)) {
@@ -409,6 +464,14 @@ int launch_max(const void* d_tiles, int64_t tiles_per_group, int n_groups, int64
   const int64_t nvec = tile_elems / VecOf<T>::N + 1;
   const int per_group = std::max(1, 4096 / n_groups);
   int blocks = (int)std::min<int64_t>((nvec + 255) / 256, per_group);
+  if (IsIntegral<T>::value && !d_dark && d_flat && flat_dt == MG_F32 && tile_elems % VecOf<T>::N == 0 &&
+      (reinterpret_cast<uintptr_t>(d_flat) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_tiles) & 15) == 0 &&
+      fabs(dark) < 16777216.0 && (double)(float)dark == dark) {
+    hipLaunchKernelGGL((k_flatfield_max_fast<T>), dim3(blocks, n_groups), dim3(256), 0, s, (const T*)d_tiles,
+                       tiles_per_group, tile_elems, dark, (const float*)d_flat, d_max2);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+  }
   hipLaunchKernelGGL((k_flatfield_max<T>), dim3(blocks, n_groups), dim3(256), 0, s, (const T*)d_tiles, tiles_per_group,
                      tile_elems, dark, d_dark, dark_dt, flat, d_flat, flat_dt, d_max2);
   MG_CHECK_LAUNCH();

@@ -437,7 +437,7 @@ class CircleFinder:
             if self.nms_grid is None or self.nms_grid.shape[1] < grid_cap:
                 self.nms_grid = torch.empty((P, grid_cap), dtype=torch.int64, device=self.dev)
                 self.nms_grid.fill_(-1)  # once: every call restores the cells it touched (mg_nms_cleanup)
-            self.state.zero_()
+                self.state.zero_()
             ring = torch.from_numpy(nat.circle_points(min_dist, True)).to(self.dev)
             group = 2  # rounds per host check (a round with nothing undecided does no work)
             while True:
