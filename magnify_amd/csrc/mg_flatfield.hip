@@ -261,13 +261,24 @@ constexpr int ROWS_PER_BLOCK = 32;
 // v = t * rcp(fl) * (m1 / m2) with a Newton-refined reciprocal agrees with the reference's three
 // roundings to ~1e-15 relative, so the truncation is the same unless v lies within 1e-6 of an
 // integer -- those (rare) pixels take the exact path.
+// Newton-refined reciprocal of a flat-field value (float32 seed, two steps in float64: ~1e-16).
+// Returns 0 when the value is outside the range in which the fast path is valid.
+__device__ __forceinline__ double refined_rcp(double fl) {
+  if (!flat_in_range(fl)) return 0.0;
+  double r = (double)__builtin_amdgcn_rcpf((float)fl);
+  r = r * (2.0 - fl * r);
+  r = r * (2.0 - fl * r);
+  return r;
+}
+
+// out = trunc(((t / fl) * m1) / m2) for an integer output type.  With r = refined_rcp(fl) != 0 and
+// k = m1 / m2, v = t * r * k agrees with the reference's three roundings to ~1e-15 relative, so the
+// truncation is the same unless v lies within 1e-6 of an integer -- those (rare) pixels, and every
+// non-integer output type, take the exact two-division path.
 template <typename T>
-__device__ __forceinline__ T correct_pixel(double t, double fl, double m1, double m2, double k, bool fast_ok) {
-  if (IsIntegral<T>::value && fast_ok && flat_in_range(fl)) {
+__device__ __forceinline__ T correct_pixel(double t, double fl, double r, double m1, double m2, double k, bool fast_ok) {
+  if (IsIntegral<T>::value && fast_ok && r != 0.0) {
     if (t == 0.0) return (T)0;  // 0 / fl * m1 / m2 == 0 exactly (m1, m2 finite and positive here)
-    double r = (double)__builtin_amdgcn_rcpf((float)fl);
-    r = r * (2.0 - fl * r);
-    r = r * (2.0 - fl * r);
     const double v = t * r * k;
     const double fv = floor(v);
     const double fr = v - fv;
@@ -310,8 +321,9 @@ __global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tile
     }
   }
   double vmin[PB], vmax[PB];
+  uint32_t imin[PB], imax[PB];  // integer outputs: min/max in integer registers
 #pragma unroll
-  for (int b = 0; b < PB; ++b) vmin[b] = INFINITY, vmax[b] = -INFINITY;
+  for (int b = 0; b < PB; ++b) vmin[b] = INFINITY, vmax[b] = -INFINITY, imin[b] = 0xFFFFFFFFu, imax[b] = 0u;
   const int64_t tile_elems = (int64_t)ty * tx;
   const int row_end = min((int)(blockIdx.y + 1) * ROWS_PER_BLOCK, h_out);
   if (ox0 < w_out) {
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tile
         pix[j] = (int64_t)y * tx + xx;
         toff[j] = ((int64_t)tr * n_tc + tc) * tile_elems;
       }
-      double dk[N], fl[N];
+      double dk[N], fl[N], rr[N];
       if (APPLY) {
         if (one_tile) {
           load_field<N>(d_dark, dark_dt, pix[0], dark, dk);
@@ -343,6 +355,9 @@ __global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tile
             fl[j] = d_flat ? mg_load_f64(d_flat, flat_dt, pix[j]) : flat;
           }
         }
+        // the refined reciprocal of flat is shared by all planes of the block
+#pragma unroll
+        for (int j = 0; j < N; ++j) rr[j] = IsIntegral<T>::value ? refined_rcp(fl[j]) : 0.0;
       }
 #pragma unroll
       for (int b = 0; b < PB; ++b) {
@@ -360,14 +375,19 @@ __global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tile
           if (APPLY) {
             double t = (double)x[j] - dk[j];
             t = t < 0.0 ? 0.0 : t;
-            o[j] = correct_pixel<T>(t, fl[j], m1[b], m2[b], kk[b], fast_ok[b]);
+            o[j] = correct_pixel<T>(t, fl[j], rr[j], m1[b], m2[b], kk[b], fast_ok[b]);
           } else {
             o[j] = x[j];
           }
           if (d_minmax && j < cnt) {
-            const double ov = (double)o[j];
-            vmin[b] = IsIntegral<T>::value ? fmin(vmin[b], ov) : mg_nanmin(vmin[b], ov);
-            vmax[b] = IsIntegral<T>::value ? fmax(vmax[b], ov) : mg_nanmax(vmax[b], ov);
+            if (IsIntegral<T>::value) {
+              imin[b] = min(imin[b], (uint32_t)o[j]);
+              imax[b] = max(imax[b], (uint32_t)o[j]);
+            } else {
+              const double ov = (double)o[j];
+              vmin[b] = mg_nanmin(vmin[b], ov);
+              vmax[b] = mg_nanmax(vmax[b], ov);
+            }
           }
         }
         T* dst = image + ((int64_t)(plane0 + b) * h_out + oy) * w_out + ox0;
@@ -384,6 +404,7 @@ __global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
+      if (IsIntegral<T>::value && imin[b] <= imax[b]) vmin[b] = (double)imin[b], vmax[b] = (double)imax[b];
       const double a = mg_wave_nanmin(vmin[b]), c = mg_wave_nanmax(vmax[b]);
       if (lane == 0) {
         smin[b][wave] = a;
