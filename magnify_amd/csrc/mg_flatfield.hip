@@ -427,6 +427,98 @@ __global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tile
   }
 }
 
+// Lean variant for the aligned case (hx % N == 0 and aligned bases: every N-pixel chunk lies
+// inside one tile and all accesses are 16-byte vectors); integer pixel types only.
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void k_apply_stitch_aligned(const T* __restrict__ tiles, int n_planes, int n_tr,
+                                                               int n_tc, int ty, int tx, int clip, int hy, int hx,
+                                                               int planes_per_group, double dark,
+                                                               const void* __restrict__ d_dark, int dark_dt,
+                                                               double flat, const void* __restrict__ d_flat,
+                                                               int flat_dt, const double* __restrict__ d_max2,
+                                                               T* __restrict__ image, double* __restrict__ d_minmax) {
+  constexpr int N = VecOf<T>::N;
+  constexpr int PB = PLANES_PER_BLOCK;
+  const int plane0 = blockIdx.z * PB;
+  const int np = min(PB, n_planes - plane0);
+  const int h_out = n_tr * hy, w_out = n_tc * hx;
+  const int ox0 = (blockIdx.x * blockDim.x + threadIdx.x) * N;
+  uint32_t imin[PB], imax[PB];
+#pragma unroll
+  for (int b = 0; b < PB; ++b) imin[b] = 0xFFFFFFFFu, imax[b] = 0u;
+  const int64_t tile_elems = (int64_t)ty * tx, plane_elems = (int64_t)n_tr * n_tc * tile_elems;
+  const int row_end = min((int)(blockIdx.y + 1) * ROWS_PER_BLOCK, h_out);
+  if (ox0 < w_out) {
+    const int tc0 = ox0 / hx;
+    const int x0 = ox0 - tc0 * hx + clip;
+    for (int oy = blockIdx.y * ROWS_PER_BLOCK; oy < row_end; ++oy) {
+      const int tr = oy / hy;
+      const int64_t p0 = (int64_t)(oy - tr * hy + clip) * tx + x0;
+      const int64_t src0 = ((int64_t)tr * n_tc + tc0) * tile_elems + p0;
+      double dk[N], fl[N], rr[N];
+      if (APPLY) {
+        load_field<N>(d_dark, dark_dt, p0, dark, dk);
+        load_field<N>(d_flat, flat_dt, p0, flat, fl);
+#pragma unroll
+        for (int j = 0; j < N; ++j) rr[j] = refined_rcp(fl[j]);
+      }
+#pragma unroll
+      for (int b = 0; b < PB; ++b) {
+        if (b >= np) break;
+        T x[N], o[N];
+        load_vec<T, N>(tiles + (int64_t)(plane0 + b) * plane_elems + src0, x);
+        if (APPLY) {
+          const int group = (plane0 + b) / planes_per_group;
+          const double m1 = d_max2[2 * group], m2 = d_max2[2 * group + 1];
+          const double kk = m1 / m2;
+          const bool ok = kk > 0.0 && kk < 1e30 && m1 > 0.0 && m1 < 1e300 && m2 > 0.0 && m2 < 1e300;
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            double t = (double)x[j] - dk[j];
+            t = t < 0.0 ? 0.0 : t;
+            o[j] = correct_pixel<T>(t, fl[j], rr[j], m1, m2, kk, ok);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < N; ++j) o[j] = x[j];
+        }
+        if (d_minmax) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            imin[b] = min(imin[b], (uint32_t)o[j]);
+            imax[b] = max(imax[b], (uint32_t)o[j]);
+          }
+        }
+        store_vec<T, N>(image + ((int64_t)(plane0 + b) * h_out + oy) * w_out + ox0, o);
+      }
+    }
+  }
+  if (d_minmax) {
+    __shared__ uint32_t smin[PB][4], smax[PB][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      uint32_t a = imin[b], c = imax[b];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        a = min(a, (uint32_t)__shfl_xor((int)a, off));
+        c = max(c, (uint32_t)__shfl_xor((int)c, off));
+      }
+      if (lane == 0) smin[b][wave] = a, smax[b][wave] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < np) {
+      const int b = threadIdx.x;
+      const uint32_t a = min(min(smin[b][0], smin[b][1]), min(smin[b][2], smin[b][3]));
+      const uint32_t c = max(max(smax[b][0], smax[b][1]), max(smax[b][2], smax[b][3]));
+      if (a <= c) {
+        mg_atomic_nanmin(d_minmax + 2 * (plane0 + b), (double)a);
+        mg_atomic_nanmax(d_minmax + 2 * (plane0 + b) + 1, (double)c);
+      }
+    }
+  }
+}
+
 // ---- per-plane min/max of strided planes ------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_plane_minmax(const T* __restrict__ src, int64_t plane_stride, int h, int w,
@@ -512,6 +604,22 @@ int launch_apply(const void* d_tiles, int64_t n_planes, int n_tr, int n_tc, int 
   dim3 grid((w_out + 256 * N - 1) / (256 * N), (h_out + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK,
             (unsigned)((n_planes + PLANES_PER_BLOCK - 1) / PLANES_PER_BLOCK));
   if (grid.y > 65535 || grid.z > 65535) return MG_EINVAL;
+  const bool aligned = IsIntegral<T>::value && hx % N == 0 && tx % N == 0 && clip % N == 0 &&
+                       (reinterpret_cast<uintptr_t>(d_tiles) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_image) & 15) == 0 &&
+                       (!d_flat || (reinterpret_cast<uintptr_t>(d_flat) & 15) == 0) &&
+                       (!d_dark || (reinterpret_cast<uintptr_t>(d_dark) & 15) == 0);
+  if (aligned) {
+    if (apply)
+      hipLaunchKernelGGL((k_apply_stitch_aligned<T, true>), grid, dim3(256), 0, s, (const T*)d_tiles, (int)n_planes, n_tr,
+                         n_tc, ty, tx, clip, hy, hx, planes_per_group, dark, d_dark, dark_dt, flat, d_flat, flat_dt,
+                         d_max2, (T*)d_image, d_minmax);
+    else
+      hipLaunchKernelGGL((k_apply_stitch_aligned<T, false>), grid, dim3(256), 0, s, (const T*)d_tiles, (int)n_planes, n_tr,
+                         n_tc, ty, tx, clip, hy, hx, planes_per_group, dark, d_dark, dark_dt, flat, d_flat, flat_dt,
+                         d_max2, (T*)d_image, d_minmax);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+  }
   if (apply)
     hipLaunchKernelGGL((k_apply_stitch<T, true>), grid, dim3(256), 0, s, (const T*)d_tiles, (int)n_planes, n_tr, n_tc,
                        ty, tx, clip, hy, hx, planes_per_group, dark, d_dark, dark_dt, flat, d_flat, flat_dt, d_max2,
