@@ -145,7 +145,7 @@ def find_beads(image: np.ndarray, min_bead_diameter, max_bead_diameter, low_edge
     return out
 
 
-def roi_reduce(roi: np.ndarray, fg: np.ndarray, bg: np.ndarray):
+def roi_reduce(roi: np.ndarray, fg: np.ndarray, bg: np.ndarray, medians: bool = True):
     """The ROI reductions of README.md:21-22, identify.py:76-80, filter.py:21-22.
 
     roi (M,C,T,L,L), masks (M,T,L,L).  Integer sums and counts are exact;
@@ -164,6 +164,8 @@ def roi_reduce(roi: np.ndarray, fg: np.ndarray, bg: np.ndarray):
     with np.errstate(invalid="ignore", divide="ignore"):
         res["fg_mean"] = res["fg_sum"] / res["fg_count"][:, None].astype(np.float64)
         res["bg_mean"] = res["bg_sum"] / res["bg_count"][:, None].astype(np.float64)
+    if not medians:
+        return res
     import warnings
 
     with warnings.catch_warnings():
