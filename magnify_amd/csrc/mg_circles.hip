@@ -221,18 +221,21 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
   const int64_t first = lo[(int64_t)tile * nr];
   const int64_t last = min((int64_t)lo[(int64_t)(tile + 1) * nr], circle_cap);
   if (first >= last) return;
-  const int side = TS + 2 * max_r, wpr = (side + 31) >> 5;
+  const int side = TS + 2 * max_r;
+  int wsh = 0;
+  while ((32 << wsh) < side) ++wsh;  // words per window row, rounded up to a power of two
+  const int wpr = 1 << wsh;
   uint32_t* win = lds;                                    // [side][wpr]
   int32_t* tab = reinterpret_cast<int32_t*>(lds + side * wpr);  // packed (dr << 16) | (dc & 0xFFFF)
   int32_t* list = tab + per_total;                        // [CHUNK]
   const int wy0 = (tile / ntc) * TS - 2 * max_r, wx0 = (tile % ntc) * TS - 2 * max_r;
   const uint32_t* bits = d_bits + plane * words_per_plane;
   for (int i = threadIdx.x; i < side * wpr; i += NT) {
-    const int j = i / wpr, k = i - j * wpr;
+    const int j = i >> wsh, k = i & (wpr - 1);
     const int y = wy0 + j, xs = wx0 + 32 * k;
     uint32_t v = 0;
     if (y >= 0 && y < h) {
-      const int x_lo = max(xs, 0), x_hi = min(xs + 32, w);
+      const int x_lo = max(xs, 0), x_hi = min(min(xs + 32, wx0 + side), w);
       if (x_lo < x_hi) v = bits_at(bits, (int64_t)y * w + x_lo, x_hi - x_lo) << (x_lo - xs);
     }
     win[i] = v;
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
       // need: hits >= min_roundness * len - 1e-3 (margin far above any rounding of the real sum)
       const int need = (int)ceil((double)min_roundness * len - 1e-3);
       const int by = row - wy0, bx = col - wx0;
-#define MG_BIT(yy, xx) ((win[(by + (yy)) * wpr + ((bx + (xx)) >> 5)] >> ((bx + (xx)) & 31)) & 1u)
+#define MG_BIT(yy, xx) ((win[((by + (yy)) << wsh) + ((bx + (xx)) >> 5)] >> ((bx + (xx)) & 31)) & 1u)
       // The midpoint circle is emitted as 4 axis points, groups of 8 symmetric points sharing one
       // (x, y), and possibly 4 diagonal points (utils.py:441-464): one table read per group.
       int hits = MG_BIT(0, -rad) + MG_BIT(-rad, 0) + MG_BIT(0, rad) + MG_BIT(rad, 0);
@@ -294,14 +297,15 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
         for (int j = 0; j < cnt; ++j) {
           const int v = tab[base + j];
           const int y = by + (v >> 16), x = bx + (int)(int16_t)(v & 0xFFFF);
-          mask |= ((win[y * wpr + (x >> 5)] >> (x & 31)) & 1u) << j;
+          mask |= ((win[(y << wsh) + (x >> 5)] >> (x & 31)) & 1u) << j;
         }
         while (mask) {
           const int j = __ffs(mask) - 1;
           mask &= mask - 1;
           const int p = base + j;
           const int v = tab[p];
-          const float an = ang[(int64_t)(row + (v >> 16)) * w + (col + (int)(int16_t)(v & 0xFFFF))];
+          // hits lie inside the image: 24-bit multiply (h, w < 2^24 guaranteed by the launcher)
+          const float an = ang[(int64_t)(__umul24(row + (v >> 16), w) + (col + (int)(int16_t)(v & 0xFFFF)))];
           double d = fabs((double)an - d_per_expected[p]);
           if (d > PI) d = d - PI;
           // x / pi, correctly rounded without the division (Markstein: y = RN(1/pi), q0 = RN(x y),
@@ -526,7 +530,10 @@ extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bit
   int64_t n_layers, words;
   if (mg_dedup_layout(h, w, min_r, max_r, &ntr, &ntc, &n_layers, &words) != MG_OK) return MG_EINVAL;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
-  const int side = TS + 2 * max_r, wpr = (side + 31) >> 5;
+  const int side = TS + 2 * max_r;
+  int wpr = 1;
+  while (32 * wpr < side) wpr <<= 1;
+  if (h >= (1 << 24) || w >= (1 << 24) || (int64_t)h * w >= (1LL << 31)) return MG_EINVAL;
   const size_t lds_bytes = ((size_t)side * wpr + per_total + CHUNK) * 4;
   if (lds_bytes > 150 * 1024) return MG_EINVAL;  // radii beyond ~300 px: outside this build's envelope
   static bool attr_set = false;
