@@ -24,21 +24,22 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 
 
 def algorithmic_bytes(stage, p):
-    """Algorithmic HBM bytes of ONE launch of a stage (DESIGN.md 'Kernels'); p = workload numbers."""
+    """Algorithmic HBM bytes of a stage PER STEP, summed over its launches (DESIGN.md 'Kernels');
+    p = workload numbers of the step.  A launch's share is this divided by the launches per step."""
     n, planes, c = p["h"] * p["w"], p["search_planes"], p["n_c"]
     table = {
-        "mg_flatfield_max": 2 * c * n * p["n_t"],            # read u16, whole stack in one launch
+        "mg_flatfield_max": 2 * c * n * p["n_t"],            # read u16, whole stack
         "mg_flatfield_apply_stitch": 4 * c * n * p["n_t"],   # read u16 + write u16
         "mg_to_uint8_blur": 3 * planes * n,                 # read u16, write blurred u8
-        "mg_scharr_hist": 1 * planes * n,                   # read u8
+        "mg_scharr_hist": 1 * planes * n * p["hist_passes"],  # read u8
         "mg_canny_nms": (1 + 2 / 8) * planes * n,           # read u8, write weak + strong bitmaps
-        "mg_canny_hysteresis": (3 / 8) * planes * n,        # read weak + strong bits, write strong (per sweep)
+        "mg_canny_hysteresis": (3 / 8) * planes * n * p["sweeps"],  # weak + strong bits in, strong out, per sweep
         "mg_edge_angles": p["edges"] * (8 + 9 + 4),          # coordinate, 3x3 blurred neighbourhood, angle
-        "mg_edge_grid": planes * n / 8 + 8 * p["edges"],    # read bitmap (twice: count, fill), write coords
+        "mg_edge_grid": 2 * planes * n / 8 + 8 * p["edges"],  # bitmap twice (count, fill), write coords
         "mg_candidate_circles": 28 * planes * p["num_iter"],  # 3 coordinate reads (8 B) + bitmap word
         "mg_bitmap_to_circles": 2 * 4 * p["bitmap_words"] * planes + 12 * p["unique"],  # bitmap read twice + list
         "mg_score_circles": p["unique"] * (12 + p["mean_perimeter"] / 8 + 4),  # circle + perimeter edge bits + score
-        "mg_nms_round": p["alive"] * p["ring_len"] * 16,
+        "mg_nms_round": p["alive"] * p["ring_len"] * 16 * p["nms_rounds"],
         "mg_collect_circles": p["alive"] * 4 + p["markers"] * 16,
         "mg_circle_labels": p["markers"] * p["mean_disk"] * 8,
         "mg_roi_gather_reduce_batched": p["markers"] * p["L"] ** 2 * (4 * c + 6),
@@ -85,6 +86,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--num-iter", type=int, default=5_000_000)
     ap.add_argument("--plane-batch", type=int, default=0, help="searched planes per kernel batch (0 = all)")
+    ap.add_argument("--streams", type=int, default=4, help="detection sub-batches on separate HIP streams")
     ap.add_argument("--cpu-size", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -108,7 +110,8 @@ def main():
     flat_np = vignette((S, S))
     flat = torch.from_numpy(flat_np).to(dev)
     proc = StackProcessor(T, C, S, S, num_iter=args.num_iter, min_bead_diameter=10, max_bead_diameter=50,
-                          search_channels=(0,), mode="P", plane_batch=args.plane_batch or None, device=dev)
+                          search_channels=(0,), mode="P", plane_batch=args.plane_batch or None, device=dev,
+                          n_streams=args.streams)
 
     def step(seed):
         out = proc(stack, flat, 100.0, seed=seed)
@@ -147,38 +150,44 @@ def main():
     if rank == 0:
         # workload numbers for the algorithmic-byte table (last step, rank 0)
         f = proc.finder
-        unique = int(f.num_circles.sum().item())
-        alive = int(f.num_alive.sum().item())
+        finders = getattr(proc, "finders", [f]) if proc.n_streams > 1 else [f]
+        unique = int(sum(x.num_circles.sum().item() for x in finders))
+        alive = int(sum(x.num_alive.sum().item() for x in finders))
         per_starts = f.per_starts.cpu().numpy()
         mean_perimeter = float(np.mean(np.diff(per_starts)))
-        p = {"h": S, "w": S, "n_c": C, "n_t": T, "search_planes": f.P, "num_iter": args.num_iter,
-             "edges": int(f.n_edges_host.sum()), "bitmap_words": f.bitmap_words, "unique": unique, "alive": alive,
+        p = {"h": S, "w": S, "n_c": C, "n_t": T, "search_planes": sum(x.P for x in finders), "num_iter": args.num_iter,
+             "hist_passes": max(x.stats.get("hist_passes", 1) for x in finders),
+             "sweeps": max(x.stats.get("hysteresis_sweeps", 1) for x in finders),
+             "nms_rounds": max(x.stats.get("nms_rounds", 1) for x in finders),
+             "edges": int(sum(x.n_edges_host.sum() for x in finders)), "bitmap_words": f.bitmap_words, "unique": unique, "alive": alive,
              "mean_perimeter": mean_perimeter, "ring_len": len(hp.nat.circle_points(proc.min_r, True)),
              "markers": markers_local, "mean_disk": 600, "L": proc.L}
         total_ms = sum(v[0] for v in stages.values())
         breakdown = {k: {"ms_total": round(v[0], 3), "launches": v[1], "ms_avg": round(v[0] / v[1], 4)}
                      for k, v in sorted(stages.items(), key=lambda kv: -kv[1][0])}
         dom, (dom_ms, dom_n) = max(stages.items(), key=lambda kv: kv[1][0])
-        ab = algorithmic_bytes(dom, p)
-        avg_s = dom_ms / dom_n / 1e3
+        ab_step = algorithmic_bytes(dom, p)                  # bytes per step, all launches of the stage
+        launches_per_step = dom_n / args.steps
+        ab = ab_step / launches_per_step if ab_step else None  # bytes of one launch
+        avg_s = dom_ms / dom_n / 1e3                          # average duration of one launch
         achieved = ab / avg_s / 1e9 if ab else None
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
             if (T, C, S, args.num_iter) == (64, 4, 4096, 5_000_000) and dom in pmc["stages"]:
-                traffic = pmc["stages"][dom]["hbm_bytes_per_step"] / (dom_n / args.steps)
+                traffic = pmc["stages"][dom]["hbm_bytes_per_step"] / launches_per_step
         except (OSError, KeyError, ValueError):
             traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                     "algorithmic_bytes_per_launch": ab, "avg_launch_ms": dom_ms / dom_n,
-                    "share_of_kernel_time": dom_ms / total_ms}
+                    "launches_per_step": launches_per_step, "share_of_kernel_time": dom_ms / total_ms}
         # the streaming part alone (everything that is not RANSAC scoring / suppression)
         stream_stages = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_to_uint8_blur", "mg_scharr_hist",
                          "mg_canny_nms", "mg_canny_hysteresis", "mg_edge_grid", "mg_edge_angles", "mg_circle_labels",
                          "mg_roi_gather_reduce_batched"]
         stream_ms = sum(stages[s][0] for s in stream_stages if s in stages) / args.steps
-        n_all, n_s = T * C * S * S, f.P * S * S
+        n_all, n_s = T * C * S * S, sum(x.P for x in finders) * S * S
         stream_bytes = 6 * n_all + 12 * n_s + markers_local * proc.L**2 * (4 * C + 6)
         result = {
             "metric": "megapixels/sec through flatfield+segment+ROI-reduce; markers/sec",
@@ -195,9 +204,10 @@ def main():
                                "achieved_GBs": stream_bytes / (stream_ms / 1e3) / 1e9 if stream_ms else None,
                                "frac_of_peak": stream_bytes / (stream_ms / 1e3) / 1e9 / HBM_PEAK_GBS if stream_ms else None},
             "stages": breakdown,
-            "stats": {"unique_circles": unique, "scored_exactly": int(f.num_scored.sum().item()),
+            "stats": {"unique_circles": unique, "scored_exactly": int(sum(x.num_scored.sum().item() for x in finders)),
+                      "streams": proc.n_streams,
                       "alive_circles": alive, "edges": p["edges"],
-                      "hysteresis_sweeps": f.stats.get("hysteresis_sweeps"), "nms_rounds": f.stats.get("nms_rounds"),
+                      "hysteresis_sweeps": p["sweeps"], "nms_rounds": p["nms_rounds"],
                       "kernel_ms_per_step": total_ms / args.steps},
         }
         if not args.no_cpu and world == 1:

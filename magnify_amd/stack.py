@@ -24,7 +24,7 @@ class StackProcessor:
 
     def __init__(self, n_t, n_c, h, w, dtype=torch.uint16, min_bead_diameter=10, max_bead_diameter=50,
                  low_edge_quantile=0.1, high_edge_quantile=0.9, num_iter=5_000_000, min_roundness=0.3,
-                 roi_length=None, search_channels=(0,), mode="P", plane_batch=None, device="cuda"):
+                 roi_length=None, search_channels=(0,), mode="P", plane_batch=None, device="cuda", n_streams=1):
         hp.require_gpu()
         if min_bead_diameter > max_bead_diameter:
             raise ValueError("min_bead_diameter must be <= max_bead_diameter.")
@@ -38,8 +38,20 @@ class StackProcessor:
         self.mode = mode
         self.dev = torch.device(device)
         self.n_assays = n_t if mode == "P" else 1
-        self.batch = min(self.n_assays, plane_batch or self.n_assays)
-        self.finder = hp.CircleFinder(self.batch, h, w, self.min_r, self.max_r, num_iter, device=device)
+        self.n_streams = n_streams if (self.n_assays >= 2 * n_streams and not plane_batch) else 1
+        if self.n_streams > 1:
+            # detection runs as n_streams contiguous sub-batches, each on its own HIP stream and host
+            # thread: one sub-batch's latency-bound tails and host checks overlap the other's kernels
+            per = -(-self.n_assays // self.n_streams)
+            self.ranges = [(i, min(i + per, self.n_assays)) for i in range(0, self.n_assays, per)]
+            self.finders = [hp.CircleFinder(b - a, h, w, self.min_r, self.max_r, num_iter, device=device)
+                            for a, b in self.ranges]
+            self.streams = [torch.cuda.Stream(device=device) for _ in self.ranges]
+            self.finder = self.finders[0]
+            self.batch = self.ranges[0][1] - self.ranges[0][0]
+        else:
+            self.batch = min(self.n_assays, plane_batch or self.n_assays)
+            self.finder = hp.CircleFinder(self.batch, h, w, self.min_r, self.max_r, num_iter, device=device)
         self.image = torch.empty((n_t, n_c, h, w), dtype=dtype, device=self.dev)
         self.minmax = torch.empty((n_t, n_c, 2), dtype=torch.float64, device=self.dev)
 
@@ -58,6 +70,8 @@ class StackProcessor:
         T, h, w = self.T, self.h, self.w
         assays = list(range(self.n_assays))
         beads = [np.empty((0, 3), dtype=np.int32) for _ in assays]
+        if self.n_streams > 1:
+            return self._detect_streams(seed, beads)
         for k, ch in enumerate(self.search_channels):
             done = 0
             while done < len(assays):
@@ -73,6 +87,39 @@ class StackProcessor:
                     if a >= done:
                         beads[a] = np.concatenate([beads[a], dedup_against(beads[a], res[j][0], 2 * self.min_r)])
                 done = lo + self.batch
+        return beads
+
+    def _detect_streams(self, seed, beads):
+        import threading
+
+        main = torch.cuda.current_stream()
+        errors = []
+
+        def work(idx):
+            try:
+                lo, hi = self.ranges[idx]
+                stream = self.streams[idx]
+                stream.wait_stream(main)  # the flat-field pass ran on the caller's stream
+                with torch.cuda.stream(stream):
+                    for k, ch in enumerate(self.search_channels):
+                        planes = self.image[lo:hi, ch]
+                        mm = self.minmax[lo:hi, ch].contiguous()
+                        seeds = [(seed + 1000003 * a + 7919 * k) & 0xFFFFFFFFFFFFFFFF for a in range(lo, hi)]
+                        res, _ = self.finders[idx].find(planes, mm, self.low_q, self.high_q, self.min_roundness,
+                                                        self.min_r, seeds)
+                        for j, a in enumerate(range(lo, hi)):
+                            beads[a] = np.concatenate([beads[a], dedup_against(beads[a], res[j][0], 2 * self.min_r)])
+                main.wait_stream(stream)
+            except Exception as exc:  # surfaced on the caller's thread
+                errors.append(exc)
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(self.ranges))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
         return beads
 
     def segment_reduce(self, beads, want_roi=True):

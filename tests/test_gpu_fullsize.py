@@ -59,6 +59,23 @@ def test_full_size_stack_properties(mg):
         np.testing.assert_array_equal(a, b)
 
 
+def test_streamed_detection_is_identical(mg):
+    """Detection split over HIP streams / host threads gives exactly the single-stream result."""
+    from magnify_amd.stack import StackProcessor, synthetic_stack
+
+    stack, _ = synthetic_stack(6, 2, 512, 640, seed=77)
+    outs = []
+    for n_streams in (1, 2, 3):
+        proc = StackProcessor(6, 2, 512, 640, num_iter=100000, search_channels=(0, 1), mode="P", n_streams=n_streams)
+        outs.append(proc(stack, 0.9, 100.0, seed=5))
+        assert proc.n_streams == n_streams
+    for other in outs[1:]:
+        for a, b in zip(outs[0]["beads"], other["beads"]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(outs[0]["sums"].cpu().numpy(), other["sums"].cpu().numpy())
+    assert sum(len(b) for b in outs[0]["beads"]) > 50
+
+
 def test_mode_r_matches_oracle_small(mg):
     """Single-assay semantics (find.py:477, 543-550): detection on time 0, maxima over the stack."""
     from magnify_amd.stack import StackProcessor
