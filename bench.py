@@ -48,32 +48,39 @@ def algorithmic_bytes(stage, p):
     return table.get(stage)
 
 
-def cpu_baseline(args, flat_np):
-    """The oracle (a CPU restatement of the reference path, kind 'port') timed on this host on a
-    bounded sample of the same workload: ONE timepoint of C channels at (cpu_size x cpu_size) with
-    the RANSAC budget scaled to the same iterations per pixel."""
+def cpu_baseline(args, stack, flat_np, seeds, gpu_counts, gpu_fg_sums):
+    """The oracle's C restatement of the reference path (oracle/c/ref_port.c, kind 'port') timed on
+    this host on a bounded sample of the SAME workload: the first timepoints of the bench stack (one
+    assay per OpenMP thread, at most 16 threads = the box's CPU share), same flat-field, same
+    RANSAC budget and the seeds of the last GPU step, so the bead counts and the fg-sum checksums
+    of the two paths can be compared as well."""
     import numpy as np
 
-    from oracle import ref_numeric as rn
-    from oracle import ref_pipeline as rp
-    from synth import noisy_bead_image
+    from oracle import cport
 
-    s = args.cpu_size
-    n_beads = int(round(120 * s * s / 1e6))
-    planes = np.stack([noisy_bead_image(9000 + c, (s, s), n_beads)[0] for c in range(args.channels)])
-    tiles = planes[:, None, None, None]
-    num_iter = max(1000, int(args.num_iter * (s * s) / (args.size * args.size)))
-    flat = flat_np[:s, :s]
+    cores = max(1, min(16, len(os.sched_getaffinity(0)), cport.max_threads(), args.timepoints))
+    n = min(args.timepoints, cores * max(1, args.cpu_assays_per_core))
+    sample = stack[:n].cpu().numpy()
     t0 = time.perf_counter()
-    image = rp.stitch(rp.flatfield_correct(tiles, flat, 100.0), 0)
-    out = rp.find_beads(image, 10, 50, num_iter=num_iter, search_channels=[0], seed=1)
-    red = rp.roi_reduce(out["roi"], out["fg"], out["bg"], medians=False)  # the GPU step reduces sums/counts too
+    total, counts, sums = cport.run_stack(sample, flat_np, 100.0, 5, 25, 100, seeds[:n], num_iter=args.num_iter,
+                                          n_threads=cores)
     dt = time.perf_counter() - t0
-    mp = args.channels * s * s / 1e6
-    return {"value": mp / dt, "unit": "MP/s", "cores": 1, "kind": "port",
-            "sample": f"1 timepoint x {args.channels} ch x {s}x{s} uint16, num_iter={num_iter}, "
-                      f"{len(out['beads'])} markers, {dt:.1f} s (NumPy oracle, single thread)",
-            "markers_per_s": len(out["beads"]) / dt, "_check": float(red["fg_count"].sum())}
+    mp = n * args.channels * args.size * args.size / 1e6
+    agree = bool(np.array_equal(counts, np.asarray(gpu_counts[:n])) and np.array_equal(sums, np.asarray(gpu_fg_sums[:n])))
+    return {"value": mp / dt, "unit": "MP/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} of the step's {args.timepoints} timepoints ({args.channels} ch x {args.size}x{args.size} "
+                      f"uint16 each, num_iter={args.num_iter}), one assay per OpenMP thread on {cores} threads, "
+                      f"{total} markers, {dt:.1f} s (C restatement oracle/c/ref_port.c)",
+            "markers_per_s": total / dt, "same_markers_and_sums_as_gpu": agree}
+
+
+def per_assay_fg_sums(out, n_assays):
+    """Sum of the foreground sums of every assay's markers (exact integers held in float64)."""
+    import numpy as np
+
+    fg = out["sums"][..., 0].sum(dim=(1, 2)).cpu().numpy()
+    off = out["offsets"]
+    return [int(fg[off[a]:off[a + 1]].sum()) for a in range(n_assays)]
 
 
 def main():
@@ -87,7 +94,7 @@ def main():
     ap.add_argument("--num-iter", type=int, default=5_000_000)
     ap.add_argument("--plane-batch", type=int, default=0, help="searched planes per kernel batch (0 = all)")
     ap.add_argument("--streams", type=int, default=4, help="detection sub-batches on separate HIP streams")
-    ap.add_argument("--cpu-size", type=int, default=4096)
+    ap.add_argument("--cpu-assays-per-core", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -211,9 +218,10 @@ def main():
                       "kernel_ms_per_step": total_ms / args.steps},
         }
         if not args.no_cpu and world == 1:
-            cb = cpu_baseline(args, flat_np)
-            cb.pop("_check", None)
-            result["cpu_baseline"] = cb
+            last = args.warmup + args.steps - 1  # seed of the step whose results are in `out`
+            seeds = [(last + 1000003 * a) & 0xFFFFFFFFFFFFFFFF for a in range(T)]
+            result["cpu_baseline"] = cpu_baseline(args, stack, flat_np, seeds, [len(b) for b in out["beads"]],
+                                                  per_assay_fg_sums(out, T))
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))

@@ -76,6 +76,37 @@ def test_streamed_detection_is_identical(mg):
     assert sum(len(b) for b in outs[0]["beads"]) > 50
 
 
+def test_full_size_assays_match_c_oracle(mg):
+    """BASELINE's plane size (4096 x 4096, 5e6 RANSAC iterations): the whole chain of two assays
+    against the oracle's C restatement -- corrected image, bead tables, ROI windows, masks and sums
+    all bit-exact."""
+    from magnify_amd.stack import StackProcessor, synthetic_stack
+    from oracle import cport
+
+    T, C, S = 2, 2, 4096
+    stack, _ = synthetic_stack(T, C, S, S, seed=4100)
+    flat_np = vignette((S, S))
+    proc = StackProcessor(T, C, S, S, num_iter=5_000_000, search_channels=(0,), mode="P")
+    out = proc(stack, torch.from_numpy(flat_np).cuda(), 100.0, seed=9)
+    host = stack.cpu().numpy()
+    off = out["offsets"]
+    for t in range(T):
+        img = cport.flatfield_correct(host[t][:, None, None, None], flat_np, 100.0)[:, 0, 0, 0]
+        np.testing.assert_array_equal(proc.image[t].cpu().numpy(), img)
+        want = cport.bead_assay(img, proc.min_r, proc.max_r, proc.L, num_iter=5_000_000,
+                                seed=(9 + 1000003 * t) & 0xFFFFFFFFFFFFFFFF)
+        np.testing.assert_array_equal(out["beads"][t], want["beads"])
+        assert len(want["beads"]) > 1500
+        lo, hi = off[t], off[t + 1]
+        np.testing.assert_array_equal(out["roi"][lo:hi, :, 0].cpu().numpy(), want["roi"])
+        np.testing.assert_array_equal(out["fg"][lo:hi].cpu().numpy().astype(bool), want["fg"])
+        np.testing.assert_array_equal(out["bg"][lo:hi].cpu().numpy().astype(bool), want["bg"])
+        sums = out["sums"][lo:hi, :, 0].cpu().numpy()
+        np.testing.assert_array_equal(sums[..., 0], want["fg_sum"])
+        np.testing.assert_array_equal(sums[..., 1], want["bg_sum"])
+        np.testing.assert_array_equal(out["counts"][lo:hi].cpu().numpy(), np.stack([want["fg_count"], want["bg_count"]], 1))
+
+
 def test_mode_r_matches_oracle_small(mg):
     """Single-assay semantics (find.py:477, 543-550): detection on time 0, maxima over the stack."""
     from magnify_amd.stack import StackProcessor
