@@ -43,6 +43,7 @@ def algorithmic_bytes(stage, p):
         "mg_collect_circles": p["alive"] * 4 + p["markers"] * 16,
         "mg_circle_labels": p["markers"] * p["mean_disk"] * 8,
         "mg_roi_gather_reduce_batched": p["markers"] * p["L"] ** 2 * (4 * c + 6),
+        "mg_roi_segment_reduce": p["markers"] * p["L"] ** 2 * (4 * c + 2),  # no label map: pixels in/out + masks out
         "mg_plane_minmax": 2 * planes * n,
     }
     return table.get(stage)
@@ -192,10 +193,12 @@ def main():
         # the streaming part alone (everything that is not RANSAC scoring / suppression)
         stream_stages = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_to_uint8_blur", "mg_scharr_hist",
                          "mg_canny_nms", "mg_canny_hysteresis", "mg_edge_grid", "mg_edge_angles", "mg_circle_labels",
-                         "mg_roi_gather_reduce_batched"]
+                         "mg_roi_gather_reduce_batched", "mg_roi_segment_reduce"]
         stream_ms = sum(stages[s][0] for s in stream_stages if s in stages) / args.steps
         n_all, n_s = T * C * S * S, sum(x.P for x in finders) * S * S
-        stream_bytes = 6 * n_all + 12 * n_s + markers_local * proc.L**2 * (4 * C + 6)
+        # SURVEY.md 8d's count minus the label map this build no longer writes (4 B/px of the searched
+        # planes) or reads (4 B per window pixel): masks come straight from the bead tables
+        stream_bytes = 6 * n_all + 8 * n_s + markers_local * proc.L**2 * (4 * C + 2)
         result = {
             "metric": "megapixels/sec through flatfield+segment+ROI-reduce; markers/sec",
             "value": mp_total / (dt / args.steps), "unit": "MP/s", "n_gpus": world, "steps": args.steps,

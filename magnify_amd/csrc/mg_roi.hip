@@ -52,33 +52,103 @@ __device__ __forceinline__ void window(int c, int len, int size, int& lo) {
   lo = a;
 }
 
+// fg/bg segmentation straight from the bead table, without the label map: a window pixel is
+//   foreground  <=> it lies in this marker's disk and in no other disk   (labels == i,  find.py:580)
+//   background  <=> it lies in no disk at all                            (labels == -1, find.py:582)
+// which is what circle_labels' "exactly one owner / contested" rule (utils.py:380-395) yields.
+// Row bit masks of the window in LDS: any (covered), multi (covered twice or more), own.
+struct DiskMasks {
+  uint32_t* any;
+  uint32_t* multi;
+  uint32_t* own;
+  int wpr;  // words per window row
+  __device__ __forceinline__ void flags(int ry, int rx, uint32_t& f, uint32_t& b) const {
+    const int i = ry * wpr + (rx >> 5), sh = rx & 31;
+    f = ((own[i] & ~multi[i]) >> sh) & 1u;
+    b = (~any[i] >> sh) & 1u;
+  }
+};
+
+__device__ __forceinline__ DiskMasks build_disk_masks(uint32_t* base, int len, int top, int left,
+                                                      const int32_t* __restrict__ beads, int nb, int local,
+                                                      const int32_t* __restrict__ hwtab, int max_r) {
+  DiskMasks m;
+  m.wpr = (len + 31) >> 5;
+  const int words = len * m.wpr;
+  m.any = base;
+  m.multi = base + words;
+  m.own = base + 2 * words;
+  for (int i = threadIdx.x; i < 3 * words; i += NT) base[i] = 0u;
+  __syncthreads();
+  for (int j = threadIdx.x; j < nb; j += NT) {
+    const int yj = beads[3 * j], xj = beads[3 * j + 1], rj = beads[3 * j + 2];
+    if (rj < 2 || rj > max_r) continue;  // undefined in the reference, no coverage (as k_circle_labels)
+    if (yj + rj < top || yj - rj >= top + len || xj + rj < left || xj - rj >= left + len) continue;
+    const int32_t* hw = hwtab + (int64_t)rj * (2 * max_r + 1);
+    const int ry0 = max(yj - rj, top) - top, ry1 = min(yj + rj, top + len - 1) - top;
+    for (int ry = ry0; ry <= ry1; ++ry) {
+      const int hwid = hw[top + ry - yj + rj];
+      if (hwid < 0) continue;
+      const int xa = max(xj - hwid, left) - left, xb = min(xj + hwid, left + len - 1) - left;
+      if (xa > xb) continue;
+      for (int wd = xa >> 5; wd <= (xb >> 5); ++wd) {
+        const int lo = max(xa, 32 * wd) - 32 * wd, hi = min(xb, 32 * wd + 31) - 32 * wd;
+        const uint32_t bits = (hi - lo == 31) ? 0xFFFFFFFFu : (((1u << (hi - lo + 1)) - 1u) << lo);
+        const uint32_t old = atomicOr(&m.any[ry * m.wpr + wd], bits);
+        if (old & bits) atomicOr(&m.multi[ry * m.wpr + wd], old & bits);
+        if (j == local) m.own[ry * m.wpr + wd] |= bits;  // only this thread ever writes own
+      }
+    }
+  }
+  __syncthreads();
+  return m;
+}
+
+__device__ __forceinline__ int mask_words(int len) { return 3 * len * ((len + 31) >> 5); }
+inline size_t roi_lds_bytes(int len, bool disks) {
+  const size_t fl = ((size_t)len * len + 3) & ~(size_t)3;
+  return fl + (disks ? (size_t)3 * len * ((len + 31) >> 5) * 4 : 0);
+}
+
 template <typename T, typename ACC>
 __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64_t assay_stride, int n_c, int n_t, int h,
                                             int w, const int32_t* __restrict__ d_beads,
                                             const int32_t* __restrict__ d_marker_assay,
                                             const int32_t* __restrict__ d_marker_local, int len,
-                                            const int32_t* __restrict__ d_labels, T* __restrict__ d_roi,
+                                            const int32_t* __restrict__ d_labels,
+                                            const int32_t* __restrict__ d_assay_offsets,
+                                            const int32_t* __restrict__ d_halfwidths, int max_r, T* __restrict__ d_roi,
                                             uint8_t* __restrict__ d_fg, uint8_t* __restrict__ d_bg,
                                             double* __restrict__ d_sums, int32_t* __restrict__ d_counts) {
-  extern __shared__ uint8_t flags[];
+  extern __shared__ __attribute__((aligned(4))) uint8_t flags[];
   __shared__ ACC s_red[2][NT / 64];
   __shared__ int s_cnt[2][NT / 64];
   const int g = blockIdx.x;
   const int assay = d_marker_assay ? d_marker_assay[g] : 0;
-  const int local = d_marker_local ? d_marker_local[g] : g;
+  const int first = d_assay_offsets ? d_assay_offsets[assay] : 0;
+  const int local = d_assay_offsets ? g - first : (d_marker_local ? d_marker_local[g] : g);
   const int cy = d_beads[3 * (int64_t)g], cx = d_beads[3 * (int64_t)g + 1];
   int top, left;
   window(cy, len, h, top);
   window(cx, len, w, left);
   const int n = len * len;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // masks from the label map (find.py:580-584)
+  // masks from the label map (find.py:580-584) or straight from the assay's bead table
   const int32_t* lab = d_labels ? d_labels + (int64_t)assay * h * w : nullptr;
+  DiskMasks dm{};
+  if (d_halfwidths)
+    dm = build_disk_masks(reinterpret_cast<uint32_t*>(flags + ((n + 3) & ~3)), len, top, left,
+                          d_beads + 3 * (int64_t)first, d_assay_offsets[assay + 1] - first, local, d_halfwidths, max_r);
   int cf = 0, cb = 0;
   for (int p = threadIdx.x; p < n; p += NT) {
     const int ry = p / len, rx = p - ry * len;
     uint8_t f = 0, b = 0;
-    if (lab) {
+    if (d_halfwidths) {
+      uint32_t ff, bb;
+      dm.flags(ry, rx, ff, bb);
+      f = (uint8_t)ff;
+      b = (uint8_t)bb;
+    } else if (lab) {
       const int v = lab[(int64_t)(top + ry) * w + (left + rx)];
       f = v == local;
       b = v == -1;
@@ -144,15 +214,18 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
                                                      const int32_t* __restrict__ d_marker_assay,
                                                      const int32_t* __restrict__ d_marker_local, int len,
                                                      const int32_t* __restrict__ d_labels,
+                                                     const int32_t* __restrict__ d_assay_offsets,
+                                                     const int32_t* __restrict__ d_halfwidths, int max_r,
                                                      uint16_t* __restrict__ d_roi, uint8_t* __restrict__ d_fg,
                                                      uint8_t* __restrict__ d_bg, double* __restrict__ d_sums,
                                                      int32_t* __restrict__ d_counts) {
-  extern __shared__ uint8_t flags[];  // [len][len]: bit 0 fg, bit 1 bg
+  extern __shared__ __attribute__((aligned(4))) uint8_t flags[];  // [len][len]: bit 0 fg, bit 1 bg
   __shared__ long long s_red[2][NT / 64];
   __shared__ int s_cnt[2][NT / 64];
   const int g = blockIdx.x;
   const int assay = d_marker_assay ? d_marker_assay[g] : 0;
-  const int local = d_marker_local ? d_marker_local[g] : g;
+  const int first = d_assay_offsets ? d_assay_offsets[assay] : 0;
+  const int local = d_assay_offsets ? g - first : (d_marker_local ? d_marker_local[g] : g);
   int top, left;
   window(d_beads[3 * (int64_t)g], len, h, top);
   window(d_beads[3 * (int64_t)g + 1], len, w, left);
@@ -161,11 +234,18 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
   const int x = 2 * lane;
   const bool act = lane < half;
   const int32_t* lab = d_labels ? d_labels + (int64_t)assay * h * w : nullptr;
+  DiskMasks dm{};
+  if (d_halfwidths)
+    dm = build_disk_masks(reinterpret_cast<uint32_t*>(flags + ((n + 3) & ~3)), len, top, left,
+                          d_beads + 3 * (int64_t)first, d_assay_offsets[assay + 1] - first, local, d_halfwidths, max_r);
   int cf = 0, cb = 0;
   for (int ry = wave; ry < len; ry += NT / 64) {
     if (!act) continue;
     uint32_t f0 = 0, f1 = 0, b0 = 0, b1 = 0;
-    if (lab) {
+    if (d_halfwidths) {
+      dm.flags(ry, x, f0, b0);
+      dm.flags(ry, x + 1, f1, b1);
+    } else if (lab) {
       const int32_t* lp = lab + (int64_t)(top + ry) * w + left + x;
       const int v0 = lp[0], v1 = lp[1];
       f0 = v0 == local, f1 = v1 == local, b0 = v0 == -1, b1 = v1 == -1;
@@ -296,10 +376,11 @@ __global__ __launch_bounds__(NT) void k_masked_median_u16(const uint16_t* __rest
 template <typename T, typename ACC>
 int launch_roi(const void* d_image, int64_t assay_stride, int n_c, int n_t, int h, int w, const int32_t* d_beads,
                const int32_t* d_marker_assay, const int32_t* d_marker_local, int m, int len, const int32_t* d_labels,
-               void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, hipStream_t s) {
-  hipLaunchKernelGGL((k_roi<T, ACC>), dim3(m), dim3(NT), (size_t)len * len, s, (const T*)d_image, assay_stride, n_c,
-                     n_t, h, w, d_beads, d_marker_assay, d_marker_local, len, d_labels, (T*)d_roi, d_fg, d_bg, d_sums,
-                     d_counts);
+               const int32_t* d_assay_offsets, const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg,
+               uint8_t* d_bg, double* d_sums, int32_t* d_counts, hipStream_t s) {
+  hipLaunchKernelGGL((k_roi<T, ACC>), dim3(m), dim3(NT), roi_lds_bytes(len, d_halfwidths != nullptr), s,
+                     (const T*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, len,
+                     d_labels, d_assay_offsets, d_halfwidths, max_r, (T*)d_roi, d_fg, d_bg, d_sums, d_counts);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -319,39 +400,64 @@ extern "C" int mg_circle_labels(const int32_t* d_beads, int64_t bead_cap, const 
   return MG_OK;
 }
 
-extern "C" int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t,
-                                            int h, int w, const int32_t* d_beads, const int32_t* d_marker_assay,
-                                            const int32_t* d_marker_local, int m, int roi_len,
-                                            const int32_t* d_labels, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
-                                            double* d_sums, int32_t* d_counts, void* stream) {
+namespace {
+int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h, int w,
+                 const int32_t* d_beads, const int32_t* d_marker_assay, const int32_t* d_marker_local, int m, int roi_len,
+                 const int32_t* d_labels, const int32_t* d_assay_offsets, const int32_t* d_halfwidths, int max_r,
+                 void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream) {
   if (!d_image || !d_beads || m < 0 || roi_len <= 0 || n_c <= 0 || n_t <= 0) return MG_EINVAL;
-  if (roi_len > h || roi_len > w || (int64_t)roi_len * roi_len > 60000) return MG_EINVAL;
+  if (roi_len > h || roi_len > w || roi_lds_bytes(roi_len, d_halfwidths != nullptr) > 60000) return MG_EINVAL;
   if (m == 0) return MG_OK;
   hipStream_t s = mg_stream(stream);
   if (dtype == MG_U16 && (roi_len & 1) == 0 && roi_len <= 126 && (w & 1) == 0 && (assay_stride & 1) == 0 &&
       (reinterpret_cast<uintptr_t>(d_image) & 3) == 0 && (!d_roi || (reinterpret_cast<uintptr_t>(d_roi) & 3) == 0) &&
       (!d_fg || (reinterpret_cast<uintptr_t>(d_fg) & 1) == 0) && (!d_bg || (reinterpret_cast<uintptr_t>(d_bg) & 1) == 0)) {
-    hipLaunchKernelGGL(k_roi_u16_even, dim3(m), dim3(NT), (size_t)roi_len * roi_len, s, (const uint16_t*)d_image,
-                       assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, roi_len, d_labels,
-                       (uint16_t*)d_roi, d_fg, d_bg, d_sums, d_counts);
+    hipLaunchKernelGGL(k_roi_u16_even, dim3(m), dim3(NT), roi_lds_bytes(roi_len, d_halfwidths != nullptr), s,
+                       (const uint16_t*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
+                       roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg, d_sums,
+                       d_counts);
     MG_CHECK_LAUNCH();
     return MG_OK;
   }
   switch (dtype) {
     case MG_U8:
       return launch_roi<uint8_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
-                                            d_marker_local, m, roi_len, d_labels, d_roi, d_fg, d_bg, d_sums, d_counts, s);
+                                            d_marker_local, m, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r,
+                                            d_roi, d_fg, d_bg, d_sums, d_counts, s);
     case MG_U16:
       return launch_roi<uint16_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
-                                             d_marker_local, m, roi_len, d_labels, d_roi, d_fg, d_bg, d_sums, d_counts, s);
+                                             d_marker_local, m, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r,
+                                             d_roi, d_fg, d_bg, d_sums, d_counts, s);
     case MG_F32:
       return launch_roi<float, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                                       m, roi_len, d_labels, d_roi, d_fg, d_bg, d_sums, d_counts, s);
+                                       m, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                                       d_sums, d_counts, s);
     case MG_F64:
       return launch_roi<double, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                                        m, roi_len, d_labels, d_roi, d_fg, d_bg, d_sums, d_counts, s);
+                                        m, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                                        d_sums, d_counts, s);
   }
   return MG_EINVAL;
+}
+}  // namespace
+
+extern "C" int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t,
+                                            int h, int w, const int32_t* d_beads, const int32_t* d_marker_assay,
+                                            const int32_t* d_marker_local, int m, int roi_len,
+                                            const int32_t* d_labels, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
+                                            double* d_sums, int32_t* d_counts, void* stream) {
+  return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, m, roi_len,
+                      d_labels, nullptr, nullptr, 0, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
+}
+
+extern "C" int mg_roi_segment_reduce(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h,
+                                     int w, const int32_t* d_beads, const int32_t* d_marker_assay,
+                                     const int32_t* d_assay_offsets, int n_assays, int m, int roi_len,
+                                     const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
+                                     double* d_sums, int32_t* d_counts, void* stream) {
+  if (!d_marker_assay || !d_assay_offsets || !d_halfwidths || n_assays <= 0 || max_r < 0) return MG_EINVAL;
+  return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, nullptr, m, roi_len,
+                      nullptr, d_assay_offsets, d_halfwidths, max_r, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
 }
 
 extern "C" int mg_roi_gather_reduce(const void* d_image, int dtype, int n_c, int n_t, int h, int w,

@@ -560,8 +560,11 @@ def release_labels(labels):
 
 
 def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, labels: torch.Tensor | None,
-                      want_roi=True, want_masks=True, want_sums=True, reuse_buffers=False):
+                      want_roi=True, want_masks=True, want_sums=True, reuse_buffers=False, disks=False):
     """images (A, C, T, h, w); centers_per_assay: list of (M_a, >=2) int arrays [row, col, ...].
+
+    Masks: from the ``labels`` map (utils.circle_labels) or, with ``disks=True`` and (M_a, 3) bead
+    tables [row, col, r], straight from the bead geometry (same result, no label map at all).
 
     Returns dict: roi (M, C, T, L, L), fg/bg (M, L, L) uint8, sums (M, C, T, 2) float64
     [fg sum, bg sum], counts (M, 2) int32, offsets (A+1,) numpy.  ``reuse_buffers`` returns views of
@@ -590,11 +593,19 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         b = np.asarray(b)
         lo, hi = offsets[k], offsets[k + 1]
         if hi > lo:
-            beads[lo:hi, :2] = b[:, :2]
+            beads[lo:hi, : 3 if disks else 2] = b[:, : 3 if disks else 2]
             assay[lo:hi] = k
             local[lo:hi] = np.arange(hi - lo)
     d_beads = torch.from_numpy(beads).to(dev)
     d_assay = torch.from_numpy(assay).to(dev)
+    if disks:
+        max_r = max(int(beads[:, 2].max()), 2)
+        tab = _halfwidth_table(max_r, dev)
+        d_off = torch.from_numpy(offsets.astype(np.int32)).to(dev)
+        _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
+              d_beads.data_ptr(), d_assay.data_ptr(), d_off.data_ptr(), a, m, L, tab.data_ptr(), max_r,
+              _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
+        return res
     d_local = torch.from_numpy(local).to(dev)
     _call("mg_roi_gather_reduce_batched", 
         images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w, d_beads.data_ptr(),

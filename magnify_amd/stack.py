@@ -123,16 +123,14 @@ class StackProcessor:
         return beads
 
     def segment_reduce(self, beads, want_roi=True):
-        """Labels, fg/bg masks, ROI gather and masked sums for every marker."""
+        """fg/bg masks, ROI gather and masked sums for every marker (find.py:561-602)."""
         T, C, h, w = self.T, self.C, self.h, self.w
-        labels = hp.circle_labels(beads, h, w, device=self.dev, reuse=True)
         if self.mode == "P":
             images = self.image.view(T, C, 1, h, w)
         else:
             images = self.image.permute(1, 0, 2, 3).contiguous().view(1, C, T, h, w)
-        out = hp.roi_gather_reduce(images, beads, self.L, labels, want_roi=want_roi, reuse_buffers=True)
-        hp.release_labels(labels)
-        return out
+        # masks straight from the bead tables (mg_roi_segment_reduce): no label map is written or read
+        return hp.roi_gather_reduce(images, beads, self.L, None, want_roi=want_roi, reuse_buffers=True, disks=True)
 
     def __call__(self, stack, flatfield=1.0, darkfield=0.0, seed=0, want_roi=True):
         self.flatfield(stack, flatfield, darkfield)

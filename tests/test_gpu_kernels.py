@@ -383,3 +383,40 @@ def test_roi_gather_reduce(hp, dtype):
     else:
         np.testing.assert_allclose(sums[..., 0], red["fg_sum"], rtol=1e-12)  # float64 sums, other order
         np.testing.assert_allclose(sums[..., 1], red["bg_sum"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("dtype,L", [(np.uint16, 40), (np.uint16, 100), (np.uint16, 33), (np.float32, 40), (np.uint8, 64)])
+def test_roi_segment_reduce_from_disks(hp, dtype, L):
+    """Masks straight from the bead table (no label map) equal the masks read from the oracle's
+    circle_labels map: overlapping (contested) disks, disks cut by the image border, centres outside
+    the image, crowded windows, several assays with different bead counts."""
+    rng = np.random.default_rng(33)
+    c, t, h, w = 2, 2, 180, 220
+    images = rng.integers(0, 250, size=(3, c, t, h, w)).astype(dtype)
+    crowded = np.column_stack([rng.integers(40, 140, 60), rng.integers(40, 180, 60), rng.integers(2, 12, 60)])
+    assays = [
+        np.array([[20, 20, 8], [5, 190, 6], [150, 100, 10], [80, 80, 9], [84, 92, 9], [179, 0, 5], [33, 57, 6],
+                  [121, 143, 7], [-3, 100, 6], [90, 224, 7], [80, 84, 25]]),
+        crowded,
+        np.empty((0, 3), dtype=np.int64),
+    ]
+    res = hp.roi_gather_reduce(dev(images), assays, L, None, disks=True)
+    off = res["offsets"]
+    assert off[-1] == sum(len(b) for b in assays)
+    for a, beads in enumerate(assays):
+        if len(beads) == 0:
+            continue
+        lab = rn.circle_labels(beads, h, w)
+        assert (lab == -2).any()
+        for i, (row, col, _) in enumerate(beads):
+            g = off[a] + i
+            top, bottom, left, right = rn.bounding_box(int(col), int(row), L, w, h)
+            sub = lab[top:bottom, left:right]
+            np.testing.assert_array_equal(res["fg"][g].cpu().numpy().astype(bool), sub == i)
+            np.testing.assert_array_equal(res["bg"][g].cpu().numpy().astype(bool), sub == -1)
+            win = images[a][:, :, top:bottom, left:right]
+            np.testing.assert_array_equal(res["roi"][g].cpu().numpy(), win)
+            sums = res["sums"][g].cpu().numpy()
+            np.testing.assert_array_equal(sums[..., 0], win.astype(np.float64)[:, :, sub == i].sum(-1))
+            np.testing.assert_array_equal(sums[..., 1], win.astype(np.float64)[:, :, sub == -1].sum(-1))
+            assert tuple(res["counts"][g].cpu().numpy()) == (int((sub == i).sum()), int((sub == -1).sum()))
