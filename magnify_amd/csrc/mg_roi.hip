@@ -69,9 +69,34 @@ struct DiskMasks {
   }
 };
 
+// OR one row span of a disk into the masks (LDS atomics; any thread, any order).
+__device__ __forceinline__ void mask_row(const DiskMasks& m, int ry, int xa, int xb, bool is_own) {
+  for (int wd = xa >> 5; wd <= (xb >> 5); ++wd) {
+    const int lo = max(xa, 32 * wd) - 32 * wd, hi = min(xb, 32 * wd + 31) - 32 * wd;
+    const uint32_t bits = (hi - lo == 31) ? 0xFFFFFFFFu : (((1u << (hi - lo + 1)) - 1u) << lo);
+    const uint32_t old = atomicOr(&m.any[ry * m.wpr + wd], bits);
+    if (old & bits) atomicOr(&m.multi[ry * m.wpr + wd], old & bits);
+    if (is_own) atomicOr(&m.own[ry * m.wpr + wd], bits);
+  }
+}
+// Row ry of the window under the disk (yj, xj, rj), if it intersects the window.
+__device__ __forceinline__ void mask_disk_row(const DiskMasks& m, int ry, int len, int top, int left, int yj, int xj,
+                                              int rj, bool is_own, const int32_t* __restrict__ hwtab, int max_r) {
+  const int dy = top + ry - yj;
+  if (dy < -rj || dy > rj) return;
+  const int hwid = hwtab[(int64_t)rj * (2 * max_r + 1) + dy + rj];
+  if (hwid < 0) return;
+  const int xa = max(xj - hwid, left) - left, xb = min(xj + hwid, left + len - 1) - left;
+  if (xa <= xb) mask_row(m, ry, xa, xb, is_own);
+}
+
+constexpr int NBR_CAP = 96;  // disks overlapping one window that are handled row-parallel
+
 __device__ __forceinline__ DiskMasks build_disk_masks(uint32_t* base, int len, int top, int left,
                                                       const int32_t* __restrict__ beads, int nb, int local,
                                                       const int32_t* __restrict__ hwtab, int max_r) {
+  __shared__ int s_nn;
+  __shared__ int s_nbr[NBR_CAP][3];
   DiskMasks m;
   m.wpr = (len + 31) >> 5;
   const int words = len * m.wpr;
@@ -79,26 +104,49 @@ __device__ __forceinline__ DiskMasks build_disk_masks(uint32_t* base, int len, i
   m.multi = base + words;
   m.own = base + 2 * words;
   for (int i = threadIdx.x; i < 3 * words; i += NT) base[i] = 0u;
+  if (threadIdx.x == 0) s_nn = 0;
   __syncthreads();
-  for (int j = threadIdx.x; j < nb; j += NT) {
-    const int yj = beads[3 * j], xj = beads[3 * j + 1], rj = beads[3 * j + 2];
-    if (rj < 2 || rj > max_r) continue;  // undefined in the reference, no coverage (as k_circle_labels)
-    if (yj + rj < top || yj - rj >= top + len || xj + rj < left || xj - rj >= left + len) continue;
-    const int32_t* hw = hwtab + (int64_t)rj * (2 * max_r + 1);
-    const int ry0 = max(yj - rj, top) - top, ry1 = min(yj + rj, top + len - 1) - top;
-    for (int ry = ry0; ry <= ry1; ++ry) {
-      const int hwid = hw[top + ry - yj + rj];
-      if (hwid < 0) continue;
-      const int xa = max(xj - hwid, left) - left, xb = min(xj + hwid, left + len - 1) - left;
-      if (xa > xb) continue;
-      for (int wd = xa >> 5; wd <= (xb >> 5); ++wd) {
-        const int lo = max(xa, 32 * wd) - 32 * wd, hi = min(xb, 32 * wd + 31) - 32 * wd;
-        const uint32_t bits = (hi - lo == 31) ? 0xFFFFFFFFu : (((1u << (hi - lo + 1)) - 1u) << lo);
-        const uint32_t old = atomicOr(&m.any[ry * m.wpr + wd], bits);
-        if (old & bits) atomicOr(&m.multi[ry * m.wpr + wd], old & bits);
-        if (j == local) m.own[ry * m.wpr + wd] |= bits;  // only this thread ever writes own
+  // 1. scan the assay's bead table for disks that reach into the window (loads issued in batches:
+  //    one memory latency per 8 * NT beads); collect them in LDS
+  constexpr int UB = 8;
+  for (int b0 = 0; b0 < nb; b0 += NT * UB) {
+    int yy[UB], xx[UB], rr[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int j = b0 + u * NT + (int)threadIdx.x;
+      rr[u] = 0;
+      if (j < nb) {
+        yy[u] = beads[3 * j];
+        xx[u] = beads[3 * j + 1];
+        rr[u] = beads[3 * j + 2];
       }
     }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int j = b0 + u * NT + (int)threadIdx.x;
+      const int yj = yy[u], xj = xx[u], rj = rr[u];
+      if (rj < 2 || rj > max_r) continue;  // undefined in the reference, no coverage (as k_circle_labels)
+      if (yj + rj < top || yj - rj >= top + len || xj + rj < left || xj - rj >= left + len) continue;
+      const int k = atomicAdd(&s_nn, 1);
+      if (k < NBR_CAP) {
+        s_nbr[k][0] = yj;
+        s_nbr[k][1] = xj;
+        s_nbr[k][2] = rj | (j == local ? 0x10000 : 0);
+      } else {  // an extremely crowded window: this thread draws the whole disk itself
+        for (int ry = max(yj - rj, top) - top; ry <= min(yj + rj, top + len - 1) - top; ++ry)
+          mask_disk_row(m, ry, len, top, left, yj, xj, rj, j == local, hwtab, max_r);
+      }
+    }
+  }
+  __syncthreads();
+  // 2. one (disk, row) pair per thread
+  const int nn = min(s_nn, NBR_CAP), side = 2 * max_r + 1;
+  for (int p = threadIdx.x; p < nn * side; p += NT) {
+    const int k = p / side, dyi = p - k * side - max_r;
+    const int yj = s_nbr[k][0], xj = s_nbr[k][1], rj = s_nbr[k][2] & 0xFFFF;
+    const int ry = yj + dyi - top;
+    if (dyi < -rj || dyi > rj || ry < 0 || ry >= len) continue;
+    mask_disk_row(m, ry, len, top, left, yj, xj, rj, (s_nbr[k][2] & 0x10000) != 0, hwtab, max_r);
   }
   __syncthreads();
   return m;
@@ -123,10 +171,18 @@ __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64
   extern __shared__ __attribute__((aligned(4))) uint8_t flags[];
   __shared__ ACC s_red[2][NT / 64];
   __shared__ int s_cnt[2][NT / 64];
-  const int g = blockIdx.x;
-  const int assay = d_marker_assay ? d_marker_assay[g] : 0;
-  const int first = d_assay_offsets ? d_assay_offsets[assay] : 0;
-  const int local = d_assay_offsets ? g - first : (d_marker_local ? d_marker_local[g] : g);
+  // label mode: one block per marker of a flat list; disk mode: grid (local index, assay)
+  int g = blockIdx.x, assay, first = 0, local;
+  if (d_assay_offsets) {
+    assay = blockIdx.y;
+    first = d_assay_offsets[assay];
+    local = blockIdx.x;
+    if (local >= d_assay_offsets[assay + 1] - first) return;
+    g = first + local;
+  } else {
+    assay = d_marker_assay ? d_marker_assay[g] : 0;
+    local = d_marker_local ? d_marker_local[g] : g;
+  }
   const int cy = d_beads[3 * (int64_t)g], cx = d_beads[3 * (int64_t)g + 1];
   int top, left;
   window(cy, len, h, top);
@@ -208,6 +264,7 @@ __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64
 // ---- fast path: uint16 image, even window length <= 126, even image width -------------------------
 // One wave per window row, one dword (2 pixels) per lane: aligned 4-byte loads (odd source offsets
 // are funnel-shifted from two neighbouring dwords), 4-byte roi stores, 2-byte mask stores.
+template <int U>
 __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict__ d_image, int64_t assay_stride,
                                                      int n_c, int n_t, int h, int w,
                                                      const int32_t* __restrict__ d_beads,
@@ -222,10 +279,18 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
   extern __shared__ __attribute__((aligned(4))) uint8_t flags[];  // [len][len]: bit 0 fg, bit 1 bg
   __shared__ long long s_red[2][NT / 64];
   __shared__ int s_cnt[2][NT / 64];
-  const int g = blockIdx.x;
-  const int assay = d_marker_assay ? d_marker_assay[g] : 0;
-  const int first = d_assay_offsets ? d_assay_offsets[assay] : 0;
-  const int local = d_assay_offsets ? g - first : (d_marker_local ? d_marker_local[g] : g);
+  // label mode: one block per marker of a flat list; disk mode: grid (local index, assay)
+  int g = blockIdx.x, assay, first = 0, local;
+  if (d_assay_offsets) {
+    assay = blockIdx.y;
+    first = d_assay_offsets[assay];
+    local = blockIdx.x;
+    if (local >= d_assay_offsets[assay + 1] - first) return;
+    g = first + local;
+  } else {
+    assay = d_marker_assay ? d_marker_assay[g] : 0;
+    local = d_marker_local ? d_marker_local[g] : g;
+  }
   int top, left;
   window(d_beads[3 * (int64_t)g], len, h, top);
   window(d_beads[3 * (int64_t)g + 1], len, w, left);
@@ -272,23 +337,42 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
     const uint16_t* plane = img + (int64_t)ct * h * w;
     uint16_t* out = d_roi ? d_roi + ((int64_t)g * n_c * n_t + ct) * n : nullptr;
     long long sf = 0, sb = 0;
-    for (int ry = wave; ry < len; ry += NT / 64) {
-      const int64_t e0 = (int64_t)(top + ry) * w + left;  // element offset of the row start in the plane
-      const int odd = (int)(e0 & 1);
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(plane + (e0 - odd));
-      uint32_t d = 0;
-      if (lane < half) d = src[lane];
-      else if (lane == half && odd) d = plane[e0 + len - 1];  // last pixel of the row, no over-read
-      const uint32_t nx = (uint32_t)__shfl_down((int)d, 1);
-      const uint32_t v = odd ? ((d >> 16) | (nx << 16)) : d;
-      if (act) {
-        if (out) *reinterpret_cast<uint32_t*>(&out[ry * len + x]) = v;
-        const uint32_t fl = *reinterpret_cast<const uint16_t*>(&flags[ry * len + x]);
-        const long long p0 = v & 0xFFFFu, p1 = v >> 16;
-        if (fl & 0x0001u) sf += p0;
-        if (fl & 0x0100u) sf += p1;
-        if (fl & 0x0002u) sb += p0;
-        if (fl & 0x0200u) sb += p1;
+    // rows are handled U at a time per wave: all U row loads are in flight before the first is
+    // consumed (the gather is latency-bound otherwise: one 256-byte request per wave at a time)
+    constexpr int WV = NT / 64;
+    for (int r0 = wave; r0 < len; r0 += WV * U) {
+      uint32_t dd[U];
+      int oddv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ry = r0 + u * WV;
+        dd[u] = 0;
+        oddv[u] = 0;
+        if (ry < len) {
+          const int64_t e0 = (int64_t)(top + ry) * w + left;  // element offset of the row start in the plane
+          const int odd = (int)(e0 & 1);
+          const uint32_t* src = reinterpret_cast<const uint32_t*>(plane + (e0 - odd));
+          if (lane < half) dd[u] = src[lane];
+          else if (lane == half && odd) dd[u] = plane[e0 + len - 1];  // last pixel of the row, no over-read
+          oddv[u] = odd;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ry = r0 + u * WV;
+        if (ry >= len) break;  // wave-uniform
+        const uint32_t d = dd[u];
+        const uint32_t nx = (uint32_t)__shfl_down((int)d, 1);
+        const uint32_t v = oddv[u] ? ((d >> 16) | (nx << 16)) : d;
+        if (act) {
+          if (out) *reinterpret_cast<uint32_t*>(&out[ry * len + x]) = v;
+          const uint32_t fl = *reinterpret_cast<const uint16_t*>(&flags[ry * len + x]);
+          const long long p0 = v & 0xFFFFu, p1 = v >> 16;
+          if (fl & 0x0001u) sf += p0;
+          if (fl & 0x0100u) sf += p1;
+          if (fl & 0x0002u) sb += p0;
+          if (fl & 0x0200u) sb += p1;
+        }
       }
     }
     if (d_sums) {
@@ -375,10 +459,10 @@ __global__ __launch_bounds__(NT) void k_masked_median_u16(const uint16_t* __rest
 
 template <typename T, typename ACC>
 int launch_roi(const void* d_image, int64_t assay_stride, int n_c, int n_t, int h, int w, const int32_t* d_beads,
-               const int32_t* d_marker_assay, const int32_t* d_marker_local, int m, int len, const int32_t* d_labels,
-               const int32_t* d_assay_offsets, const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg,
+               const int32_t* d_marker_assay, const int32_t* d_marker_local, dim3 grid, int len,
+               const int32_t* d_labels, const int32_t* d_assay_offsets, const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg,
                uint8_t* d_bg, double* d_sums, int32_t* d_counts, hipStream_t s) {
-  hipLaunchKernelGGL((k_roi<T, ACC>), dim3(m), dim3(NT), roi_lds_bytes(len, d_halfwidths != nullptr), s,
+  hipLaunchKernelGGL((k_roi<T, ACC>), grid, dim3(NT), roi_lds_bytes(len, d_halfwidths != nullptr), s,
                      (const T*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, len,
                      d_labels, d_assay_offsets, d_halfwidths, max_r, (T*)d_roi, d_fg, d_bg, d_sums, d_counts);
   MG_CHECK_LAUNCH();
@@ -403,16 +487,18 @@ extern "C" int mg_circle_labels(const int32_t* d_beads, int64_t bead_cap, const 
 namespace {
 int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h, int w,
                  const int32_t* d_beads, const int32_t* d_marker_assay, const int32_t* d_marker_local, int m, int roi_len,
-                 const int32_t* d_labels, const int32_t* d_assay_offsets, const int32_t* d_halfwidths, int max_r,
-                 void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream) {
+                 const int32_t* d_labels, const int32_t* d_assay_offsets, int n_assays, int max_per_assay,
+                 const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream) {
   if (!d_image || !d_beads || m < 0 || roi_len <= 0 || n_c <= 0 || n_t <= 0) return MG_EINVAL;
   if (roi_len > h || roi_len > w || roi_lds_bytes(roi_len, d_halfwidths != nullptr) > 60000) return MG_EINVAL;
   if (m == 0) return MG_OK;
   hipStream_t s = mg_stream(stream);
+  const dim3 grid = d_assay_offsets ? dim3(max_per_assay, n_assays) : dim3(m);
   if (dtype == MG_U16 && (roi_len & 1) == 0 && roi_len <= 126 && (w & 1) == 0 && (assay_stride & 1) == 0 &&
       (reinterpret_cast<uintptr_t>(d_image) & 3) == 0 && (!d_roi || (reinterpret_cast<uintptr_t>(d_roi) & 3) == 0) &&
       (!d_fg || (reinterpret_cast<uintptr_t>(d_fg) & 1) == 0) && (!d_bg || (reinterpret_cast<uintptr_t>(d_bg) & 1) == 0)) {
-    hipLaunchKernelGGL(k_roi_u16_even, dim3(m), dim3(NT), roi_lds_bytes(roi_len, d_halfwidths != nullptr), s,
+    // 4 row loads in flight per wave (2..13 measured: 4-7 are equally fast, 2 is 30 % slower)
+    hipLaunchKernelGGL(k_roi_u16_even<4>, grid, dim3(NT), roi_lds_bytes(roi_len, d_halfwidths != nullptr), s,
                        (const uint16_t*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
                        roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg, d_sums,
                        d_counts);
@@ -422,19 +508,19 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
   switch (dtype) {
     case MG_U8:
       return launch_roi<uint8_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
-                                            d_marker_local, m, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r,
+                                            d_marker_local, grid, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r,
                                             d_roi, d_fg, d_bg, d_sums, d_counts, s);
     case MG_U16:
       return launch_roi<uint16_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
-                                             d_marker_local, m, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r,
+                                             d_marker_local, grid, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r,
                                              d_roi, d_fg, d_bg, d_sums, d_counts, s);
     case MG_F32:
       return launch_roi<float, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                                       m, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                                       grid, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r, d_roi, d_fg, d_bg,
                                        d_sums, d_counts, s);
     case MG_F64:
       return launch_roi<double, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                                        m, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                                        grid, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r, d_roi, d_fg, d_bg,
                                         d_sums, d_counts, s);
   }
   return MG_EINVAL;
@@ -447,17 +533,19 @@ extern "C" int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int6
                                             const int32_t* d_labels, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
                                             double* d_sums, int32_t* d_counts, void* stream) {
   return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, m, roi_len,
-                      d_labels, nullptr, nullptr, 0, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
+                      d_labels, nullptr, 0, 0, nullptr, 0, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
 }
 
 extern "C" int mg_roi_segment_reduce(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h,
-                                     int w, const int32_t* d_beads, const int32_t* d_marker_assay,
-                                     const int32_t* d_assay_offsets, int n_assays, int m, int roi_len,
+                                     int w, const int32_t* d_beads, const int32_t* d_assay_offsets, int n_assays,
+                                     int max_per_assay, int m, int roi_len,
                                      const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
                                      double* d_sums, int32_t* d_counts, void* stream) {
-  if (!d_marker_assay || !d_assay_offsets || !d_halfwidths || n_assays <= 0 || max_r < 0) return MG_EINVAL;
-  return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, nullptr, m, roi_len,
-                      nullptr, d_assay_offsets, d_halfwidths, max_r, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
+  if (!d_assay_offsets || !d_halfwidths || n_assays <= 0 || n_assays > 65535 || max_per_assay < 0 || max_r < 0)
+    return MG_EINVAL;
+  if (max_per_assay == 0) return MG_OK;
+  return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, nullptr, nullptr, m, roi_len, nullptr,
+                      d_assay_offsets, n_assays, max_per_assay, d_halfwidths, max_r, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
 }
 
 extern "C" int mg_roi_gather_reduce(const void* d_image, int dtype, int n_c, int n_t, int h, int w,

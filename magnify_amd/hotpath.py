@@ -597,15 +597,15 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
             assay[lo:hi] = k
             local[lo:hi] = np.arange(hi - lo)
     d_beads = torch.from_numpy(beads).to(dev)
-    d_assay = torch.from_numpy(assay).to(dev)
     if disks:
         max_r = max(int(beads[:, 2].max()), 2)
         tab = _halfwidth_table(max_r, dev)
         d_off = torch.from_numpy(offsets.astype(np.int32)).to(dev)
         _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
-              d_beads.data_ptr(), d_assay.data_ptr(), d_off.data_ptr(), a, m, L, tab.data_ptr(), max_r,
+              d_beads.data_ptr(), d_off.data_ptr(), a, int(max(sizes)), m, L, tab.data_ptr(), max_r,
               _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
         return res
+    d_assay = torch.from_numpy(assay).to(dev)
     d_local = torch.from_numpy(local).to(dev)
     _call("mg_roi_gather_reduce_batched", 
         images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w, d_beads.data_ptr(),

@@ -393,7 +393,7 @@ def test_roi_segment_reduce_from_disks(hp, dtype, L):
     rng = np.random.default_rng(33)
     c, t, h, w = 2, 2, 180, 220
     images = rng.integers(0, 250, size=(3, c, t, h, w)).astype(dtype)
-    crowded = np.column_stack([rng.integers(40, 140, 60), rng.integers(40, 180, 60), rng.integers(2, 12, 60)])
+    crowded = np.column_stack([rng.integers(40, 140, 150), rng.integers(40, 180, 150), rng.integers(2, 12, 150)])  # > 96 disks per window: overflow path
     assays = [
         np.array([[20, 20, 8], [5, 190, 6], [150, 100, 10], [80, 80, 9], [84, 92, 9], [179, 0, 5], [33, 57, 6],
                   [121, 143, 7], [-3, 100, 6], [90, 224, 7], [80, 84, 25]]),
