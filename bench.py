@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--num-iter", type=int, default=5_000_000)
     ap.add_argument("--plane-batch", type=int, default=0, help="searched planes per kernel batch (0 = all)")
     ap.add_argument("--streams", type=int, default=4, help="detection sub-batches on separate HIP streams")
+    ap.add_argument("--sub-batches", type=int, default=0, help="sub-batches of assays (0 = one per stream)")
     ap.add_argument("--cpu-assays-per-core", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -119,7 +120,7 @@ def main():
     flat = torch.from_numpy(flat_np).to(dev)
     proc = StackProcessor(T, C, S, S, num_iter=args.num_iter, min_bead_diameter=10, max_bead_diameter=50,
                           search_channels=(0,), mode="P", plane_batch=args.plane_batch or None, device=dev,
-                          n_streams=args.streams)
+                          n_streams=args.streams, sub_batches=args.sub_batches or None)
 
     def step(seed):
         out = proc(stack, flat, 100.0, seed=seed)
@@ -158,16 +159,22 @@ def main():
     if rank == 0:
         # workload numbers for the algorithmic-byte table (last step, rank 0)
         f = proc.finder
-        finders = getattr(proc, "finders", [f]) if proc.n_streams > 1 else [f]
-        unique = int(sum(x.num_circles.sum().item() for x in finders))
-        alive = int(sum(x.num_alive.sum().item() for x in finders))
+        if proc.n_streams > 1:  # one record per (sub-batch, search channel) of the last step
+            dev_counts = torch.stack([x[0] for x in proc.step_stats]).sum(dim=0).tolist()
+            unique, alive, scored = (int(v) for v in dev_counts)
+            edges = sum(x[1] for x in proc.step_stats)
+            fstats = [x[2] for x in proc.step_stats]
+            search_planes = proc.n_assays * len(proc.search_channels)
+        else:
+            unique, alive, scored = int(f.num_circles.sum().item()), int(f.num_alive.sum().item()), int(f.num_scored.sum().item())
+            edges, fstats, search_planes = int(f.n_edges_host.sum()), [f.stats], f.P
         per_starts = f.per_starts.cpu().numpy()
         mean_perimeter = float(np.mean(np.diff(per_starts)))
-        p = {"h": S, "w": S, "n_c": C, "n_t": T, "search_planes": sum(x.P for x in finders), "num_iter": args.num_iter,
-             "hist_passes": max(x.stats.get("hist_passes", 1) for x in finders),
-             "sweeps": max(x.stats.get("hysteresis_sweeps", 1) for x in finders),
-             "nms_rounds": max(x.stats.get("nms_rounds", 1) for x in finders),
-             "edges": int(sum(x.n_edges_host.sum() for x in finders)), "bitmap_words": f.bitmap_words, "unique": unique, "alive": alive,
+        p = {"h": S, "w": S, "n_c": C, "n_t": T, "search_planes": search_planes, "num_iter": args.num_iter,
+             "hist_passes": max(x.get("hist_passes", 1) for x in fstats),
+             "sweeps": max(x.get("hysteresis_sweeps", 1) for x in fstats),
+             "nms_rounds": max(x.get("nms_rounds", 1) for x in fstats),
+             "edges": edges, "bitmap_words": f.bitmap_words, "unique": unique, "alive": alive,
              "mean_perimeter": mean_perimeter, "ring_len": len(hp.nat.circle_points(proc.min_r, True)),
              "markers": markers_local, "mean_disk": 600, "L": proc.L}
         total_ms = sum(v[0] for v in stages.values())
@@ -195,7 +202,7 @@ def main():
                          "mg_canny_nms", "mg_canny_hysteresis", "mg_edge_grid", "mg_edge_angles", "mg_circle_labels",
                          "mg_roi_gather_reduce_batched", "mg_roi_segment_reduce"]
         stream_ms = sum(stages[s][0] for s in stream_stages if s in stages) / args.steps
-        n_all, n_s = T * C * S * S, sum(x.P for x in finders) * S * S
+        n_all, n_s = T * C * S * S, search_planes * S * S
         # SURVEY.md 8d's count minus the label map this build no longer writes (4 B/px of the searched
         # planes) or reads (4 B per window pixel): masks come straight from the bead tables
         stream_bytes = 6 * n_all + 8 * n_s + markers_local * proc.L**2 * (4 * C + 2)
@@ -214,8 +221,8 @@ def main():
                                "achieved_GBs": stream_bytes / (stream_ms / 1e3) / 1e9 if stream_ms else None,
                                "frac_of_peak": stream_bytes / (stream_ms / 1e3) / 1e9 / HBM_PEAK_GBS if stream_ms else None},
             "stages": breakdown,
-            "stats": {"unique_circles": unique, "scored_exactly": int(sum(x.num_scored.sum().item() for x in finders)),
-                      "streams": proc.n_streams,
+            "stats": {"unique_circles": unique, "scored_exactly": scored,
+                      "streams": proc.n_streams, "sub_batches": len(getattr(proc, "ranges", [0])),
                       "alive_circles": alive, "edges": p["edges"],
                       "hysteresis_sweeps": p["sweeps"], "nms_rounds": p["nms_rounds"],
                       "kernel_ms_per_step": total_ms / args.steps},

@@ -28,6 +28,27 @@ __device__ __forceinline__ uint32_t draw32(uint64_t seed, uint64_t it, uint32_t 
   return (uint32_t)(z >> 32);
 }
 
+// The finaliser alone: draw32(seed, it, k) == mix_top32(seed + (3 it + k + 1) * golden).
+constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ull;
+__device__ __forceinline__ uint32_t mix_top32(uint64_t z) {
+  z ^= z >> 30;
+  z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27;
+  z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+
+// floor(x / d) for an integer-valued double 0 <= x < 2^52 and d < 2^31 with floor(x / d) < 2^32:
+// float64 only (full rate), no 64-bit integer multiply.  r = x - q d is exact (a small integer).
+__device__ __forceinline__ uint32_t div_f64(double x, double d, double inv_d) {
+  uint32_t q = (uint32_t)(x * inv_d);
+  const double r = fma(-(double)q, d, x);
+  if (r < 0.0) --q;
+  else if (r >= d) ++q;
+  return q;
+}
+
 // floor(n / d) for n < 2^52 via a float64 reciprocal and one correction step (exact).
 __device__ __forceinline__ uint64_t div_u64(uint64_t n, uint64_t d, double inv_d) {
   uint64_t q = (uint64_t)((double)n * inv_d);
@@ -41,6 +62,8 @@ __device__ __forceinline__ uint64_t div_u64(uint64_t n, uint64_t d, double inv_d
 }
 
 // ---- K7: candidate circles --------------------------------------------------------------------
+// FAST: num_iter < 2^31 and h, w <= 65536 and grid > 1 (checked by the launcher).
+template <bool FAST>
 __global__ __launch_bounds__(NT) void k_candidates(const int32_t* __restrict__ d_coords, int64_t coord_cap,
                                                    const int32_t* __restrict__ d_starts,
                                                    const int32_t* __restrict__ d_counts,
@@ -60,18 +83,36 @@ __global__ __launch_bounds__(NT) void k_candidates(const int32_t* __restrict__ d
   uint32_t* bitmap = d_bitmap + (int64_t)plane * bitmap_words;
   const double eps = (double)1e-20f;
   const double inv_iter = 1.0 / (double)num_iter;
-  for (int64_t it = (int64_t)blockIdx.x * NT + threadIdx.x; it < num_iter; it += (int64_t)gridDim.x * NT) {
+  // strength-reduced bookkeeping (same values as draw32 / floor(it E / K), fewer quarter-rate
+  // integer multiplies): the RNG counter advances by a constant per loop trip; E = eq K + er splits
+  // the stratum bound into a 32-bit product and a float64 quotient; cells by a magic multiply
+  const int64_t it0 = (int64_t)blockIdx.x * NT + threadIdx.x, stride = (int64_t)gridDim.x * NT;
+  uint64_t zbase = seed + ((uint64_t)it0 * 3ull + 1ull) * GOLDEN;
+  const uint64_t zstep = (uint64_t)stride * 3ull * GOLDEN;
+  constexpr bool small = FAST, gfast = FAST;
+  const uint32_t eq = small ? n_edges / (uint32_t)num_iter : 0u;
+  const double er = small ? (double)(n_edges - eq * (uint32_t)num_iter) : 0.0, dk = (double)num_iter;
+  const uint32_t gmagic = grid > 1 ? 0xFFFFFFFFu / (uint32_t)grid + 1u : 0u;  // exact for operands < 2^16
+  for (int64_t it = it0; it < num_iter; it += stride, zbase += zstep) {
     // jittered stratified p0: iteration it owns the slice [a, b) of the cell-major edge list
-    const uint64_t sa = div_u64((uint64_t)it * n_edges, (uint64_t)num_iter, inv_iter);
-    const uint64_t sb = div_u64(((uint64_t)it + 1) * n_edges, (uint64_t)num_iter, inv_iter);
+    uint64_t sa, sb;
+    if (small) {
+      const double x = (double)(uint32_t)it * er;  // exact: < 2^52
+      sa = (uint64_t)((uint32_t)it * eq + div_f64(x, dk, inv_iter));
+      sb = (uint64_t)(((uint32_t)it + 1u) * eq + div_f64(x + er, dk, inv_iter));
+    } else {
+      sa = div_u64((uint64_t)it * n_edges, (uint64_t)num_iter, inv_iter);
+      sb = div_u64(((uint64_t)it + 1) * n_edges, (uint64_t)num_iter, inv_iter);
+    }
     const uint64_t width = sb > sa ? sb - sa : 1;
-    const uint32_t u0 = (uint32_t)(sa + (((uint64_t)draw32(seed, (uint64_t)it, 0) * width) >> 32));
+    const uint32_t u0 = (uint32_t)(sa + (((uint64_t)mix_top32(zbase) * width) >> 32));
     const int p0r = coords[2 * (int64_t)u0], p0c = coords[2 * (int64_t)u0 + 1];
-    const int cell = (p0r / grid) * gc + (p0c / grid);
+    const int cell = gfast ? (int)(__umulhi((uint32_t)p0r, gmagic) * (uint32_t)gc + __umulhi((uint32_t)p0c, gmagic))
+                           : (p0r / grid) * gc + (p0c / grid);
     const uint32_t cnt = (uint32_t)counts[cell];
     const int64_t base = starts[cell];
-    const int64_t i1 = base + (int64_t)(((uint64_t)draw32(seed, (uint64_t)it, 1) * cnt) >> 32);
-    const int64_t i2 = base + (int64_t)(((uint64_t)draw32(seed, (uint64_t)it, 2) * cnt) >> 32);
+    const int64_t i1 = base + (int64_t)__umulhi(mix_top32(zbase + GOLDEN), cnt);
+    const int64_t i2 = base + (int64_t)__umulhi(mix_top32(zbase + 2ull * GOLDEN), cnt);
     // p0-centred integer coordinates (utils.py:319-321); the slope numerator is negated as an
     // integer (as the reference does), so a zero stays +0.0
     const int d1r = coords[2 * i1] - p0r, d1c = coords[2 * i1 + 1] - p0c;
@@ -203,7 +244,9 @@ __device__ __forceinline__ uint32_t bits_at(const uint32_t* __restrict__ bits, i
 
 constexpr int CHUNK = 1024;  // circles per prefilter/exact round (bounds the LDS survivor list)
 
+template <bool QA>
 __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_angle,
+                                                    const uint8_t* __restrict__ d_qangle,
                                                     const uint32_t* __restrict__ d_bits, int64_t words_per_plane,
                                                     int h, int w, const int32_t* __restrict__ d_circles,
                                                     int64_t circle_cap, const int32_t* __restrict__ d_layer_offsets,
@@ -228,7 +271,14 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
   uint32_t* win = lds;                                    // [side][wpr]
   int32_t* tab = reinterpret_cast<int32_t*>(lds + side * wpr);  // packed (dr << 16) | (dc & 0xFFFF)
   int32_t* list = tab + per_total;                        // [CHUNK]
+  // QA: window of the 8-bit quantised gradient direction (angle mod pi in units of pi / 256) and the
+  // same quantisation of every perimeter point's expected angle
+  int qsh = 0;
+  while ((1 << qsh) < side + 3) ++qsh;                    // bytes per window row, a power of two
+  uint8_t* qwin = reinterpret_cast<uint8_t*>(list + CHUNK);  // [side][1 << qsh], column 0 = pixel qx0
+  uint8_t* qexp = qwin + (QA ? (side << qsh) : 0);        // [per_total]
   const int wy0 = (tile / ntc) * TS - 2 * max_r, wx0 = (tile % ntc) * TS - 2 * max_r;
+  const int qx0 = wx0 & ~3;
   const uint32_t* bits = d_bits + plane * words_per_plane;
   for (int i = threadIdx.x; i < side * wpr; i += NT) {
     const int j = i >> wsh, k = i & (wpr - 1);
@@ -240,7 +290,37 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
     }
     win[i] = v;
   }
-  for (int i = threadIdx.x; i < per_total; i += NT) tab[i] = (d_per_rc[2 * i] << 16) | (d_per_rc[2 * i + 1] & 0xFFFF);
+  for (int i = threadIdx.x; i < per_total; i += NT) {
+    tab[i] = (d_per_rc[2 * i] << 16) | (d_per_rc[2 * i + 1] & 0xFFFF);
+    if (QA) qexp[i] = mg_angle_bin(d_per_expected[i]) >> 1;
+  }
+  if (QA) {
+    __syncthreads();  // the edge-bit window is complete
+    // one byte per window pixel: the direction bin halved to 7 bits (units of pi / 128), or 0x80 where
+    // the pixel is not an edge -- the prefilter then needs a single LDS read per perimeter point
+    const uint8_t* qa = d_qangle + (int64_t)plane * h * w;
+    const int dpr = (1 << qsh) >> 2;  // dwords per window row
+    const bool aligned = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(qa) & 3) == 0;
+    for (int i = threadIdx.x; i < side * dpr; i += NT) {
+      const int j = i / dpr, k = i - j * dpr;
+      const int y = wy0 + j, x = qx0 + 4 * k;
+      uint32_t v = 0x80808080u;
+      if (y >= 0 && y < h && x < w && x + 3 >= 0 && x < wx0 + side) {
+        uint32_t raw = 0;
+        if (aligned && x >= 0 && x + 4 <= w) raw = *reinterpret_cast<const uint32_t*>(qa + (int64_t)y * w + x);
+        else
+          for (int b = 0; b < 4; ++b)
+            if (x + b >= 0 && x + b < w) raw |= (uint32_t)qa[(int64_t)y * w + x + b] << (8 * b);
+        v = 0;
+        for (int b = 0; b < 4; ++b) {
+          const int wx = x + b - wx0;  // window column
+          const uint32_t e = (wx >= 0 && wx < side) ? (win[(j << wsh) + (wx >> 5)] >> (wx & 31)) & 1u : 0u;
+          v |= (e ? ((raw >> (8 * b + 1)) & 0x7Fu) : 0x80u) << (8 * b);
+        }
+      }
+      reinterpret_cast<uint32_t*>(qwin)[(j << (qsh - 2)) + k] = v;
+    }
+  }
   __syncthreads();
   const int32_t* circles = d_circles + (int64_t)plane * circle_cap * 3;
   const float* ang = d_angle + (int64_t)plane * h * w;
@@ -253,13 +333,58 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
       const int row = circles[3 * i], col = circles[3 * i + 1], rad = circles[3 * i + 2];
       const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
       const int len = p1 - p0;
-      // need: hits >= min_roundness * len - 1e-3 (margin far above any rounding of the real sum)
-      const int need = (int)ceil((double)min_roundness * len - 1e-3);
       const int by = row - wy0, bx = col - wx0;
+      int hits, need;
+      if (QA) {
+        // Upper bound of the score from the quantised directions, in units of 1/32: an edge pixel on
+        // the perimeter contributes at most 32 - max(fold - 2, 0), fold = distance (in bins of pi/128)
+        // of (angle - expected) mod pi from 0 -- the term is 1 - 4 delta / pi = 1 - fold / 32 for the
+        // folded delta, both angles are known to one bin, and one more bin covers every rounding.
+        // need: sum >= 32 (min_roundness * len - 1e-3).  Non-edge pixels (0x80) contribute 0.
+        need = (int)ceil(32.0 * ((double)min_roundness * len - 1e-3));
+        const int qbx = col - qx0;
+#define MG_UB(pp, yy, xx)                                                      \
+  do {                                                                         \
+    const int q_ = qwin[((by + (yy)) << qsh) + qbx + (xx)];                    \
+    const int k_ = (q_ - (int)qexp[pp]) & 127;                                 \
+    const int c_ = 32 - max(min(k_, 128 - k_) - 2, 0);                         \
+    hits += (q_ & 0x80) ? 0 : c_;                                              \
+  } while (0)
+        hits = 0;
+        MG_UB(p0, 0, -rad);
+        MG_UB(p0 + 1, -rad, 0);
+        MG_UB(p0 + 2, 0, rad);
+        MG_UB(p0 + 3, rad, 0);
+        int p = p0 + 4;
+        for (; p + 8 <= p1; p += 8) {
+          const int v = tab[p];
+          const int x = v >> 16, y = (int)(int16_t)(v & 0xFFFF);  // entry (dr, dc) = (x, y)
+          MG_UB(p, x, y);
+          MG_UB(p + 1, y, x);
+          MG_UB(p + 2, -x, y);
+          MG_UB(p + 3, -y, x);
+          MG_UB(p + 4, x, -y);
+          MG_UB(p + 5, y, -x);
+          MG_UB(p + 6, -x, -y);
+          MG_UB(p + 7, -y, -x);
+          if (hits + 32 * (p1 - p - 8) < need) break;  // cannot get there any more
+        }
+        if (p + 4 == p1) {
+          const int v = tab[p];
+          const int x = v >> 16, y = (int)(int16_t)(v & 0xFFFF);
+          MG_UB(p, x, y);
+          MG_UB(p + 1, -x, -y);
+          MG_UB(p + 2, -x, y);
+          MG_UB(p + 3, x, -y);
+        }
+#undef MG_UB
+      } else {
+      // need: hits >= min_roundness * len - 1e-3 (margin far above any rounding of the real sum)
+      need = (int)ceil((double)min_roundness * len - 1e-3);
 #define MG_BIT(yy, xx) ((win[((by + (yy)) << wsh) + ((bx + (xx)) >> 5)] >> ((bx + (xx)) & 31)) & 1u)
       // The midpoint circle is emitted as 4 axis points, groups of 8 symmetric points sharing one
       // (x, y), and possibly 4 diagonal points (utils.py:441-464): one table read per group.
-      int hits = MG_BIT(0, -rad) + MG_BIT(-rad, 0) + MG_BIT(0, rad) + MG_BIT(rad, 0);
+      hits = MG_BIT(0, -rad) + MG_BIT(-rad, 0) + MG_BIT(0, rad) + MG_BIT(rad, 0);
       int p = p0 + 4;
       for (; p + 8 <= p1; p += 8) {
         const int v = tab[p];
@@ -274,6 +399,7 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
         hits += MG_BIT(x, y) + MG_BIT(-x, -y) + MG_BIT(-x, y) + MG_BIT(x, -y);
       }
 #undef MG_BIT
+      }
       if (hits >= need) {
         list[atomicAdd(&n_surv, 1)] = (int32_t)(i - chunk);
       } else if (write_skipped) {
@@ -473,7 +599,9 @@ extern "C" int mg_candidate_circles(const int32_t* d_coords, int64_t coord_cap, 
   if (bitmap_words < need_words_) return MG_EINVAL;
   if (n_planes == 0 || num_iter == 0) return MG_OK;
   const int gr = (h + grid - 1) / grid, gc = (w + grid - 1) / grid;
-  hipLaunchKernelGGL(k_candidates, dim3(grid_x(num_iter), n_planes), dim3(NT), 0, mg_stream(stream), d_coords,
+  const bool fast = num_iter < (1ll << 31) && grid > 1 && h <= 65536 && w <= 65536;
+  hipLaunchKernelGGL(fast ? k_candidates<true> : k_candidates<false>, dim3(grid_x(num_iter), n_planes), dim3(NT), 0,
+                     mg_stream(stream), d_coords,
                      coord_cap, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gc, gr * gc, d_seeds, num_iter,
                      min_r, max_r, d_bitmap, bitmap_words, d_raw);
   MG_CHECK_LAUNCH();
@@ -516,7 +644,8 @@ extern "C" int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, in
   return MG_OK;
 }
 
-extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, int64_t words_per_plane,
+extern "C" int mg_score_circles(const float* d_angle, const uint8_t* d_qangle, const uint32_t* d_edge_bits,
+                                int64_t words_per_plane,
                                 int n_planes, int h, int w, const int32_t* d_circles, int64_t circle_cap,
                                 const int32_t* d_layer_offsets, int min_r, int max_r, const int32_t* d_per_rc,
                                 const double* d_per_expected, const int32_t* d_per_starts, int per_total,
@@ -534,17 +663,22 @@ extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bit
   int wpr = 1;
   while (32 * wpr < side) wpr <<= 1;
   if (h >= (1 << 24) || w >= (1 << 24) || (int64_t)h * w >= (1LL << 31)) return MG_EINVAL;
-  const size_t lds_bytes = ((size_t)side * wpr + per_total + CHUNK) * 4;
+  int qrow = 1;
+  while (qrow < side + 3) qrow <<= 1;
+  const size_t lds_bytes = ((size_t)side * wpr + per_total + CHUNK) * 4 +
+                           (d_qangle ? (size_t)side * qrow + (((size_t)per_total + 3) & ~(size_t)3) : 0);
   if (lds_bytes > 150 * 1024) return MG_EINVAL;  // radii beyond ~300 px: outside this build's envelope
   static bool attr_set = false;
   if (lds_bytes > 48 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_tiles), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            150 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_tiles<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_tiles<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
       return MG_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_score_tiles, dim3(ntr * ntc, n_planes), dim3(NT), lds_bytes, mg_stream(stream), d_angle,
-                     d_edge_bits, words_per_plane, h, w, d_circles, circle_cap, d_layer_offsets, (int)n_layers,
+  hipLaunchKernelGGL(d_qangle ? k_score_tiles<true> : k_score_tiles<false>, dim3(ntr * ntc, n_planes), dim3(NT),
+                     lds_bytes, mg_stream(stream), d_angle, d_qangle, d_edge_bits, words_per_plane, h, w, d_circles, circle_cap, d_layer_offsets, (int)n_layers,
                      max_r - min_r + 1, ntc, min_r, max_r, d_per_rc, per_total, d_per_expected, d_per_starts,
                      min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc, d_num_scored);
   MG_CHECK_LAUNCH();

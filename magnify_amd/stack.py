@@ -24,7 +24,8 @@ class StackProcessor:
 
     def __init__(self, n_t, n_c, h, w, dtype=torch.uint16, min_bead_diameter=10, max_bead_diameter=50,
                  low_edge_quantile=0.1, high_edge_quantile=0.9, num_iter=5_000_000, min_roundness=0.3,
-                 roi_length=None, search_channels=(0,), mode="P", plane_batch=None, device="cuda", n_streams=1):
+                 roi_length=None, search_channels=(0,), mode="P", plane_batch=None, device="cuda", n_streams=1,
+                 sub_batches=None):
         hp.require_gpu()
         if min_bead_diameter > max_bead_diameter:
             raise ValueError("min_bead_diameter must be <= max_bead_diameter.")
@@ -39,16 +40,23 @@ class StackProcessor:
         self.dev = torch.device(device)
         self.n_assays = n_t if mode == "P" else 1
         self.n_streams = n_streams if (self.n_assays >= 2 * n_streams and not plane_batch) else 1
+        self.step_stats = []  # per sub-batch (device counters, host counters) of the last call
         if self.n_streams > 1:
-            # detection runs as n_streams contiguous sub-batches, each on its own HIP stream and host
-            # thread: one sub-batch's latency-bound tails and host checks overlap the other's kernels
-            per = -(-self.n_assays // self.n_streams)
-            self.ranges = [(i, min(i + per, self.n_assays)) for i in range(0, self.n_assays, per)]
-            self.finders = [hp.CircleFinder(b - a, h, w, self.min_r, self.max_r, num_iter, device=device)
-                            for a, b in self.ranges]
-            self.streams = [torch.cuda.Stream(device=device) for _ in self.ranges]
+            # The stack is cut into contiguous sub-batches of assays; HIP stream / host thread k works
+            # through sub-batches k, k + n_streams, ...: flat-field (mode P: every assay has its own
+            # maxima, so sub-batches are independent) then detection.  One sub-batch's bandwidth-bound
+            # flat-field and its latency-bound tails (hysteresis sweeps, suppression rounds, host
+            # convergence checks) overlap the other streams' kernels.
+            divisors = [d for d in range(1, self.n_assays + 1) if self.n_assays % d == 0]
+            self.n_streams = max(d for d in divisors if d <= self.n_streams)
+            n_sub = max([d for d in divisors if self.n_streams <= d <= (sub_batches or self.n_streams)] or [self.n_streams])
+            per = self.n_assays // n_sub
+            self.ranges = [(i, i + per) for i in range(0, self.n_assays, per)]
+            self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n_streams)]
+            self.finders = [hp.CircleFinder(per, h, w, self.min_r, self.max_r, num_iter, device=device)
+                            for _ in range(self.n_streams)]
             self.finder = self.finders[0]
-            self.batch = self.ranges[0][1] - self.ranges[0][0]
+            self.batch = per
         else:
             self.batch = min(self.n_assays, plane_batch or self.n_assays)
             self.finder = hp.CircleFinder(self.batch, h, w, self.min_r, self.max_r, num_iter, device=device)
@@ -89,31 +97,42 @@ class StackProcessor:
                 done = lo + self.batch
         return beads
 
-    def _detect_streams(self, seed, beads):
+    def _detect_streams(self, seed, beads, stack=None, flatfield=1.0, darkfield=0.0):
+        """Detection (and, when ``stack`` is given, the flat-field pass) of every sub-batch on the
+        streams' host threads.  Results are identical to the single-stream path."""
         import threading
 
         main = torch.cuda.current_stream()
         errors = []
+        self.step_stats = []
+        T, C, h, w = self.T, self.C, self.h, self.w
+        tiles = stack.view(T * C, 1, 1, 1, h, w) if stack is not None else None
 
-        def work(idx):
+        def work(k):
             try:
-                lo, hi = self.ranges[idx]
-                stream = self.streams[idx]
-                stream.wait_stream(main)  # the flat-field pass ran on the caller's stream
+                stream = self.streams[k]
+                stream.wait_stream(main)  # the caller's stream produced the stack / the flat-field pass
                 with torch.cuda.stream(stream):
-                    for k, ch in enumerate(self.search_channels):
-                        planes = self.image[lo:hi, ch]
-                        mm = self.minmax[lo:hi, ch].contiguous()
-                        seeds = [(seed + 1000003 * a + 7919 * k) & 0xFFFFFFFFFFFFFFFF for a in range(lo, hi)]
-                        res, _ = self.finders[idx].find(planes, mm, self.low_q, self.high_q, self.min_roundness,
-                                                        self.min_r, seeds)
-                        for j, a in enumerate(range(lo, hi)):
-                            beads[a] = np.concatenate([beads[a], dedup_against(beads[a], res[j][0], 2 * self.min_r)])
+                    for lo, hi in self.ranges[k :: self.n_streams]:
+                        if tiles is not None:
+                            hp.flatfield_stitch(tiles[lo * C : hi * C], 0, flatfield, darkfield, out=self.image[lo:hi],
+                                                minmax_out=self.minmax[lo:hi], n_groups=hi - lo)
+                        for j, ch in enumerate(self.search_channels):
+                            planes = self.image[lo:hi, ch]
+                            mm = self.minmax[lo:hi, ch].contiguous()
+                            seeds = [(seed + 1000003 * a + 7919 * j) & 0xFFFFFFFFFFFFFFFF for a in range(lo, hi)]
+                            res, _ = self.finders[k].find(planes, mm, self.low_q, self.high_q, self.min_roundness,
+                                                          self.min_r, seeds)
+                            for i, a in enumerate(range(lo, hi)):
+                                beads[a] = np.concatenate([beads[a], dedup_against(beads[a], res[i][0], 2 * self.min_r)])
+                            f = self.finders[k]
+                            self.step_stats.append((torch.stack([f.num_circles.sum(), f.num_alive.sum(), f.num_scored.sum()]),
+                                                    int(f.n_edges_host.sum()), dict(f.stats)))
                 main.wait_stream(stream)
             except Exception as exc:  # surfaced on the caller's thread
                 errors.append(exc)
 
-        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(self.ranges))]
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(self.n_streams)]
         for t in threads:
             t.start()
         for t in threads:
@@ -133,8 +152,12 @@ class StackProcessor:
         return hp.roi_gather_reduce(images, beads, self.L, None, want_roi=want_roi, reuse_buffers=True, disks=True)
 
     def __call__(self, stack, flatfield=1.0, darkfield=0.0, seed=0, want_roi=True):
-        self.flatfield(stack, flatfield, darkfield)
-        beads = self.detect(seed)
+        if self.n_streams > 1 and self.mode == "P":
+            beads = [np.empty((0, 3), dtype=np.int32) for _ in range(self.n_assays)]
+            beads = self._detect_streams(seed, beads, stack, flatfield, darkfield)  # flat-field per sub-batch
+        else:
+            self.flatfield(stack, flatfield, darkfield)
+            beads = self.detect(seed)
         out = self.segment_reduce(beads, want_roi=want_roi)
         out["beads"] = beads
         return out

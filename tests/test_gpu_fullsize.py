@@ -65,10 +65,13 @@ def test_streamed_detection_is_identical(mg):
 
     stack, _ = synthetic_stack(6, 2, 512, 640, seed=77)
     outs = []
-    for n_streams in (1, 2, 3):
-        proc = StackProcessor(6, 2, 512, 640, num_iter=100000, search_channels=(0, 1), mode="P", n_streams=n_streams)
+    for n_streams, sub in ((1, None), (2, None), (3, None), (2, 6), (3, 6)):
+        proc = StackProcessor(6, 2, 512, 640, num_iter=100000, search_channels=(0, 1), mode="P", n_streams=n_streams,
+                              sub_batches=sub)
         outs.append(proc(stack, 0.9, 100.0, seed=5))
         assert proc.n_streams == n_streams
+        if n_streams > 1:
+            assert len(proc.ranges) == (sub or n_streams)
     for other in outs[1:]:
         for a, b in zip(outs[0]["beads"], other["beads"]):
             np.testing.assert_array_equal(a, b)
