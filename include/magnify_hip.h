@@ -151,11 +151,9 @@ int mg_edge_grid(const uint32_t* d_edge_bits, int64_t words_per_plane, int n_pla
 
 /* float32 gradient angle arctan2(dy, dx) (utils.py:118-119, 170) at every edge pixel of the
  * compact list, evaluated in float64 and rounded once: d_angle[n_planes][h][w] is written at
- * edge pixels only.  d_qangle (optional, uint8 [n_planes][h][w], written at edge pixels only)
- * receives the direction bin floor(((angle mod pi) / pi) * 256) that mg_score_circles' prefilter
- * reads. */
+ * edge pixels only. */
 int mg_edge_angles(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_coords, int64_t coord_cap,
-                   const int32_t* d_num_edges, float* d_angle, uint8_t* d_qangle, void* stream);
+                   const int32_t* d_num_edges, float* d_angle, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * A8-A11 RANSAC circle candidates, scoring, greedy NMS (utils.py:145-199, 225-344)
@@ -194,13 +192,9 @@ int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, int n_planes,
 
 /* mean_grad / len(perimeter) (utils.py:183-188, 225-251), one workgroup per centre tile with the
  * tile's window of the 1-bit edge map staged in LDS.
- * Pass A (exact prefilter): an upper bound of the sum that cannot reach min_roundness * P rules a
- * circle out (it gets MG_SCORE_SKIPPED when write_skipped != 0, else its score is left unwritten).
- * Without d_qangle the bound is the number of edge pixels on the perimeter (every term is <= 1);
- * with d_qangle (mg_edge_angles) every edge pixel contributes 1 - max(fold - 2, 0) / 32, fold = the
- * distance in bins of pi/128 between its (halved) direction bin and the perimeter point's expected
- * direction, modulo pi -- the term is exactly 1 - 4 delta / pi for the folded difference delta, and
- * two bins of slack cover the quantisation of both angles and every rounding.
+ * Pass A (exact prefilter): every term of the sum is <= 1, so circles with fewer than
+ * min_roundness * P edge pixels on their perimeter cannot pass (they get MG_SCORE_SKIPPED when
+ * write_skipped != 0, else their score is left unwritten).
  * Pass B: the reference's float64 sum, sequential in perimeter order, stored float32 and divided
  * by the perimeter length in float32; d_angle holds the gradient angle at edge pixels
  * (mg_edge_angles); per_total = number of entries of the perimeter tables.
@@ -209,8 +203,8 @@ int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, int n_planes,
  * d_max_rc[n_planes][2] (pre-set to INT32_MIN) receives max row / max col of the alive circles
  * (the claim-grid extent of utils.py:268-270).  d_num_scored (optional, [n_planes], pre-zeroed)
  * counts the circles that reached pass B. */
-int mg_score_circles(const float* d_angle, const uint8_t* d_qangle, const uint32_t* d_edge_bits,
-                     int64_t words_per_plane, int n_planes, int h, int w, const int32_t* d_circles, int64_t circle_cap, const int32_t* d_layer_offsets, int min_r,
+int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, int64_t words_per_plane, int n_planes, int h,
+                     int w, const int32_t* d_circles, int64_t circle_cap, const int32_t* d_layer_offsets, int min_r,
                      int max_r, const int32_t* d_per_rc, const double* d_per_expected, const int32_t* d_per_starts,
                      int per_total, float min_roundness, int write_skipped, float* d_scores, int32_t* d_alive,
                      int32_t* d_num_alive, int32_t* d_max_rc, int32_t* d_num_scored, void* stream);

@@ -244,9 +244,7 @@ __device__ __forceinline__ uint32_t bits_at(const uint32_t* __restrict__ bits, i
 
 constexpr int CHUNK = 1024;  // circles per prefilter/exact round (bounds the LDS survivor list)
 
-template <bool QA>
 __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_angle,
-                                                    const uint8_t* __restrict__ d_qangle,
                                                     const uint32_t* __restrict__ d_bits, int64_t words_per_plane,
                                                     int h, int w, const int32_t* __restrict__ d_circles,
                                                     int64_t circle_cap, const int32_t* __restrict__ d_layer_offsets,
@@ -271,14 +269,7 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
   uint32_t* win = lds;                                    // [side][wpr]
   int32_t* tab = reinterpret_cast<int32_t*>(lds + side * wpr);  // packed (dr << 16) | (dc & 0xFFFF)
   int32_t* list = tab + per_total;                        // [CHUNK]
-  // QA: window of the 8-bit quantised gradient direction (angle mod pi in units of pi / 256) and the
-  // same quantisation of every perimeter point's expected angle
-  int qsh = 0;
-  while ((1 << qsh) < side + 3) ++qsh;                    // bytes per window row, a power of two
-  uint8_t* qwin = reinterpret_cast<uint8_t*>(list + CHUNK);  // [side][1 << qsh], column 0 = pixel qx0
-  uint8_t* qexp = qwin + (QA ? (side << qsh) : 0);        // [per_total]
   const int wy0 = (tile / ntc) * TS - 2 * max_r, wx0 = (tile % ntc) * TS - 2 * max_r;
-  const int qx0 = wx0 & ~3;
   const uint32_t* bits = d_bits + plane * words_per_plane;
   for (int i = threadIdx.x; i < side * wpr; i += NT) {
     const int j = i >> wsh, k = i & (wpr - 1);
@@ -290,37 +281,7 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
     }
     win[i] = v;
   }
-  for (int i = threadIdx.x; i < per_total; i += NT) {
-    tab[i] = (d_per_rc[2 * i] << 16) | (d_per_rc[2 * i + 1] & 0xFFFF);
-    if (QA) qexp[i] = mg_angle_bin(d_per_expected[i]) >> 1;
-  }
-  if (QA) {
-    __syncthreads();  // the edge-bit window is complete
-    // one byte per window pixel: the direction bin halved to 7 bits (units of pi / 128), or 0x80 where
-    // the pixel is not an edge -- the prefilter then needs a single LDS read per perimeter point
-    const uint8_t* qa = d_qangle + (int64_t)plane * h * w;
-    const int dpr = (1 << qsh) >> 2;  // dwords per window row
-    const bool aligned = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(qa) & 3) == 0;
-    for (int i = threadIdx.x; i < side * dpr; i += NT) {
-      const int j = i / dpr, k = i - j * dpr;
-      const int y = wy0 + j, x = qx0 + 4 * k;
-      uint32_t v = 0x80808080u;
-      if (y >= 0 && y < h && x < w && x + 3 >= 0 && x < wx0 + side) {
-        uint32_t raw = 0;
-        if (aligned && x >= 0 && x + 4 <= w) raw = *reinterpret_cast<const uint32_t*>(qa + (int64_t)y * w + x);
-        else
-          for (int b = 0; b < 4; ++b)
-            if (x + b >= 0 && x + b < w) raw |= (uint32_t)qa[(int64_t)y * w + x + b] << (8 * b);
-        v = 0;
-        for (int b = 0; b < 4; ++b) {
-          const int wx = x + b - wx0;  // window column
-          const uint32_t e = (wx >= 0 && wx < side) ? (win[(j << wsh) + (wx >> 5)] >> (wx & 31)) & 1u : 0u;
-          v |= (e ? ((raw >> (8 * b + 1)) & 0x7Fu) : 0x80u) << (8 * b);
-        }
-      }
-      reinterpret_cast<uint32_t*>(qwin)[(j << (qsh - 2)) + k] = v;
-    }
-  }
+  for (int i = threadIdx.x; i < per_total; i += NT) tab[i] = (d_per_rc[2 * i] << 16) | (d_per_rc[2 * i + 1] & 0xFFFF);
   __syncthreads();
   const int32_t* circles = d_circles + (int64_t)plane * circle_cap * 3;
   const float* ang = d_angle + (int64_t)plane * h * w;
@@ -333,58 +294,13 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
       const int row = circles[3 * i], col = circles[3 * i + 1], rad = circles[3 * i + 2];
       const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
       const int len = p1 - p0;
-      const int by = row - wy0, bx = col - wx0;
-      int hits, need;
-      if (QA) {
-        // Upper bound of the score from the quantised directions, in units of 1/32: an edge pixel on
-        // the perimeter contributes at most 32 - max(fold - 2, 0), fold = distance (in bins of pi/128)
-        // of (angle - expected) mod pi from 0 -- the term is 1 - 4 delta / pi = 1 - fold / 32 for the
-        // folded delta, both angles are known to one bin, and one more bin covers every rounding.
-        // need: sum >= 32 (min_roundness * len - 1e-3).  Non-edge pixels (0x80) contribute 0.
-        need = (int)ceil(32.0 * ((double)min_roundness * len - 1e-3));
-        const int qbx = col - qx0;
-#define MG_UB(pp, yy, xx)                                                      \
-  do {                                                                         \
-    const int q_ = qwin[((by + (yy)) << qsh) + qbx + (xx)];                    \
-    const int k_ = (q_ - (int)qexp[pp]) & 127;                                 \
-    const int c_ = 32 - max(min(k_, 128 - k_) - 2, 0);                         \
-    hits += (q_ & 0x80) ? 0 : c_;                                              \
-  } while (0)
-        hits = 0;
-        MG_UB(p0, 0, -rad);
-        MG_UB(p0 + 1, -rad, 0);
-        MG_UB(p0 + 2, 0, rad);
-        MG_UB(p0 + 3, rad, 0);
-        int p = p0 + 4;
-        for (; p + 8 <= p1; p += 8) {
-          const int v = tab[p];
-          const int x = v >> 16, y = (int)(int16_t)(v & 0xFFFF);  // entry (dr, dc) = (x, y)
-          MG_UB(p, x, y);
-          MG_UB(p + 1, y, x);
-          MG_UB(p + 2, -x, y);
-          MG_UB(p + 3, -y, x);
-          MG_UB(p + 4, x, -y);
-          MG_UB(p + 5, y, -x);
-          MG_UB(p + 6, -x, -y);
-          MG_UB(p + 7, -y, -x);
-          if (hits + 32 * (p1 - p - 8) < need) break;  // cannot get there any more
-        }
-        if (p + 4 == p1) {
-          const int v = tab[p];
-          const int x = v >> 16, y = (int)(int16_t)(v & 0xFFFF);
-          MG_UB(p, x, y);
-          MG_UB(p + 1, -x, -y);
-          MG_UB(p + 2, -x, y);
-          MG_UB(p + 3, x, -y);
-        }
-#undef MG_UB
-      } else {
       // need: hits >= min_roundness * len - 1e-3 (margin far above any rounding of the real sum)
-      need = (int)ceil((double)min_roundness * len - 1e-3);
+      const int need = (int)ceil((double)min_roundness * len - 1e-3);
+      const int by = row - wy0, bx = col - wx0;
 #define MG_BIT(yy, xx) ((win[((by + (yy)) << wsh) + ((bx + (xx)) >> 5)] >> ((bx + (xx)) & 31)) & 1u)
       // The midpoint circle is emitted as 4 axis points, groups of 8 symmetric points sharing one
       // (x, y), and possibly 4 diagonal points (utils.py:441-464): one table read per group.
-      hits = MG_BIT(0, -rad) + MG_BIT(-rad, 0) + MG_BIT(0, rad) + MG_BIT(rad, 0);
+      int hits = MG_BIT(0, -rad) + MG_BIT(-rad, 0) + MG_BIT(0, rad) + MG_BIT(rad, 0);
       int p = p0 + 4;
       for (; p + 8 <= p1; p += 8) {
         const int v = tab[p];
@@ -399,7 +315,6 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
         hits += MG_BIT(x, y) + MG_BIT(-x, -y) + MG_BIT(-x, y) + MG_BIT(x, -y);
       }
 #undef MG_BIT
-      }
       if (hits >= need) {
         list[atomicAdd(&n_surv, 1)] = (int32_t)(i - chunk);
       } else if (write_skipped) {
@@ -644,8 +559,7 @@ extern "C" int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, in
   return MG_OK;
 }
 
-extern "C" int mg_score_circles(const float* d_angle, const uint8_t* d_qangle, const uint32_t* d_edge_bits,
-                                int64_t words_per_plane,
+extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, int64_t words_per_plane,
                                 int n_planes, int h, int w, const int32_t* d_circles, int64_t circle_cap,
                                 const int32_t* d_layer_offsets, int min_r, int max_r, const int32_t* d_per_rc,
                                 const double* d_per_expected, const int32_t* d_per_starts, int per_total,
@@ -663,22 +577,17 @@ extern "C" int mg_score_circles(const float* d_angle, const uint8_t* d_qangle, c
   int wpr = 1;
   while (32 * wpr < side) wpr <<= 1;
   if (h >= (1 << 24) || w >= (1 << 24) || (int64_t)h * w >= (1LL << 31)) return MG_EINVAL;
-  int qrow = 1;
-  while (qrow < side + 3) qrow <<= 1;
-  const size_t lds_bytes = ((size_t)side * wpr + per_total + CHUNK) * 4 +
-                           (d_qangle ? (size_t)side * qrow + (((size_t)per_total + 3) & ~(size_t)3) : 0);
+  const size_t lds_bytes = ((size_t)side * wpr + per_total + CHUNK) * 4;
   if (lds_bytes > 150 * 1024) return MG_EINVAL;  // radii beyond ~300 px: outside this build's envelope
   static bool attr_set = false;
   if (lds_bytes > 48 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_tiles<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_tiles<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_tiles), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            150 * 1024) != hipSuccess)
       return MG_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(d_qangle ? k_score_tiles<true> : k_score_tiles<false>, dim3(ntr * ntc, n_planes), dim3(NT),
-                     lds_bytes, mg_stream(stream), d_angle, d_qangle, d_edge_bits, words_per_plane, h, w, d_circles, circle_cap, d_layer_offsets, (int)n_layers,
+  hipLaunchKernelGGL(k_score_tiles, dim3(ntr * ntc, n_planes), dim3(NT), lds_bytes, mg_stream(stream), d_angle,
+                     d_edge_bits, words_per_plane, h, w, d_circles, circle_cap, d_layer_offsets, (int)n_layers,
                      max_r - min_r + 1, ntc, min_r, max_r, d_per_rc, per_total, d_per_expected, d_per_starts,
                      min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc, d_num_scored);
   MG_CHECK_LAUNCH();

@@ -126,15 +126,6 @@ __device__ __forceinline__ int mg_block_exscan(int v, int* total) {
   return res;
 }
 
-// Direction bin of an angle: floor(((a mod pi) / pi) * 256) in 0..255 (float64; consumers allow one
-// bin of slack for the rounding of this expression).  The score term of mean_grad (utils.py:246-249)
-// depends on (angle - expected) mod pi only.
-__device__ __forceinline__ uint8_t mg_angle_bin(double a) {
-  double u = a * (1.0 / 3.141592653589793);
-  u -= floor(u);
-  return (uint8_t)((int)(u * 256.0) & 255);
-}
-
 // float32 gradient angle at an edge pixel: Scharr on the blurred image (BORDER_REFLECT_101),
 // arctan2(dy, dx) evaluated in float64 and rounded once (utils.py:118-119, 170).
 __device__ __forceinline__ float mg_edge_angle(const uint8_t* __restrict__ pb, int h, int w, int y, int x) {

@@ -573,18 +573,15 @@ __global__ __launch_bounds__(NT) void k_cell_fill(const uint32_t* __restrict__ d
 __global__ __launch_bounds__(NT) void k_edge_angles(const uint8_t* __restrict__ d_blur, int h, int w,
                                                     const int32_t* __restrict__ d_coords, int64_t coord_cap,
                                                     const int32_t* __restrict__ d_num_edges,
-                                                    float* __restrict__ d_angle, uint8_t* __restrict__ d_qangle) {
+                                                    float* __restrict__ d_angle) {
   const int plane = blockIdx.y;
   const int n = min((int64_t)d_num_edges[plane], coord_cap);
   const uint8_t* pb = d_blur + (int64_t)plane * h * w;
   const int2* co = reinterpret_cast<const int2*>(d_coords + (int64_t)plane * coord_cap * 2);
   float* pa = d_angle + (int64_t)plane * h * w;
-  uint8_t* pq = d_qangle ? d_qangle + (int64_t)plane * h * w : nullptr;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
     const int2 yx = co[i];
-    const float a = mg_edge_angle(pb, h, w, yx.x, yx.y);
-    pa[(int64_t)yx.x * w + yx.y] = a;
-    if (pq) pq[(int64_t)yx.x * w + yx.y] = mg_angle_bin((double)a);
+    pa[(int64_t)yx.x * w + yx.y] = mg_edge_angle(pb, h, w, yx.x, yx.y);
   }
 }
 
@@ -727,14 +724,13 @@ extern "C" int mg_edge_grid(const uint32_t* d_edge_bits, int64_t words_per_plane
 }
 
 extern "C" int mg_edge_angles(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_coords,
-                              int64_t coord_cap, const int32_t* d_num_edges, float* d_angle, uint8_t* d_qangle,
-                              void* stream) {
+                              int64_t coord_cap, const int32_t* d_num_edges, float* d_angle, void* stream) {
   if (!d_blur || !d_coords || !d_num_edges || !d_angle || n_planes < 0 || n_planes > 65535 || coord_cap < 0)
     return MG_EINVAL;
   if (n_planes == 0 || coord_cap == 0) return MG_OK;
   const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((coord_cap + NT - 1) / NT, 4096));
   hipLaunchKernelGGL(k_edge_angles, dim3(bx, n_planes), dim3(NT), 0, mg_stream(stream), d_blur, h, w, d_coords,
-                     coord_cap, d_num_edges, d_angle, d_qangle);
+                     coord_cap, d_num_edges, d_angle);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

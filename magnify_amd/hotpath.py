@@ -270,8 +270,6 @@ class CircleFinder:
         self.blur = torch.empty((P, h, w), dtype=u8, device=dev)
         self.edges = None  # {0,1} byte map, only with keep_debug_maps
         self.angle = torch.empty((P, h, w), dtype=torch.float32, device=dev)  # valid at edge pixels
-        self.qangle = torch.empty((P, h, w), dtype=torch.uint8, device=dev)  # direction bins, edge pixels only
-        self.use_direction_bound = True  # the scoring prefilter's tighter (still exact) upper bound
         self.hist = torch.zeros((P, COMBINED_BINS), dtype=i32, device=dev)
         self.hist_base = torch.zeros((P,), dtype=i32, device=dev)
         self.thresh = torch.zeros((P, 2), dtype=i32, device=dev)
@@ -401,7 +399,7 @@ class CircleFinder:
         _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, P, h, w, self.grid, self.cell_counts.data_ptr(),
               self.cell_starts.data_ptr(), self.num_edges.data_ptr(), self.coords.data_ptr(), self.coord_cap, s)
         _call("mg_edge_angles", self.blur.data_ptr(), P, h, w, self.coords.data_ptr(), self.coord_cap,
-              self.num_edges.data_ptr(), self.angle.data_ptr(), self.qangle.data_ptr(), s)
+              self.num_edges.data_ptr(), self.angle.data_ptr(), s)
         self.n_edges_host = n_edges
         return n_edges
 
@@ -421,8 +419,7 @@ class CircleFinder:
         self.num_alive.zero_()
         self.num_scored.zero_()
         self.max_rc.fill_(-(2**31))
-        _call("mg_score_circles", self.angle.data_ptr(), self.qangle.data_ptr() if self.use_direction_bound else None,
-              self.edge_bits.data_ptr(), self.words, P, h, w,
+        _call("mg_score_circles", self.angle.data_ptr(), self.edge_bits.data_ptr(), self.words, P, h, w,
               self.circles.data_ptr(), self.cap, self.layer_offsets.data_ptr(), self.min_r, self.max_r,
               self.per_rc.data_ptr(), self.per_exp.data_ptr(), self.per_starts.data_ptr(), int(self.per_rc.shape[0]),
               float(min_roundness), int(self.keep_debug_maps), self.scores.data_ptr(), self.alive.data_ptr(),
