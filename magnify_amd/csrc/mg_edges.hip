@@ -368,28 +368,25 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
     if (yo < h) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (gx + q >= w) continue;
+        // Branch-free, and no run-time index into the register arrays (the compiler turns such an
+        // index into a compare/select chain over the whole array: that was half of this kernel).
         const int m = mg[1][q + 1];
-        if (m <= low) continue;
         const int xs = cdx[0][q], ys = cdy[0][q];
         const int x = abs(xs), y = abs(ys) << 15;
         const int tg22x = x * TG22;
-        bool is_max;
-        if (y < tg22x) {
-          is_max = m > mg[1][q] && m >= mg[1][q + 2];
-        } else {
-          const int tg67x = tg22x + (x << 16);
-          if (y > tg67x) {
-            is_max = m > mg[0][q + 1] && m >= mg[2][q + 1];
-          } else {
-            const int s = (xs ^ ys) < 0 ? -1 : 1;
-            is_max = m > mg[0][q + 1 - s] && m > mg[2][q + 1 + s];
-          }
-        }
-        if (is_max) {
-          wb |= 1u << q;
-          if (m > high) sb |= 1u << q;
-        }
+        const int tg67x = tg22x + (x << 16);
+        const bool horiz = y < tg22x;
+        const bool vert = !horiz && y > tg67x;
+        const bool neg = (xs ^ ys) < 0;  // diagonal: s = -1 where the signs differ
+        // previous / next neighbour along the gradient direction
+        const int pd = neg ? mg[0][q + 2] : mg[0][q], nd = neg ? mg[2][q] : mg[2][q + 2];
+        const int pv = horiz ? mg[1][q] : (vert ? mg[0][q + 1] : pd);
+        const int nx = horiz ? mg[1][q + 2] : (vert ? mg[2][q + 1] : nd);
+        // > towards the previous pixel; >= towards the next one on the axes, > on the diagonals
+        const bool is_max = m > pv && (m + ((horiz || vert) ? 1 : 0)) > nx;
+        const bool cand = is_max && m > low && gx + q < w;
+        wb |= (cand ? 1u : 0u) << q;
+        sb |= ((cand && m > high) ? 1u : 0u) << q;
       }
     }
     // 8 lanes x 4 bits -> one 32-bit word
