@@ -181,6 +181,28 @@ int mg_candidate_circles(const int32_t* d_coords, int64_t coord_cap, const int32
                          int grid, const uint64_t* d_seeds, int64_t num_iter, int min_r, int max_r,
                          uint32_t* d_bitmap, int64_t bitmap_words, float* d_raw, void* stream);
 
+/* The same candidates WITHOUT global atomics: every iteration stores a 32-bit key into
+ * d_keys[n_planes][num_iter] -- (tile << 17) | ((r - min_r) << 12) | ((pr & 63) << 6) | (pc & 63) with
+ * (pr, pc) = (row + max_r, col + max_r), tile = (pr >> 6) * tile_cols + (pc >> 6) -- or 0xFFFFFFFF when
+ * step 4 of filter_circles rejects it.  Needs tile_rows * tile_cols < 32768 and max_r - min_r < 32
+ * (MG_EINVAL otherwise: use mg_candidate_circles). */
+int mg_candidate_keys(const int32_t* d_coords, int64_t coord_cap, const int32_t* d_cell_starts,
+                      const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w, int grid,
+                      const uint64_t* d_seeds, int64_t num_iter, int min_r, int max_r, uint32_t* d_keys, float* d_raw,
+                      void* stream);
+
+/* Keys -> bitmap -> unique circle list.  Because p0 is a stratified draw over the cell-major edge
+ * list, the iterations that can place a centre in a given 64 x 64 tile form one contiguous key range
+ * per cell row within max_r + 2 of the tile; one workgroup per tile scans them, ORs its own keys into
+ * an LDS copy of the tile's layers, writes the layers (every word of d_bitmap is overwritten: no
+ * pre-zeroing) and their bit counts, then the scan and the ordered emission of mg_bitmap_to_circles
+ * run.  Outputs exactly as mg_bitmap_to_circles.  d_cell_* / d_num_edges / grid / num_iter must be
+ * those the keys were generated with. */
+int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, const int32_t* d_cell_starts,
+                       const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w, int grid,
+                       int min_r, int max_r, uint32_t* d_bitmap, int64_t bitmap_words, int32_t* d_layer_offsets,
+                       int32_t* d_circles, int64_t circle_cap, int32_t* d_num_circles, void* stream);
+
 /* Ordered compaction of the bitmap into the unique circle list in the build's canonical order
  * (tile_row, tile_col, r, row, col): d_circles[n_planes][circle_cap][3] int32 (row, col, r),
  * d_num_circles[n_planes], and d_layer_offsets[n_planes][n_layers + 1] (start of every layer in

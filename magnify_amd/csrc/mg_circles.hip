@@ -30,6 +30,7 @@ __device__ __forceinline__ uint32_t draw32(uint64_t seed, uint64_t it, uint32_t 
 
 // The finaliser alone: draw32(seed, it, k) == mix_top32(seed + (3 it + k + 1) * golden).
 constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ull;
+constexpr uint32_t MG_NO_KEY = 0xFFFFFFFFu;  // candidate rejected by the radius / on-image filter
 __device__ __forceinline__ uint32_t mix_top32(uint64_t z) {
   z ^= z >> 30;
   z *= 0xBF58476D1CE4E5B9ull;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(NT) void k_candidates(const int32_t* __restrict__ d
                                                    int gc, int n_cells, const uint64_t* __restrict__ d_seeds,
                                                    int64_t num_iter, int min_r, int max_r,
                                                    uint32_t* __restrict__ d_bitmap, int64_t bitmap_words,
-                                                   float* __restrict__ d_raw) {
+                                                   float* __restrict__ d_raw, uint32_t* __restrict__ d_keys) {
   const int plane = blockIdx.y;
   const uint32_t n_edges = (uint32_t)d_num_edges[plane];
   if (n_edges == 0) return;
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(NT) void k_candidates(const int32_t* __restrict__ d
   const int32_t* counts = d_counts + (int64_t)plane * n_cells;
   const uint64_t seed = d_seeds[plane];
   const int ntc = (w + 2 * max_r + 63) >> 6, nr = max_r - min_r + 1;
-  uint32_t* bitmap = d_bitmap + (int64_t)plane * bitmap_words;
+  uint32_t* bitmap = d_bitmap ? d_bitmap + (int64_t)plane * bitmap_words : nullptr;
+  uint32_t* keys = d_keys ? d_keys + (int64_t)plane * num_iter : nullptr;
   const double eps = (double)1e-20f;
   const double inv_iter = 1.0 / (double)num_iter;
   // strength-reduced bookkeeping (same values as draw32 / floor(it E / K), fewer quarter-rate
@@ -136,17 +138,25 @@ __global__ __launch_bounds__(NT) void k_candidates(const int32_t* __restrict__ d
       o[2] = rad;
     }
     // filter_circles step 4 (utils.py:157-166)
-    if (!(rad >= (float)min_r && rad <= (float)max_r)) continue;
-    const float rr = rintf(f_row), rc = rintf(f_col);
-    if (!(fabsf(rr) < 1.0e9f && fabsf(rc) < 1.0e9f)) continue;  // cannot be on the image (and NaN)
-    const int ir = (int)rr, ic = (int)rc, irad = (int)rintf(rad);
-    if (ir + irad < 0 || ic + irad < 0 || ir - irad >= h || ic - irad >= w) continue;
-    // tile-major de-duplication bitmap: 64 x 64 tiles of the padded centre grid, one 4096-bit layer
-    // per (tile, radius); the ordered compaction then emits circles grouped by tile
-    const int pr = ir + max_r, pc = ic + max_r;
-    const int64_t layer = ((int64_t)(pr >> 6) * ntc + (pc >> 6)) * nr + (irad - min_r);
-    const int64_t bit = (layer << 12) + ((pr & 63) << 6) + (pc & 63);
-    atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+    uint32_t key = MG_NO_KEY;
+    do {
+      if (!(rad >= (float)min_r && rad <= (float)max_r)) break;
+      const float rr = rintf(f_row), rc = rintf(f_col);
+      if (!(fabsf(rr) < 1.0e9f && fabsf(rc) < 1.0e9f)) break;  // cannot be on the image (and NaN)
+      const int ir = (int)rr, ic = (int)rc, irad = (int)rintf(rad);
+      if (ir + irad < 0 || ic + irad < 0 || ir - irad >= h || ic - irad >= w) break;
+      // tile-major de-duplication: 64 x 64 tiles of the padded centre grid, one 4096-bit layer per
+      // (tile, radius); the ordered compaction then emits circles grouped by tile
+      const int pr = ir + max_r, pc = ic + max_r;
+      const int tile = (pr >> 6) * ntc + (pc >> 6);
+      if (keys) {
+        key = ((uint32_t)tile << 17) | ((uint32_t)(irad - min_r) << 12) | (uint32_t)(((pr & 63) << 6) + (pc & 63));
+      } else {
+        const int64_t bit = (((int64_t)tile * nr + (irad - min_r)) << 12) + ((pr & 63) << 6) + (pc & 63);
+        atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+      }
+    } while (false);
+    if (keys) keys[it] = key;  // coalesced plain store; k_tile_dedup builds the bitmap tile by tile in LDS
   }
 }
 
@@ -166,6 +176,82 @@ __global__ __launch_bounds__(NT) void k_layer_count(const uint32_t* __restrict__
                                                  (int64_t)layer * LAYER_WORDS)[lane];
   const int c = mg_wave_sum_i32(__popc(v.x) + __popc(v.y));
   if (lane == 0) d_layer_offsets[(int64_t)plane * (n_layers + 1) + layer] = c;
+}
+
+// Keyed de-duplication (no global atomics): candidates were written as 32-bit keys
+// (tile << 17 | radius layer << 12 | position in the 64 x 64 tile) in iteration order.  p0 is a
+// stratified draw over the cell-major edge list, so the iterations that can put a centre into a
+// given tile are a handful of contiguous iteration ranges -- one per cell row within reach of the
+// tile.  One workgroup per tile scans those ranges, sets the bits of its own keys in an LDS copy of
+// the tile's layers, counts every layer and stores the layers with plain coalesced stores.
+// (Global atomics execute at the memory side on this chip: 320 M scattered atomicOr cost 3.8 ms of
+// the 6.1 ms candidates kernel.)
+constexpr int MAX_RANGES = 64;
+
+__global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ d_keys, int64_t num_iter,
+                                                   const int32_t* __restrict__ d_starts,
+                                                   const int32_t* __restrict__ d_counts,
+                                                   const int32_t* __restrict__ d_num_edges, int h, int w, int grid,
+                                                   int gr, int gc, int ntc, int nr, int max_r,
+                                                   uint32_t* __restrict__ d_bitmap, int64_t bitmap_words, int n_layers,
+                                                   int32_t* __restrict__ d_layer_offsets) {
+  extern __shared__ uint32_t lbits[];  // [nr][LAYER_WORDS]
+  __shared__ long long s_lo[MAX_RANGES];
+  __shared__ int s_pre[MAX_RANGES + 1];
+  const int plane = blockIdx.y, tile = blockIdx.x;
+  const int words = nr * LAYER_WORDS;
+  for (int i = threadIdx.x; i < words; i += NT) lbits[i] = 0u;
+  const long long n_edges = d_num_edges[plane];
+  const int tr = tile / ntc, tc = tile - tr * ntc;
+  // p0 lies on the circle: within max_r + 1 of the rounded centre (one more for safety)
+  const int reach = max_r + 2;
+  const int y0 = max(tr * TS - max_r - reach, 0), y1 = min(tr * TS + TS - 1 - max_r + reach, h - 1);
+  const int x0 = max(tc * TS - max_r - reach, 0), x1 = min(tc * TS + TS - 1 - max_r + reach, w - 1);
+  int n_ranges = 0;
+  if (n_edges > 0 && y0 <= y1 && x0 <= x1) {
+    const int cr0 = y0 / grid, cr1 = y1 / grid, cc0 = x0 / grid, cc1 = x1 / grid;
+    n_ranges = cr1 - cr0 + 1;  // <= MAX_RANGES (checked by the launcher)
+    if ((int)threadIdx.x < n_ranges) {
+      const int32_t* starts = d_starts + (int64_t)plane * gr * gc;
+      const int32_t* counts = d_counts + (int64_t)plane * gr * gc;
+      const int cr = cr0 + threadIdx.x;
+      const long long ea = starts[cr * gc + cc0], eb = (long long)starts[cr * gc + cc1] + counts[cr * gc + cc1];
+      // iterations whose stratum [floor(i E / K), floor((i + 1) E / K)) can touch [ea, eb): a
+      // conservative superset (keys carry their own tile, foreign ones are skipped)
+      long long lo = 0, hi = 0;
+      if (eb > ea) {
+        const double kpe = (double)num_iter / (double)n_edges;
+        lo = max((long long)((double)ea * kpe) - 2, 0ll);
+        hi = min((long long)((double)eb * kpe) + 3, (long long)num_iter);
+      }
+      s_lo[threadIdx.x] = lo;
+      s_pre[threadIdx.x + 1] = (int)(hi - lo);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_pre[0] = 0;
+    for (int r = 0; r < n_ranges; ++r) s_pre[r + 1] += s_pre[r];
+  }
+  __syncthreads();
+  const int total = n_ranges ? s_pre[n_ranges] : 0;
+  const uint32_t* keys = d_keys + (int64_t)plane * num_iter;
+  for (int i = threadIdx.x; i < total; i += NT) {
+    int r = 0;
+    while (i >= s_pre[r + 1]) ++r;
+    const uint32_t key = keys[s_lo[r] + (i - s_pre[r])];
+    if ((key >> 17) == (uint32_t)tile) atomicOr(&lbits[(key & 0x1FFFFu) >> 5], 1u << (key & 31u));
+  }
+  __syncthreads();
+  // per-layer counts (one wave per layer, as k_layer_count) and the layers themselves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int ri = wave; ri < nr; ri += NT / 64) {
+    const uint2 v = reinterpret_cast<const uint2*>(lbits + ri * LAYER_WORDS)[lane];
+    const int c = mg_wave_sum_i32(__popc(v.x) + __popc(v.y));
+    if (lane == 0) d_layer_offsets[(int64_t)plane * (n_layers + 1) + (int64_t)tile * nr + ri] = c;
+  }
+  uint4* dst = reinterpret_cast<uint4*>(d_bitmap + (int64_t)plane * bitmap_words + (int64_t)tile * words);
+  for (int i = threadIdx.x; i < words / 4; i += NT) dst[i] = reinterpret_cast<const uint4*>(lbits)[i];
 }
 
 __global__ __launch_bounds__(1024) void k_layer_scan(int32_t* __restrict__ d_layer_offsets, int n_layers,
@@ -221,6 +307,61 @@ __global__ __launch_bounds__(NT) void k_layer_emit(uint32_t* __restrict__ d_bitm
       out[3 * pos + 2] = min_r + ri;
     }
     ++pos;
+  }
+}
+
+// Emission for the keyed path: one workgroup per tile, a wave takes the tile's radius layers
+// w, w + 4, ... with all of its bitmap rows loaded up front (5x fewer, fatter waves than
+// k_layer_emit; the bitmap is left as it is -- the next k_tile_dedup overwrites every word).
+constexpr int EMIT_LAYERS_PER_WAVE = 8;  // nr <= 32 on the keyed path
+
+__global__ __launch_bounds__(NT) void k_tile_emit(const uint32_t* __restrict__ d_bitmap, int64_t bitmap_words,
+                                                  int n_layers, const int32_t* __restrict__ d_layer_offsets, int ntc,
+                                                  int nr, int min_r, int max_r, int32_t* __restrict__ d_circles,
+                                                  int64_t circle_cap) {
+  const int plane = blockIdx.y, tile = blockIdx.x;
+  const int32_t* lo = d_layer_offsets + (int64_t)plane * (n_layers + 1) + (int64_t)tile * nr;
+  if (lo[nr] == lo[0]) return;  // empty tile (block-uniform)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint2* words = reinterpret_cast<const uint2*>(d_bitmap + (int64_t)plane * bitmap_words +
+                                                      (int64_t)tile * nr * LAYER_WORDS);
+  uint2 v[EMIT_LAYERS_PER_WAVE];
+  int start[EMIT_LAYERS_PER_WAVE];
+#pragma unroll
+  for (int u = 0; u < EMIT_LAYERS_PER_WAVE; ++u) {
+    const int ri = wave + u * (NT / 64);
+    v[u] = make_uint2(0u, 0u);
+    start[u] = 0;
+    if (ri < nr) {
+      v[u] = words[ri * (LAYER_WORDS / 2) + lane];
+      start[u] = lo[ri];
+    }
+  }
+  const int row = (tile / ntc) * TS + lane - max_r, col0 = (tile % ntc) * TS - max_r;
+  int32_t* out = d_circles + (int64_t)plane * circle_cap * 3;
+#pragma unroll
+  for (int u = 0; u < EMIT_LAYERS_PER_WAVE; ++u) {
+    const int ri = wave + u * (NT / 64);
+    uint64_t bits = ((uint64_t)v[u].y << 32) | v[u].x;
+    if (ri >= nr || !__any(bits != 0)) continue;  // wave-uniform
+    const int c = __popcll(bits);
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    int64_t pos = (int64_t)start[u] + incl - c;
+    while (bits) {
+      const int b = __ffsll((unsigned long long)bits) - 1;
+      bits &= bits - 1;
+      if (pos < circle_cap) {
+        out[3 * pos] = row;
+        out[3 * pos + 1] = col0 + b;
+        out[3 * pos + 2] = min_r + ri;
+      }
+      ++pos;
+    }
   }
 }
 
@@ -500,27 +641,49 @@ inline int grid_x(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t
 
 }  // namespace
 
-extern "C" int mg_candidate_circles(const int32_t* d_coords, int64_t coord_cap, const int32_t* d_cell_starts,
-                                    const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h,
-                                    int w, int grid, const uint64_t* d_seeds, int64_t num_iter, int min_r, int max_r,
-                                    uint32_t* d_bitmap, int64_t bitmap_words, float* d_raw, void* stream) {
-  if (!d_coords || !d_cell_starts || !d_cell_counts || !d_num_edges || !d_seeds || !d_bitmap) return MG_EINVAL;
+namespace {
+int launch_candidates(const int32_t* d_coords, int64_t coord_cap, const int32_t* d_cell_starts,
+                      const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w, int grid,
+                      const uint64_t* d_seeds, int64_t num_iter, int min_r, int max_r, uint32_t* d_bitmap,
+                      int64_t bitmap_words, float* d_raw, uint32_t* d_keys, void* stream) {
+  if (!d_coords || !d_cell_starts || !d_cell_counts || !d_num_edges || !d_seeds || (!d_bitmap && !d_keys))
+    return MG_EINVAL;
   if (n_planes < 0 || n_planes > 65535 || h <= 0 || w <= 0 || grid <= 0 || num_iter < 0 || min_r < 0 || max_r < min_r)
     return MG_EINVAL;
   if ((double)num_iter * (double)h * (double)w >= 4.0e15) return MG_EINVAL;  // exact-division range of the strata
   int ntr_, ntc_;
   int64_t n_layers_, need_words_;
   if (mg_dedup_layout(h, w, min_r, max_r, &ntr_, &ntc_, &n_layers_, &need_words_) != MG_OK) return MG_EINVAL;
-  if (bitmap_words < need_words_) return MG_EINVAL;
+  if (d_bitmap && bitmap_words < need_words_) return MG_EINVAL;
+  if (d_keys && ((int64_t)ntr_ * ntc_ >= 32768 || max_r - min_r + 1 > 32)) return MG_EINVAL;  // key fields
   if (n_planes == 0 || num_iter == 0) return MG_OK;
   const int gr = (h + grid - 1) / grid, gc = (w + grid - 1) / grid;
   const bool fast = num_iter < (1ll << 31) && grid > 1 && h <= 65536 && w <= 65536;
   hipLaunchKernelGGL(fast ? k_candidates<true> : k_candidates<false>, dim3(grid_x(num_iter), n_planes), dim3(NT), 0,
                      mg_stream(stream), d_coords,
                      coord_cap, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gc, gr * gc, d_seeds, num_iter,
-                     min_r, max_r, d_bitmap, bitmap_words, d_raw);
+                     min_r, max_r, d_bitmap, bitmap_words, d_raw, d_keys);
   MG_CHECK_LAUNCH();
   return MG_OK;
+}
+}  // namespace
+
+extern "C" int mg_candidate_circles(const int32_t* d_coords, int64_t coord_cap, const int32_t* d_cell_starts,
+                                    const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h,
+                                    int w, int grid, const uint64_t* d_seeds, int64_t num_iter, int min_r, int max_r,
+                                    uint32_t* d_bitmap, int64_t bitmap_words, float* d_raw, void* stream) {
+  if (!d_bitmap) return MG_EINVAL;
+  return launch_candidates(d_coords, coord_cap, d_cell_starts, d_cell_counts, d_num_edges, n_planes, h, w, grid, d_seeds,
+                           num_iter, min_r, max_r, d_bitmap, bitmap_words, d_raw, nullptr, stream);
+}
+
+extern "C" int mg_candidate_keys(const int32_t* d_coords, int64_t coord_cap, const int32_t* d_cell_starts,
+                                 const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w,
+                                 int grid, const uint64_t* d_seeds, int64_t num_iter, int min_r, int max_r,
+                                 uint32_t* d_keys, float* d_raw, void* stream) {
+  if (!d_keys) return MG_EINVAL;
+  return launch_candidates(d_coords, coord_cap, d_cell_starts, d_cell_counts, d_num_edges, n_planes, h, w, grid, d_seeds,
+                           num_iter, min_r, max_r, nullptr, 0, d_raw, d_keys, stream);
 }
 
 extern "C" int mg_dedup_layout(int h, int w, int min_r, int max_r, int* n_tile_rows, int* n_tile_cols,
@@ -555,6 +718,36 @@ extern "C" int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, in
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_layer_emit, g, dim3(NT), 0, s, d_bitmap, bitmap_words, nl, d_layer_offsets, ntc, nr, min_r, max_r,
                      d_circles, circle_cap);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, const int32_t* d_cell_starts,
+                                  const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w,
+                                  int grid, int min_r, int max_r, uint32_t* d_bitmap, int64_t bitmap_words,
+                                  int32_t* d_layer_offsets, int32_t* d_circles, int64_t circle_cap,
+                                  int32_t* d_num_circles, void* stream) {
+  if (!d_keys || !d_cell_starts || !d_cell_counts || !d_num_edges || !d_bitmap || !d_layer_offsets || !d_circles ||
+      !d_num_circles || n_planes < 0 || n_planes > 65535 || circle_cap < 0 || num_iter < 0 || grid <= 0)
+    return MG_EINVAL;
+  int ntr, ntc;
+  int64_t n_layers, need_words;
+  if (mg_dedup_layout(h, w, min_r, max_r, &ntr, &ntc, &n_layers, &need_words) != MG_OK) return MG_EINVAL;
+  const int nr = max_r - min_r + 1;
+  if (bitmap_words < need_words || n_layers > 0x7FFFFFF0 || (int64_t)ntr * ntc >= 32768 || nr > 32) return MG_EINVAL;
+  if ((TS + 2 * (max_r + 2)) / grid + 2 > MAX_RANGES || num_iter >= (1ll << 31)) return MG_EINVAL;
+  if (n_planes == 0) return MG_OK;
+  const int nl = (int)n_layers;
+  const int gr = (h + grid - 1) / grid, gc = (w + grid - 1) / grid;
+  hipStream_t s = mg_stream(stream);
+  hipLaunchKernelGGL(k_tile_dedup, dim3(ntr * ntc, n_planes), dim3(NT), (size_t)nr * LAYER_WORDS * 4, s, d_keys,
+                     num_iter, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gr, gc, ntc, nr, max_r, d_bitmap,
+                     bitmap_words, nl, d_layer_offsets);
+  MG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_layer_scan, dim3(n_planes), dim3(1024), 0, s, d_layer_offsets, nl, d_num_circles, circle_cap);
+  MG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_tile_emit, dim3(ntr * ntc, n_planes), dim3(NT), 0, s, d_bitmap, bitmap_words, nl,
+                     d_layer_offsets, ntc, nr, min_r, max_r, d_circles, circle_cap);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -285,8 +285,13 @@ class CircleFinder:
         self.cell_starts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
         self.num_edges = torch.zeros((P,), dtype=i32, device=dev)
         self.coords = None
-        _, _, self.n_layers, self.bitmap_words = nat.dedup_layout(h, w, self.min_r, self.max_r)
+        ntr, ntc, self.n_layers, self.bitmap_words = nat.dedup_layout(h, w, self.min_r, self.max_r)
         self.bitmap = torch.zeros((P, self.bitmap_words), dtype=i32, device=dev)
+        # keyed de-duplication (mg_candidate_keys + mg_keys_to_circles: no global atomics) whenever its
+        # 32-bit key has room for the layout; else the atomicOr bitmap path
+        self.keyed = (ntr * ntc < 32768 and self.max_r - self.min_r + 1 <= 32 and self.num_iter < 2**31
+                      and (64 + 2 * (self.max_r + 2)) // self.grid + 2 <= 64)
+        self.keys = torch.empty((P, self.num_iter), dtype=i32, device=dev) if self.keyed else None
         self.layer_offsets = torch.zeros((P, self.n_layers + 1), dtype=i32, device=dev)
         self.cap = max(1, min(self.num_iter, self.bitmap_words * 32))
         self.circles = torch.empty((P, self.cap, 3), dtype=i32, device=dev)
@@ -409,13 +414,23 @@ class CircleFinder:
         seeds = np.asarray(seeds, dtype=np.uint64).reshape(P)
         self.seeds.copy_(torch.from_numpy(seeds.view(np.int64)))
         self.raw = torch.empty((P, self.num_iter, 3), dtype=torch.float32, device=self.dev) if keep_raw else None
-        _call("mg_candidate_circles", self.coords.data_ptr(), self.coord_cap, self.cell_starts.data_ptr(),
-                                         self.cell_counts.data_ptr(), self.num_edges.data_ptr(), P, h, w, self.grid,
-                                         self.seeds.data_ptr(), self.num_iter, self.min_r, self.max_r,
-                                         self.bitmap.data_ptr(), self.bitmap_words, _ptr(self.raw), s)
-        _call("mg_bitmap_to_circles", self.bitmap.data_ptr(), self.bitmap_words, P, h, w, self.min_r, self.max_r,
-                                         self.layer_offsets.data_ptr(), self.circles.data_ptr(), self.cap,
-                                         self.num_circles.data_ptr(), s)
+        if self.keyed:
+            _call("mg_candidate_keys", self.coords.data_ptr(), self.coord_cap, self.cell_starts.data_ptr(),
+                  self.cell_counts.data_ptr(), self.num_edges.data_ptr(), P, h, w, self.grid, self.seeds.data_ptr(),
+                  self.num_iter, self.min_r, self.max_r, self.keys.data_ptr(), _ptr(self.raw), s,
+                  stage="mg_candidate_circles")
+            _call("mg_keys_to_circles", self.keys.data_ptr(), self.num_iter, self.cell_starts.data_ptr(),
+                  self.cell_counts.data_ptr(), self.num_edges.data_ptr(), P, h, w, self.grid, self.min_r, self.max_r,
+                  self.bitmap.data_ptr(), self.bitmap_words, self.layer_offsets.data_ptr(), self.circles.data_ptr(),
+                  self.cap, self.num_circles.data_ptr(), s, stage="mg_bitmap_to_circles")
+        else:
+            _call("mg_candidate_circles", self.coords.data_ptr(), self.coord_cap, self.cell_starts.data_ptr(),
+                  self.cell_counts.data_ptr(), self.num_edges.data_ptr(), P, h, w, self.grid,
+                  self.seeds.data_ptr(), self.num_iter, self.min_r, self.max_r,
+                  self.bitmap.data_ptr(), self.bitmap_words, _ptr(self.raw), s)
+            _call("mg_bitmap_to_circles", self.bitmap.data_ptr(), self.bitmap_words, P, h, w, self.min_r, self.max_r,
+                  self.layer_offsets.data_ptr(), self.circles.data_ptr(), self.cap,
+                  self.num_circles.data_ptr(), s)
         self.num_alive.zero_()
         self.num_scored.zero_()
         self.max_rc.fill_(-(2**31))

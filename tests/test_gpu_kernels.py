@@ -220,11 +220,16 @@ def test_edge_stage_empty_and_tiny(hp):
 # ---------------------------------------------------------------------------------------------
 
 
-def test_candidates_scores_nms(hp):
+@pytest.mark.parametrize("keyed", [True, False])
+def test_candidates_scores_nms(hp, keyed):
+    """keyed: de-duplication by 32-bit keys and per-tile LDS bitmaps (no global atomics);
+    not keyed: atomicOr into the global bitmap.  Same unique circle list either way."""
     planes = _edge_images()
     p, h, w = planes.shape
     min_r, max_r, num_iter, min_dist = 5, 14, 20000, 5
     cf = hp.CircleFinder(p, h, w, min_r, max_r, num_iter)
+    assert cf.keyed
+    cf.keyed = keyed
     cf.keep_debug_maps = True
     seeds = [11, 12, 13]
     res, _ = cf.find(dev(planes), None, 0.1, 0.9, 0.3, min_dist, seeds, keep_raw=True)
@@ -233,7 +238,8 @@ def test_candidates_scores_nms(hp):
     n_circles = cf.num_circles.cpu().numpy()
     scores = cf.scores.cpu().numpy()
     angle = cf.angle.cpu().numpy()
-    assert cf.bitmap.count_nonzero().item() == 0  # the compaction leaves the bitmap clean
+    if not keyed:
+        assert cf.bitmap.count_nonzero().item() == 0  # the atomic path's compaction leaves the bitmap clean
     for k in range(p):
         u8 = rn.to_uint8(planes[k])
         _, dx, dy, edges, _ = rp.edge_stage(u8, 0.1, 0.9)
