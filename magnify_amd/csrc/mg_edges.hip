@@ -566,6 +566,53 @@ __global__ __launch_bounds__(NT) void k_cell_fill(const uint32_t* __restrict__ d
     }
 }
 
+// The same fill with one lane per cell ROW (64 / grid cells per wave): every lane loads its row's
+// bits at once, a segmented wave scan over the rows of a cell gives each row its output position,
+// and a lane then writes only its own row's few coordinates -- a short store run instead of a
+// thread walking a whole cell (grid rows of dependent loads and ~70 stores).  grid <= 64.
+__global__ __launch_bounds__(NT) void k_cell_fill_rows(const uint32_t* __restrict__ d_bits, int64_t words_per_plane,
+                                                       int h, int w, int grid, int gc, int n_cells,
+                                                       const int32_t* __restrict__ d_starts,
+                                                       int32_t* __restrict__ d_coords, int64_t coord_cap) {
+  const int plane = blockIdx.y;
+  const int cpw = 64 / grid;  // cells per wave
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int ci = lane / grid, r = lane - ci * grid;
+  const int64_t cell = wave * cpw + ci;
+  const uint32_t* bits = d_bits + plane * words_per_plane;
+  uint64_t rowbits = 0;
+  int y = 0, x0 = 0;
+  int64_t pos = 0;
+  if (ci < cpw && cell < n_cells) {
+    const int cr = (int)(cell / gc), cc = (int)(cell - (int64_t)cr * gc);
+    y = cr * grid + r;
+    x0 = cc * grid;
+    const int cw = min(grid, w - x0);
+    if (y < h) {
+      const int64_t b0 = (int64_t)y * w + x0;
+      rowbits = bits_at(bits, b0, min(32, cw));
+      if (cw > 32) rowbits |= (uint64_t)bits_at(bits, b0 + 32, cw - 32) << 32;
+    }
+    pos = d_starts[(int64_t)plane * n_cells + cell];
+  }
+  const int cnt = __popcll(rowbits);
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (r >= off) incl += t;  // lane - off belongs to the same cell
+  }
+  pos += incl - cnt;
+  int2* out = reinterpret_cast<int2*>(d_coords + (int64_t)plane * coord_cap * 2);
+  while (rowbits) {
+    const int b = __ffsll((unsigned long long)rowbits) - 1;
+    rowbits &= rowbits - 1;
+    if (pos < coord_cap) out[pos] = make_int2(y, x0 + b);
+    ++pos;
+  }
+}
+
 // ---- K6: gradient angle at every edge pixel (thread per entry of the compact edge list) ---------
 __global__ __launch_bounds__(NT) void k_edge_angles(const uint8_t* __restrict__ d_blur, int h, int w,
                                                     const int32_t* __restrict__ d_coords, int64_t coord_cap,
@@ -713,8 +760,14 @@ extern "C" int mg_edge_grid(const uint32_t* d_edge_bits, int64_t words_per_plane
     return MG_OK;
   }
   if (n_cells > 0) {  // phase 2: ordered fill
-    hipLaunchKernelGGL(k_cell_fill, dim3((n_cells + NT - 1) / NT, n_planes), dim3(NT), 0, s, d_edge_bits,
-                       words_per_plane, h, w, grid, gc, n_cells, d_cell_starts, d_coords, coord_cap);
+    if (grid <= 64) {
+      const int64_t waves = (n_cells + 64 / grid - 1) / (64 / grid);
+      hipLaunchKernelGGL(k_cell_fill_rows, dim3((unsigned)((waves + NT / 64 - 1) / (NT / 64)), n_planes), dim3(NT), 0, s,
+                         d_edge_bits, words_per_plane, h, w, grid, gc, n_cells, d_cell_starts, d_coords, coord_cap);
+    } else {
+      hipLaunchKernelGGL(k_cell_fill, dim3((n_cells + NT - 1) / NT, n_planes), dim3(NT), 0, s, d_edge_bits,
+                         words_per_plane, h, w, grid, gc, n_cells, d_cell_starts, d_coords, coord_cap);
+    }
     MG_CHECK_LAUNCH();
   }
   return MG_OK;
