@@ -478,7 +478,7 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
       }
 #undef MG_BIT
       if (hits >= need) {
-        list[atomicAdd(&n_surv, 1)] = (int32_t)(i - chunk);
+        list[atomicAdd(&n_surv, 1)] = (int32_t)(i - chunk) | (hits << 10);  // CHUNK = 1024; hits = all of them
       } else if (write_skipped) {
         scores[i] = MG_SCORE_SKIPPED;
       }
@@ -487,14 +487,21 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
     const int ns = n_surv;
     if (threadIdx.x == 0 && d_num_scored) atomicAdd(&d_num_scored[plane], ns);
     for (int a = threadIdx.x; a < ns; a += NT) {
-      const int64_t i = chunk + list[a];
+      const int64_t i = chunk + (list[a] & (CHUNK - 1));
       const int row = circles[3 * i], col = circles[3 * i + 1], rad = circles[3 * i + 2];
       const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
       const int by = row - wy0, bx = col - wx0;
       double acc = 0.0;
+      // Early abort (exact): every remaining edge pixel adds at most 1, so once
+      // acc + remaining < min_roundness * len - 1e-3 the circle cannot pass any more.  Most circles
+      // that survive the count-only prefilter sit just above it and their terms average ~0 (noise
+      // edges point anywhere): they are ruled out after a handful of terms.
+      double left = (double)(list[a] >> 10);  // edge pixels on the perimeter not yet summed
+      const double floor_sum = (double)min_roundness * (double)(p1 - p0) - 1e-3;
+      bool dead = false;
       // 32 perimeter points at a time: hit mask from LDS, then only the hits (in perimeter order)
       // pay for the angle gather and the float64 arithmetic
-      for (int base = p0; base < p1; base += 32) {
+      for (int base = p0; base < p1 && !dead; base += 32) {
         uint32_t mask = 0;
         const int cnt = min(32, p1 - base);
         for (int j = 0; j < cnt; ++j) {
@@ -518,7 +525,16 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
           const double q0 = x4 * INV_PI;
           const double q = fma(fma(-q0, PI, x4), INV_PI, q0);
           acc += q - 1.0;
+          left -= 1.0;
+          if (acc + left < floor_sum) {
+            dead = true;
+            break;
+          }
         }
+      }
+      if (dead) {
+        if (write_skipped) scores[i] = MG_SCORE_SKIPPED;
+        continue;
       }
       const float score = (float)acc / (float)(p1 - p0);
       scores[i] = score;
