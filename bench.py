@@ -36,8 +36,9 @@ def algorithmic_bytes(stage, p):
         "mg_canny_hysteresis": (3 / 8) * planes * n * p["sweeps"],  # weak + strong bits in, strong out, per sweep
         "mg_edge_angles": p["edges"] * (8 + 9 + 4),          # coordinate, 3x3 blurred neighbourhood, angle
         "mg_edge_grid": 2 * planes * n / 8 + 8 * p["edges"],  # bitmap twice (count, fill), write coords
-        "mg_candidate_circles": 28 * planes * p["num_iter"],  # 3 coordinate reads (8 B) + bitmap word
-        "mg_bitmap_to_circles": 2 * 4 * p["bitmap_words"] * planes + 12 * p["unique"],  # bitmap read twice + list
+        "mg_candidate_circles": 28 * planes * p["num_iter"],  # 3 coordinate reads (8 B) + the 32-bit key
+        # keys read once, tile layers written and read back once, the (row, col, r) list written
+        "mg_bitmap_to_circles": 4 * planes * p["num_iter"] + 2 * 4 * p["bitmap_words"] * planes + 12 * p["unique"],
         "mg_score_circles": p["unique"] * (12 + p["mean_perimeter"] / 8 + 4),  # circle + perimeter edge bits + score
         "mg_nms_round": p["alive"] * p["ring_len"] * 16 * p["nms_rounds"],
         "mg_collect_circles": p["alive"] * 4 + p["markers"] * 16,
@@ -75,6 +76,43 @@ def cpu_baseline(args, stack, flat_np, seeds, gpu_counts, gpu_fg_sums):
             "markers_per_s": total / dt, "same_markers_and_sums_as_gpu": agree}
 
 
+STREAM_STAGES = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_to_uint8_blur", "mg_scharr_hist", "mg_canny_nms",
+                 "mg_canny_hysteresis", "mg_edge_grid", "mg_edge_angles", "mg_circle_labels",
+                 "mg_roi_gather_reduce_batched", "mg_roi_segment_reduce"]
+
+
+def stage_report(stages, steps, p, pmc, stream_bytes):
+    """Per-stage table (time, algorithmic bytes, achieved GB/s, PMC traffic), the `roofline` object of
+    the stage with the largest total time, and the streaming part (everything that is not RANSAC
+    scoring / suppression) against SURVEY 8d's byte count."""
+    total_ms = sum(v[0] for v in stages.values())
+    breakdown = {}
+    for k, v in sorted(stages.items(), key=lambda kv: -kv[1][0]):
+        ab = algorithmic_bytes(k, p)
+        ms_step = v[0] / steps
+        breakdown[k] = {"ms_per_step": round(ms_step, 3), "launches_per_step": v[1] / steps,
+                        "ms_avg_launch": round(v[0] / v[1], 4),
+                        "algorithmic_GB_per_step": round(ab / 1e9, 3) if ab else None,
+                        "achieved_GBs": round(ab / (ms_step / 1e3) / 1e9, 1) if ab and ms_step else None,
+                        "hbm_traffic_GB_per_step": round(pmc[k]["hbm_bytes_per_step"] / 1e9, 3) if pmc and k in pmc else None}
+    dom, (dom_ms, dom_n) = max(stages.items(), key=lambda kv: kv[1][0])
+    ab_step = algorithmic_bytes(dom, p)                  # bytes per step, all launches of the stage
+    launches_per_step = dom_n / steps
+    ab = ab_step / launches_per_step if ab_step else None  # bytes of one launch
+    avg_s = dom_ms / dom_n / 1e3                          # average duration of one launch
+    achieved = ab / avg_s / 1e9 if ab else None
+    traffic = pmc[dom]["hbm_bytes_per_step"] / launches_per_step if pmc and dom in pmc else None
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                "algorithmic_bytes_per_launch": ab, "avg_launch_ms": dom_ms / dom_n,
+                "launches_per_step": launches_per_step, "share_of_kernel_time": dom_ms / total_ms}
+    stream_ms = sum(stages[s][0] for s in STREAM_STAGES if s in stages) / steps
+    streaming = {"ms_per_step": stream_ms, "algorithmic_bytes": stream_bytes,
+                 "achieved_GBs": stream_bytes / (stream_ms / 1e3) / 1e9 if stream_ms else None,
+                 "frac_of_peak": stream_bytes / (stream_ms / 1e3) / 1e9 / HBM_PEAK_GBS if stream_ms else None}
+    return breakdown, roofline, streaming, total_ms
+
+
 def per_assay_fg_sums(out, n_assays):
     """Sum of the foreground sums of every assay's markers (exact integers held in float64)."""
     import numpy as np
@@ -98,6 +136,7 @@ def main():
     ap.add_argument("--sub-batches", type=int, default=0, help="sub-batches of assays (0 = one per stream)")
     ap.add_argument("--cpu-assays-per-core", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-stream pass")
     args = ap.parse_args()
 
     import numpy as np
@@ -177,35 +216,38 @@ def main():
              "edges": edges, "bitmap_words": f.bitmap_words, "unique": unique, "alive": alive,
              "mean_perimeter": mean_perimeter, "ring_len": len(hp.nat.circle_points(proc.min_r, True)),
              "markers": markers_local, "mean_disk": 600, "L": proc.L}
-        total_ms = sum(v[0] for v in stages.values())
-        breakdown = {k: {"ms_total": round(v[0], 3), "launches": v[1], "ms_avg": round(v[0] / v[1], 4)}
-                     for k, v in sorted(stages.items(), key=lambda kv: -kv[1][0])}
-        dom, (dom_ms, dom_n) = max(stages.items(), key=lambda kv: kv[1][0])
-        ab_step = algorithmic_bytes(dom, p)                  # bytes per step, all launches of the stage
-        launches_per_step = dom_n / args.steps
-        ab = ab_step / launches_per_step if ab_step else None  # bytes of one launch
-        avg_s = dom_ms / dom_n / 1e3                          # average duration of one launch
-        achieved = ab / avg_s / 1e9 if ab else None
-        traffic = None
-        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            if (T, C, S, args.num_iter) == (64, 4, 4096, 5_000_000) and dom in pmc["stages"]:
-                traffic = pmc["stages"][dom]["hbm_bytes_per_step"] / launches_per_step
+        pmc = None
+        try:  # HBM bytes per step from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json)
+            if (T, C, S, args.num_iter) == (64, 4, 4096, 5_000_000):
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["stages"]
         except (OSError, KeyError, ValueError):
-            traffic = None
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": ab, "avg_launch_ms": dom_ms / dom_n,
-                    "launches_per_step": launches_per_step, "share_of_kernel_time": dom_ms / total_ms}
-        # the streaming part alone (everything that is not RANSAC scoring / suppression)
-        stream_stages = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_to_uint8_blur", "mg_scharr_hist",
-                         "mg_canny_nms", "mg_canny_hysteresis", "mg_edge_grid", "mg_edge_angles", "mg_circle_labels",
-                         "mg_roi_gather_reduce_batched", "mg_roi_segment_reduce"]
-        stream_ms = sum(stages[s][0] for s in stream_stages if s in stages) / args.steps
+            pmc = None
         n_all, n_s = T * C * S * S, search_planes * S * S
         # SURVEY.md 8d's count minus the label map this build no longer writes (4 B/px of the searched
         # planes) or reads (4 B per window pixel): masks come straight from the bead tables
         stream_bytes = 6 * n_all + 8 * n_s + markers_local * proc.L**2 * (4 * C + 2)
+        breakdown, roofline, streaming, total_ms = stage_report(stages, args.steps, p, pmc, stream_bytes)
+        isolated = None
+        if world == 1 and proc.n_streams > 1 and not args.no_isolated:
+            # the same step once more on ONE stream (untimed for `value`): kernel durations without the
+            # overlap of the four detection streams, for the per-stage roofline table
+            proc1 = StackProcessor(T, C, S, S, num_iter=args.num_iter, min_bead_diameter=10, max_bead_diameter=50,
+                                   search_channels=(0,), mode="P", device=dev, n_streams=1)
+            proc1(stack, flat, 100.0, seed=0)
+            t1 = hp.StageTimer()
+            torch.cuda.synchronize()
+            hp.set_timer(t1)
+            w0 = time.perf_counter()
+            for i in range(2):
+                proc1(stack, flat, 100.0, seed=args.warmup + args.steps - 1)
+            torch.cuda.synchronize()
+            w1 = time.perf_counter() - w0
+            hp.set_timer(None)
+            bd1, rf1, st1, tot1 = stage_report(t1.summary(), 2, p, pmc, stream_bytes)
+            isolated = {"note": "one HIP stream, no overlap between kernels; not the timed region",
+                        "ms_per_step": w1 / 2 * 1e3, "kernel_ms_per_step": tot1 / 2, "roofline": rf1,
+                        "streaming_part": st1, "stages": bd1}
+            del proc1
         result = {
             "metric": "megapixels/sec through flatfield+segment+ROI-reduce; markers/sec",
             "value": mp_total / (dt / args.steps), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
@@ -217,10 +259,9 @@ def main():
                        "timepoints_per_gpu": T, "parallelism": f"time-shard x{world}"},
             "markers_per_s": markers_total / (dt / args.steps), "markers": markers_total,
             "roofline": roofline,
-            "streaming_part": {"ms_per_step": stream_ms, "algorithmic_bytes": stream_bytes,
-                               "achieved_GBs": stream_bytes / (stream_ms / 1e3) / 1e9 if stream_ms else None,
-                               "frac_of_peak": stream_bytes / (stream_ms / 1e3) / 1e9 / HBM_PEAK_GBS if stream_ms else None},
+            "streaming_part": streaming,
             "stages": breakdown,
+            "isolated": isolated,
             "stats": {"unique_circles": unique, "scored_exactly": scored,
                       "streams": proc.n_streams, "sub_batches": len(getattr(proc, "ranges", [0])),
                       "alive_circles": alive, "edges": p["edges"],

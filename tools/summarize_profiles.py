@@ -8,19 +8,19 @@ import shutil
 import sys
 
 tag, stats_dir, fetch_dir, write_dir, steps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
-shutil.copy(glob.glob(f"{stats_dir}/*/*kernel_stats.csv")[0], f"profiles/{tag}_kernel_stats.csv")
+shutil.copy(glob.glob(f"{stats_dir}/**/*kernel_stats.csv", recursive=True)[0], f"profiles/{tag}_kernel_stats.csv")
 
 STAGE_OF = {"k_flatfield_max": "mg_flatfield_max", "k_apply_stitch": "mg_flatfield_apply_stitch", "k_u8_blur": "mg_to_uint8_blur",
             "k_scharr_hist": "mg_scharr_hist", "k_canny_nms": "mg_canny_nms", "k_hysteresis": "mg_canny_hysteresis",
             "k_cell_": "mg_edge_grid", "k_edge_angles": "mg_edge_angles", "k_candidates": "mg_candidate_circles",
-            "k_layer_": "mg_bitmap_to_circles", "k_score_tiles": "mg_score_circles", "k_nms<": "mg_nms_round",
+            "k_layer_": "mg_bitmap_to_circles", "k_tile_": "mg_bitmap_to_circles", "k_score_tiles": "mg_score_circles", "k_nms<": "mg_nms_round",
             "k_collect": "mg_collect_circles", "k_clamp": "mg_collect_circles", "k_circle_labels": "mg_circle_labels",
-            "k_roi": "mg_roi_gather_reduce_batched"}
+            "k_roi": "mg_roi_segment_reduce"}
 
 
 def agg(d, name):
     out = collections.defaultdict(float)
-    for r in csv.DictReader(open(glob.glob(f"{d}/*/*counter_collection.csv")[0])):
+    for r in csv.DictReader(open(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0])):
         if r["Counter_Name"] != name:
             continue
         for pat, st in STAGE_OF.items():
