@@ -115,7 +115,11 @@ int mg_to_uint8_blur(const void* d_src, int dtype, int n_planes, int64_t plane_s
  * mode 1 (window, 8192 bins per plane): bin m - d_base[plane] for m in [base, base + 8192).
  * d_hist must be pre-zeroed. */
 int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w, int mode, const uint32_t* d_base,
-                   uint32_t* d_hist, void* stream);
+                   uint32_t* d_hist, uint32_t* d_scratch, int64_t scratch_words, void* stream);
+/* Words of caller-owned scratch that let mg_scharr_hist hand its per-workgroup histograms over with
+ * plain stores (summed by a second small kernel) instead of one global atomicAdd per non-empty bin.
+ * d_scratch == NULL selects the atomic hand-over. */
+int64_t mg_scharr_hist_scratch_words(int n_planes, int h, int w, int mode);
 
 /* Bitmaps over pixels use the linear layout bit i of word k <-> pixel 32 k + i (i = y * w + x);
  * words_per_plane >= ceil(h w / 32) + 1. */

@@ -35,7 +35,8 @@ PROTOTYPES = {
     "mg_flatfield_apply_stitch": [_p, _i, _l, _i, _i, _i, _i, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p, _p, _p],
     "mg_plane_minmax": [_p, _i, _i, _l, _i, _i, _l, _p, _p],
     "mg_to_uint8_blur": [_p, _i, _i, _l, _i, _i, _l, _p, _p, _p, _p],
-    "mg_scharr_hist": [_p, _i, _i, _i, _i, _p, _p, _p],
+    "mg_scharr_hist": [_p, _i, _i, _i, _i, _p, _p, _p, _l, _p],
+    "mg_scharr_hist_scratch_words": [_i, _i, _i, _i],
     "mg_canny_nms": [_p, _i, _i, _i, _p, _p, _p, _l, _p],
     "mg_canny_hysteresis": [_p, _p, _l, _i, _i, _i, _p, _p, _p, _p],
     "mg_unpack_bits": [_p, _l, _i, _l, _p, _p],
@@ -61,6 +62,8 @@ PROTOTYPES = {
     "mg_masked_sums": [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p],
 }
 
+RETURNS_INT64 = {"mg_scharr_hist_scratch_words"}
+
 _lib = None
 
 
@@ -81,7 +84,7 @@ def lib():
         for name, argtypes in PROTOTYPES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
-            fn.restype = C.c_int
+            fn.restype = C.c_int64 if name in RETURNS_INT64 else C.c_int
         _lib = handle
     return _lib
 

@@ -78,7 +78,7 @@ __device__ __forceinline__ void fetch16(const T* __restrict__ rowp, int gx0, int
       for (int j = 0; j < PER; ++j) v[q * PER + j] = to_u8<T>(e[j], sc);
     }
   } else {
-#pragma unroll 4
+#pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = to_u8<T>(rowp[mg_reflect101(gx0 + j, w)], sc);
   }
 }
@@ -128,14 +128,57 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ base, int64_t ro
     }
     return;
   }
-  for (int i = threadIdx.x; i < TOTAL; i += NT) {
-    const int j = i / CHUNKS, k = i - j * CHUNKS;
-    const int gy = mg_reflect101(ty0 - HALO + j, h);
-    uint8_t v[16];
-    fetch16<T>(base + (int64_t)gy * row_stride, tx0 - LPAD + 16 * k, w, sc, v);
-    uint4 raw;
-    __builtin_memcpy(&raw, v, 16);
-    *reinterpret_cast<uint4*>(&tile[j][16 * k]) = raw;
+  // Border tiles: the chunks that lie wholly inside the image (nearly all of them) still take the
+  // batched 16-byte loads, rows through reflect-101; only a chunk that crosses or lies beyond an
+  // image edge is assembled pixel by pixel -- and only the HALO pixels next to the tile that a stencil
+  // can reach (the rest of the 16-pixel pad is never read).  This path used to walk every chunk one
+  // after the other with per-byte loads and cost more than all interior tiles together.
+  const bool rows_ok = ((row_stride * sizeof(T)) & 15) == 0;
+  uint4 raw[ITER][NLD];
+  bool fast[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int i = threadIdx.x + it * NT;
+    fast[it] = false;
+    if (i < TOTAL) {
+      const int j = i / CHUNKS, k = i - j * CHUNKS;
+      const int gy = mg_reflect101(ty0 - HALO + j, h), gx0 = tx0 - LPAD + 16 * k;
+      const T* p = base + (int64_t)gy * row_stride + gx0;
+      fast[it] = rows_ok && gx0 >= 0 && gx0 + 16 <= w && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+      if (fast[it]) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) raw[it][q] = reinterpret_cast<const uint4*>(p)[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int i = threadIdx.x + it * NT;
+    if (i < TOTAL) {
+      const int j = i / CHUNKS, k = i - j * CHUNKS;
+      uint8_t v[16];
+      if (fast[it]) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+          T e[PER];
+          __builtin_memcpy(e, &raw[it][q], 16);
+#pragma unroll
+          for (int m = 0; m < PER; ++m) v[q * PER + m] = to_u8<T>(e[m], sc);
+        }
+      } else {
+        const int gy = mg_reflect101(ty0 - HALO + j, h), gx0 = tx0 - LPAD + 16 * k;
+        const T* rowp = base + (int64_t)gy * row_stride;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          const int c = 16 * k + m;  // column in the LDS row; the tile proper is [LPAD, LPAD + TW)
+          const bool needed = c >= LPAD - HALO && c < LPAD + TW + HALO;
+          v[m] = needed ? to_u8<T>(rowp[mg_reflect101(gx0 + m, w)], sc) : (uint8_t)0;
+        }
+      }
+      uint4 out;
+      __builtin_memcpy(&out, v, 16);
+      *reinterpret_cast<uint4*>(&tile[j][16 * k]) = out;
+    }
   }
 }
 
@@ -231,63 +274,148 @@ __device__ __forceinline__ void scharr_n(const Row12& a, const Row12& b, const R
 constexpr int FINE = 8192;
 constexpr int COARSE = 4096;
 
+// A workgroup accumulates HIST_TILES vertically adjacent tiles (3 x 16384 pixels: a 16-bit counter
+// cannot overflow) before it hands its histogram over: a plain coalesced store of the packed counters
+// into the workgroup's own slot of d_partial, summed by k_hist_reduce (or, without d_partial, one
+// global atomicAdd per non-empty bin).
+// DIRECT (interior tile groups): no LDS tile at all -- a lane loads its own dword of each of the 18
+// rows of its wave's strip straight into registers (all loads in flight at once), neighbours' pixels
+// come from the adjacent lanes by wave shuffles, so the waves of a workgroup never wait for each
+// other and LDS holds only the histogram (6 instead of 3 workgroups per CU).  Border tile groups go
+// through the LDS-staged path (reflect-101) in a second launch.
+constexpr int HIST_TILES = 3;
+
+__device__ __forceinline__ void hist_add4(const Row12& ra, const Row12& rb, const Row12& rc, int gx, int w, int mode,
+                                          uint32_t base, int n_bins, uint32_t* hist, uint32_t& zeros) {
+  int dx[4], dy[4];
+  scharr_n<0, 4>(ra, rb, rc, dx, dy);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (gx + q >= w) continue;
+    const uint32_t m = (uint32_t)(dx[q] * dx[q] + dy[q] * dy[q]);
+    if (mode == 0) {
+      if (m == 0) ++zeros;
+      else {
+        const uint32_t b = m < FINE ? m : FINE + (m >> 13);
+        atomicAdd(&hist[b >> 1], 1u << (16 * (b & 1)));
+      }
+    } else if (m >= base && m - base < (uint32_t)n_bins) {
+      if (m == base) ++zeros;
+      else {
+        const uint32_t b = m - base;
+        atomicAdd(&hist[b >> 1], 1u << (16 * (b & 1)));
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ bool hist_group_interior(const uint8_t* pb, int h, int w, int tx0, int gy) {
+  const int y_first = gy * HIST_TILES * TH, y_end = y_first + HIST_TILES * TH;  // rows [y_first, y_end)
+  return tx0 >= 4 && tx0 + TW + 4 <= w && y_first >= 1 && y_end + 1 <= h && (w & 3) == 0 &&
+         (reinterpret_cast<uintptr_t>(pb) & 3) == 0;
+}
+
+template <bool DIRECT>
 __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ d_blur, int h, int w, int mode,
                                                     const uint32_t* __restrict__ d_base, int n_bins,
-                                                    uint32_t* __restrict__ d_hist) {
+                                                    uint32_t* __restrict__ d_hist, uint32_t* __restrict__ d_partial,
+                                                    int split) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t (*tile)[LS] = reinterpret_cast<uint8_t (*)[LS]>(smem);
-  // 16-bit counters, two per word (a tile holds 16384 pixels, so a bin cannot overflow its half)
-  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (TH + 2) * LS);
+  // 16-bit counters, two per word
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (DIRECT ? 0 : (TH + 2) * LS));
   const int plane = blockIdx.z;
-  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+  const int tx0 = blockIdx.x * TW;
+  const uint8_t* pb = d_blur + (int64_t)plane * h * w;
+  // DIRECT: grid.y counts tile groups; staged: grid.y counts tiles (one tile per workgroup)
+  const bool interior = hist_group_interior(pb, h, w, tx0, DIRECT ? blockIdx.y : blockIdx.y / HIST_TILES);
+  uint32_t* slot = (DIRECT && d_partial) ? d_partial + ((int64_t)plane * gridDim.y * gridDim.x +
+                                                        (int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (n_bins / 2)
+                                         : nullptr;
+  if (DIRECT && !interior) {  // the staged launch handles this group (and adds straight into d_hist)
+    if (slot)
+      for (int i = threadIdx.x; i < n_bins / 2; i += NT) slot[i] = 0u;
+    return;
+  }
+  if (!DIRECT && split && interior) return;
   for (int i = threadIdx.x; i < n_bins / 2; i += NT) hist[i] = 0;
-  U8Scale sc;
-  sc.passthrough = 1;
-  load_tile<uint8_t, 1>(d_blur + (int64_t)plane * h * w, w, h, w, tx0, ty0, sc, tile);
-  __syncthreads();
   const uint32_t base = (mode == 1 && d_base) ? d_base[plane] : 0u;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = 4 * lane, gx = tx0 + c0;
   uint32_t zeros = 0;
-  Row12 ra = read_row(tile, wave * RPW, c0), rb = read_row(tile, wave * RPW + 1, c0);
-#pragma unroll 4
-  for (int jr = 2; jr < RPW + 2; ++jr) {
-    const Row12 rc = read_row(tile, wave * RPW + jr, c0);
-    const int gy = ty0 + wave * RPW + jr - 2;
-    if (gy < h && gx < w) {
-      int dx[4], dy[4];
-      scharr_n<0, 4>(ra, rb, rc, dx, dy);
+  if (DIRECT) {
+    __syncthreads();  // histogram zeroed
+#pragma unroll 1
+    for (int sub = 0; sub < HIST_TILES; ++sub) {
+      const int y0 = (blockIdx.y * HIST_TILES + sub) * TH + wave * RPW;  // first row of this wave's strip
+      uint32_t mid[RPW + 2], edge[RPW + 2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (gx + q >= w) continue;
-        const uint32_t m = (uint32_t)(dx[q] * dx[q] + dy[q] * dy[q]);
-        if (mode == 0) {
-          if (m == 0) ++zeros;
-          else {
-            const uint32_t b = m < FINE ? m : FINE + (m >> 13);
-            atomicAdd(&hist[b >> 1], 1u << (16 * (b & 1)));
-          }
-        } else if (m >= base && m - base < (uint32_t)n_bins) {
-          if (m == base) ++zeros;
-          else {
-            const uint32_t b = m - base;
-            atomicAdd(&hist[b >> 1], 1u << (16 * (b & 1)));
-          }
-        }
+      for (int j = 0; j < RPW + 2; ++j) {
+        const uint32_t* rowp = reinterpret_cast<const uint32_t*>(pb + (int64_t)(y0 - 1 + j) * w + tx0);
+        mid[j] = rowp[lane];
+        edge[j] = 0;
+        if (lane == 0) edge[j] = rowp[-1];
+        else if (lane == 63) edge[j] = rowp[64];
+      }
+      Row12 ra, rb;
+#pragma unroll
+      for (int j = 0; j < RPW + 2; ++j) {
+        uint32_t d0 = (uint32_t)__shfl_up((int)mid[j], 1), d2 = (uint32_t)__shfl_down((int)mid[j], 1);
+        if (lane == 0) d0 = edge[j];
+        if (lane == 63) d2 = edge[j];
+        const Row12 rc{d0, mid[j], d2};
+        if (j >= 2) hist_add4(ra, rb, rc, gx, w, mode, base, n_bins, hist, zeros);
+        ra = rb;
+        rb = rc;
       }
     }
-    ra = rb;
-    rb = rc;
+  } else {
+    U8Scale sc;
+    sc.passthrough = 1;
+    const int ty0 = blockIdx.y * TH;
+    load_tile<uint8_t, 1>(pb, w, h, w, tx0, ty0, sc, tile);
+    __syncthreads();  // tile staged, histogram zeroed
+    Row12 ra = read_row(tile, wave * RPW, c0), rb = read_row(tile, wave * RPW + 1, c0);
+#pragma unroll 4
+    for (int jr = 2; jr < RPW + 2; ++jr) {
+      const Row12 rc = read_row(tile, wave * RPW + jr, c0);
+      const int gy = ty0 + wave * RPW + jr - 2;
+      if (gy < h && gx < w) hist_add4(ra, rb, rc, gx, w, mode, base, n_bins, hist, zeros);
+      ra = rb;
+      rb = rc;
+    }
   }
   zeros = (uint32_t)mg_wave_sum_i32((int)zeros);
   uint32_t* out = d_hist + (int64_t)plane * n_bins;
   if (lane == 0 && zeros) atomicAdd(&out[0], zeros);  // bin 0 goes straight to global memory
   __syncthreads();
+  if (slot) {
+    for (int i = threadIdx.x; i < n_bins / 2; i += NT) slot[i] = hist[i];
+    return;
+  }
   for (int i = threadIdx.x; i < n_bins / 2; i += NT) {
     const uint32_t v = hist[i];
     if (v & 0xFFFFu) atomicAdd(&out[2 * i], v & 0xFFFFu);
     if (v >> 16) atomicAdd(&out[2 * i + 1], v >> 16);
   }
+}
+
+// d_hist[plane][bin] += sum over the plane's workgroup slots (packed 16-bit pairs).
+__global__ __launch_bounds__(NT) void k_hist_reduce(const uint32_t* __restrict__ d_partial, int slots, int n_bins,
+                                                    uint32_t* __restrict__ d_hist) {
+  const int plane = blockIdx.y;
+  const int i = blockIdx.x * NT + threadIdx.x;  // packed word = bins 2i, 2i + 1
+  if (i >= n_bins / 2) return;
+  const uint32_t* p = d_partial + (int64_t)plane * slots * (n_bins / 2) + i;
+  uint32_t lo = 0, hi = 0;
+  for (int s = 0; s < slots; ++s) {
+    const uint32_t v = p[(int64_t)s * (n_bins / 2)];
+    lo += v & 0xFFFFu;
+    hi += v >> 16;
+  }
+  uint32_t* out = d_hist + (int64_t)plane * n_bins;
+  out[2 * i] += lo;      // bin 0 also receives the register-counted zeros by atomicAdd in k_scharr_hist,
+  out[2 * i + 1] += hi;  // which has completed: kernels on a stream run in order
 }
 
 // ---- bit helpers on the linear (y * w + x) bitmaps --------------------------------------------
@@ -669,24 +797,47 @@ extern "C" int mg_to_uint8_blur(const void* d_src, int dtype, int n_planes, int6
   return MG_OK;
 }
 
+extern "C" int64_t mg_scharr_hist_scratch_words(int n_planes, int h, int w, int mode) {
+  if (n_planes < 0 || h < 0 || w < 0 || (mode != 0 && mode != 1)) return -1;
+  const dim3 t = tile_grid(h, w, n_planes);
+  const int64_t slots = (int64_t)t.x * ((t.y + HIST_TILES - 1) / HIST_TILES);
+  return (int64_t)n_planes * slots * ((mode == 0 ? FINE + COARSE : FINE) / 2);
+}
+
 extern "C" int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w, int mode, const uint32_t* d_base,
-                              uint32_t* d_hist, void* stream) {
+                              uint32_t* d_hist, uint32_t* d_scratch, int64_t scratch_words, void* stream) {
   if (!d_blur || !d_hist || n_planes < 0 || h < 0 || w < 0 || (mode != 0 && mode != 1)) return MG_EINVAL;
   if (mode == 1 && !d_base) return MG_EINVAL;
   if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
-  const dim3 g = tile_grid(h, w, n_planes);
+  const dim3 t = tile_grid(h, w, n_planes);
+  const dim3 g(t.x, (t.y + HIST_TILES - 1) / HIST_TILES, t.z);
   if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
+  if (d_scratch && scratch_words < mg_scharr_hist_scratch_words(n_planes, h, w, mode)) return MG_EINVAL;
   const int n_bins = mode == 0 ? FINE + COARSE : FINE;
   const size_t lds = (size_t)(TH + 2) * LS + (size_t)n_bins * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_scharr_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            96 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_scharr_hist<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
       return MG_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_scharr_hist, g, dim3(NT), lds, mg_stream(stream), d_blur, h, w, mode, d_base, n_bins, d_hist);
+  // with scratch: interior tile groups by the register-direct kernel into their slots, border groups
+  // by the LDS-staged kernel straight into d_hist; without: the staged kernel does everything
+  const int split = d_scratch ? 1 : 0;
+  if (split) {
+    hipLaunchKernelGGL(k_scharr_hist<true>, g, dim3(NT), (size_t)n_bins * 2, mg_stream(stream), d_blur, h, w, mode,
+                       d_base, n_bins, d_hist, d_scratch, split);
+    MG_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_scharr_hist<false>, t, dim3(NT), lds, mg_stream(stream), d_blur, h, w, mode, d_base, n_bins,
+                     d_hist, d_scratch, split);
   MG_CHECK_LAUNCH();
+  if (d_scratch) {
+    hipLaunchKernelGGL(k_hist_reduce, dim3((n_bins / 2 + NT - 1) / NT, n_planes), dim3(NT), 0, mg_stream(stream),
+                       d_scratch, (int)(g.x * g.y), n_bins, d_hist);
+    MG_CHECK_LAUNCH();
+  }
   return MG_OK;
 }
 

@@ -272,6 +272,8 @@ class CircleFinder:
         self.angle = torch.empty((P, h, w), dtype=torch.float32, device=dev)  # valid at edge pixels
         self.hist = torch.zeros((P, COMBINED_BINS), dtype=i32, device=dev)
         self.hist_base = torch.zeros((P,), dtype=i32, device=dev)
+        # per-workgroup histogram slots: plain stores + a reduce kernel instead of global atomics
+        self.hist_scratch = torch.empty((int(nat.lib().mg_scharr_hist_scratch_words(P, h, w, 0)),), dtype=i32, device=dev)
         self.thresh = torch.zeros((P, 2), dtype=i32, device=dev)
         self.changed = torch.zeros((4, P), dtype=i32, device=dev)
         tx, ty = nat.C.c_int(0), nat.C.c_int(0)
@@ -331,7 +333,8 @@ class CircleFinder:
                                      _ptr(minmax), self.blur.data_ptr(), _ptr(self.u8), s)
         # one-pass combined histogram of m = dx^2 + dy^2: exact below 8192, coarse (m >> 13) above
         self.hist.zero_()
-        _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 0, 0, self.hist.data_ptr(), s)
+        _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 0, 0, self.hist.data_ptr(), self.hist_scratch.data_ptr(),
+              self.hist_scratch.numel(), s)
         ccum = torch.cumsum(self.hist.to(torch.int64), dim=1).cpu().numpy()
         n = h * w
         want = []
@@ -351,7 +354,8 @@ class CircleFinder:
             self.hist_base.copy_(torch.from_numpy((base_bins << COARSE_SHIFT).astype(np.int32)))
             fine = self.hist.view(-1)[: P * FINE_BINS].view(P, FINE_BINS)
             fine.zero_()
-            _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 1, self.hist_base.data_ptr(), fine.data_ptr(), s)
+            _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 1, self.hist_base.data_ptr(), fine.data_ptr(),
+                  self.hist_scratch.data_ptr(), self.hist_scratch.numel(), s)
             fcum = torch.cumsum(fine.to(torch.int64), dim=1).cpu().numpy()
             for p in range(P):
                 if not todo[p]:

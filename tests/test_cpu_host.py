@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "magnify_hip.h")).read()
-    declared = set(re.findall(r"^int (mg_\w+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t) (mg_\w+)\(", header, flags=re.M))
     assert len(declared) >= 20
     assert declared == set(nat.PROTOTYPES), declared ^ set(nat.PROTOTYPES)
     lib = ctypes.CDLL(nat.LIB_PATH)
