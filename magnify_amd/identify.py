@@ -1,6 +1,6 @@
-"""identify_buttons (reference: src/magnify/identify.py:13-47).  identify_mrbles (spectral
-decoding, identify.py:50-234) is outside the hot path; only its
-ROI-reduce expression (identify.py:76-80) is, and that lives in ``magnify_amd.reduce``."""
+"""identify_buttons (reference: src/magnify/identify.py:13-47) and the front half of
+identify_mrbles (identify.py:50-90: intensities, lanthanide volumes and ratios); the spectral code
+assignment (identify.py:92-234) is outside the hot path."""
 from __future__ import annotations
 
 import re
@@ -37,6 +37,43 @@ def identify_buttons(assay, shape=None, pinlist=None, blank=None):
 
 
 @registry.component("identify_mrbles")
-def identify_mrbles(assay, spectra, codes, reference="eu"):
-    raise NotImplementedError("identify_mrbles (lanthanide decoding) is outside the MI355X hot path; "
-                              "use magnify_amd.reduce.fg_mean_minus_bg_median for its ROI-reduce step")
+def identify_mrbles(assay, spectra, codes, reference="eu", decode=False):
+    """Front half of the reference's identify_mrbles (identify.py:50-90): per-bead
+    intensities ``fg mean - bg median`` at time 0 (the fused device reductions of
+    ``magnify_amd.reduce``), lanthanide volumes by least squares against the reference spectra
+    (``S V = I``) and their ratios to the reference lanthanide, stored as ``ln_vol`` / ``ln_ratio``
+    over the new ``ln`` coordinate.  Same argument meaning and ValueErrors as the reference
+    (unknown reference lanthanide; lanthanide names of the two CSV files differ).
+
+    The code-assignment back half (outlier removal, affine fit of the code grid, Gaussian-mixture
+    assignment, identify.py:92-234) is outside this build: ``decode=True`` raises
+    NotImplementedError after the volumes have been computed."""
+    import pandas as pd
+
+    from . import reduce
+
+    table = pd.read_csv(spectra)
+    hits = table.index[table["name"] == reference]
+    if len(hits) == 0:
+        raise ValueError(f"Reference lanthanide '{reference}' not found in spectra file")
+    order = [hits[0]] + [i for i in range(len(table)) if i != hits[0]]  # the reference lanthanide first
+    table = table.reindex(order)
+    lanthanides = table["name"].to_list()
+    code_table = pd.read_csv(codes)
+    if set(code_table.columns) - {"name"} != set(lanthanides):
+        raise ValueError(f"Lanthanide names in {codes} do not match lanthanide names in {spectra}.")
+
+    names = [str(c) for c in np.asarray(assay.coords["channel"].values).tolist()]
+    use = [i for i, c in enumerate(names) if c in table.columns]
+    sp = table[[names[i] for i in use]].to_numpy(dtype=np.float64)  # (lanthanide, channel)
+    inten = reduce.fg_mean_minus_bg_median(assay).transpose("mark", "channel", "time").data
+    inten = inten[:, use, 0].cpu().numpy()  # (mark, channel) at time 0
+    volumes = np.linalg.lstsq(sp.T, inten.T, rcond=None)[0].T
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ratios = volumes / volumes[:, 0:1]
+    assay = assay.assign_coords(ln=("ln", lanthanides))
+    assay["ln_vol"] = (("mark", "ln"), volumes)
+    assay["ln_ratio"] = (("mark", "ln"), ratios)
+    if decode:
+        raise NotImplementedError("code assignment of identify_mrbles (identify.py:92-234) is not part of this build")
+    return assay

@@ -5,6 +5,7 @@ the reference detector is unseeded."""
 import numpy as np
 import pytest
 
+from oracle import ref_pipeline as rp
 from synth import draw_beads
 
 pytestmark = pytest.mark.gpu
@@ -183,3 +184,51 @@ def test_stitcher_component(mg):
         Stitcher(overlap=10)(mg.Dataset({"other": mg.DataArray([1, 2, 3], ("x",))}))
     with pytest.raises(ValueError):
         Stitcher(overlap=100)(mg.Dataset({"tile": mg.DataArray(rng.random((1, 1, 2, 2, 50, 50)), dims)}))
+
+
+def test_mrbles_front_half(mg, tmp_path):
+    """identify.py:50-90 through mg.mrbles: fg mean - bg median per channel, least-squares lanthanide
+    volumes against the spectra, ratios to the reference lanthanide; and the reference's ValueErrors."""
+    rng = np.random.default_rng(5)
+    spectra = np.array([[1.0, 0.2, 0.0], [0.1, 1.0, 0.3], [0.0, 0.25, 1.0]])  # (lanthanide, channel)
+    lns, chans = ["eu", "dy", "sm"], ["c620", "c572", "c600"]
+    pos = [[120, 120], [120, 360], [360, 120], [360, 360], [240, 240]]
+    vols = rng.uniform(200, 900, size=(len(pos), 3))
+    data = np.zeros((3, 480, 480), dtype=np.uint16)
+    for c in range(3):
+        inten = (vols @ spectra[:, c]).round().astype(int)
+        data[c] = draw_beads((480, 480), pos, 20, inten) + np.uint16(100)  # flat background, like the reference's tests
+    sp_csv, codes_csv = tmp_path / "spectra.csv", tmp_path / "codes.csv"
+    # the file lists dy first: the reference lanthanide must still come out first
+    sp_csv.write_text("name," + ",".join(chans) + "\n" + "dy," + ",".join(map(str, spectra[1])) + "\n" +
+                      "eu," + ",".join(map(str, spectra[0])) + "\n" + "sm," + ",".join(map(str, spectra[2])) + "\n")
+    codes_csv.write_text("name,eu,dy,sm\ncode0,1,0.5,0.2\ncode1,1,1.0,0.4\n")
+    pipe = mg.mrbles_pipe(spectra=str(sp_csv), codes=str(codes_csv), min_bead_diameter=16, max_bead_diameter=24,
+                          overlap=0, num_iter=20000)
+    pipe.remove_pipe("restore_format")
+    xp = pipe(arr(mg, data, ("channel", "y", "x"), channel=chans))
+    assert list(xp.ln.values) == ["eu", "dy", "sm"]
+    m = xp.roi.sizes["mark"]
+    assert m == len(pos) and xp.ln_vol.shape == (m, 3) and xp.ln_ratio.shape == (m, 3)
+    # oracle: the same expression on the returned arrays
+    roi = xp.roi.transpose("mark", "channel", "time", "roi_y", "roi_x").values
+    fg = xp.fg.transpose("mark", "time", "roi_y", "roi_x").values
+    bg = xp.bg.transpose("mark", "time", "roi_y", "roi_x").values
+    red = rp.roi_reduce(roi, fg, bg)
+    inten = (red["fg_mean"] - red["bg_median"])[:, :, 0]
+    sp = np.stack([spectra[0], spectra[1], spectra[2]])  # eu, dy, sm
+    want = np.linalg.lstsq(sp.T, inten.T, rcond=None)[0].T
+    np.testing.assert_array_equal(xp.ln_vol.values, want)
+    np.testing.assert_array_equal(xp.ln_ratio.values, want / want[:, 0:1])
+    # beads are found in some order: match by position, volumes recovered to a few percent
+    got = {(int(round(y / 120)), int(round(x / 120))): v for y, x, v in zip(xp.y.values[:, 0], xp.x.values[:, 0], want)}
+    for p, v in zip(pos, vols):
+        np.testing.assert_allclose(got[(p[0] // 120, p[1] // 120)], v, rtol=0.05)
+    with pytest.raises(ValueError):
+        mg.mrbles(arr(mg, data, ("channel", "y", "x"), channel=chans), spectra=str(sp_csv), codes=str(codes_csv),
+                  reference="tm", min_bead_diameter=16, max_bead_diameter=24, overlap=0, num_iter=2000)
+    bad = tmp_path / "bad.csv"
+    bad.write_text("name,eu,dy\ncode0,1,0.5\n")
+    with pytest.raises(ValueError):
+        mg.mrbles(arr(mg, data, ("channel", "y", "x"), channel=chans), spectra=str(sp_csv), codes=str(bad),
+                  min_bead_diameter=16, max_bead_diameter=24, overlap=0, num_iter=2000)
