@@ -208,3 +208,61 @@ def test_button_finder_stages_match_oracle(mg):
     np.testing.assert_allclose(x, x_o, atol=1e-9)
     np.testing.assert_allclose(y, y_o, atol=1e-9)
     assert radius[1, 2] == 16 and (radius[tag != ""] <= 12).all()
+
+
+def test_marker_filters(mg):
+    """filter_expression / filter_leaky (filter.py:11-37, 65-94) on the device medians against the
+    reference's expressions evaluated with NumPy on the same arrays."""
+    import torch
+
+    from oracle import ref_pipeline as rp
+
+    rng = np.random.default_rng(3)
+    n_rows, n_cols, L = 4, 5, 24
+    m = n_rows * n_cols
+    roi = rng.integers(90, 120, size=(m, 2, 1, L, L)).astype(np.uint16)
+    fg = np.zeros((m, 1, L, L), dtype=bool)
+    fg[:, :, 8:16, 8:16] = True
+    bg = np.zeros_like(fg)
+    bg[:, :, :4, :] = True
+    bright = rng.random(m) < 0.5
+    bright[[2, 7, 13]] = False  # the blanks: 2 and 7 stay dark
+    roi[bright, 0, :, 8:16, 8:16] += 400  # expression in channel 0 only
+    tag = np.array(["x"] * m, dtype="<U8")
+    tag[[2, 7, 13]] = ""  # blanks
+    bright[13] = True
+    roi[13, 0, :, 8:16, 8:16] += 400  # a leaking blank: its tagged neighbours must go
+    rows = np.repeat(np.arange(n_rows), n_cols)
+    ds = mg.Dataset({"roi": mg.DataArray(torch.from_numpy(roi.view(np.int16)).view(torch.uint16).cuda(),
+                                         ("mark", "channel", "time", "roi_y", "roi_x"))},
+                    coords={"fg": (("mark", "time", "roi_y", "roi_x"), fg), "bg": (("mark", "time", "roi_y", "roi_x"), bg),
+                            "valid": (("mark", "time"), np.ones((m, 1), dtype=bool)), "tag": (("mark",), tag),
+                            "mark_row": (("mark",), rows), "channel": ["gfp", "dna"]})
+    red = rp.roi_reduce(roi, fg, bg)
+    fgm, bgm = red["fg_median"][:, :, 0], red["bg_median"][:, :, 0]
+
+    def spread(b):
+        d = b[:, None] - b[None, :]
+        return d[~np.eye(len(b), dtype=bool)].std()
+
+    out = mg.filter.filter_expression(ds, search_channel="gfp")
+    want = (fgm[:, 0] - bgm[:, 0]) > 4 * spread(bgm[:, 0])
+    np.testing.assert_array_equal(out.valid.values[:, 0], want)
+    assert want.sum() == bright.sum()
+    out = mg.filter.filter_expression(ds, min_contrast=1000)
+    assert not out.valid.values.any()
+    out = mg.filter.filter_leaky_buttons(ds, search_channel=["gfp"])
+    empty = (fgm[:, 0] - bgm[:, 0]) < 5 * spread(bgm[:, 0])
+    want = np.ones(m, dtype=bool)
+    for i in range(m):
+        if tag[i] == "":
+            continue
+        if rows[i] > 0 and tag[i - 1] == "":
+            want[i] &= empty[i - 1]
+        if rows[i] < rows.max() and tag[i + 1] == "":
+            want[i] &= empty[i + 1]
+    np.testing.assert_array_equal(out.valid.values[:, 0], want)
+    assert not want[12] and not want[14] and want[6] and want[8]
+    with pytest.raises(NotImplementedError):
+        mg.filter.filter_nonround(ds)
+    assert {"filter_expression", "filter_leaky", "filter_nonround"} <= set(mg.components.get_all())
