@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="detection sub-batches on separate HIP streams")
     ap.add_argument("--sub-batches", type=int, default=0, help="sub-batches of assays (0 = one per stream)")
     ap.add_argument("--cpu-assays-per-core", type=int, default=2)
+    ap.add_argument("--from-host", action="store_true",
+                    help="the stack starts every step in pinned HOST memory (PCIe-inclusive rate; not the headline)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-stream pass")
     args = ap.parse_args()
@@ -161,8 +163,10 @@ def main():
                           search_channels=(0,), mode="P", plane_batch=args.plane_batch or None, device=dev,
                           n_streams=args.streams, sub_batches=args.sub_batches or None)
 
+    src = stack.cpu().pin_memory() if args.from_host else stack
+
     def step(seed):
-        out = proc(stack, flat, 100.0, seed=seed)
+        out = proc(src, flat, 100.0, seed=seed)
         table = mgd.marker_table(out, rank * T, C, dev)
         table = mgd.gather_marker_table(table)
         return out, table
@@ -252,7 +256,7 @@ def main():
             "metric": "megapixels/sec through flatfield+segment+ROI-reduce; markers/sec",
             "value": mp_total / (dt / args.steps), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u16", "data": "synthetic" + (" (host-resident, PCIe-inclusive)" if args.from_host else ""),
             "config": {"workload": f"C4: {T} timepoints x {C} ch x {S}x{S} uint16 per GPU, mode P (per-timepoint "
                                    f"detection), search channel 0, num_iter={args.num_iter}, vignette flat-field, "
                                    f"dark=100, roi_length={proc.L}",

@@ -41,6 +41,7 @@ class StackProcessor:
         self.n_assays = n_t if mode == "P" else 1
         self.n_streams = n_streams if (self.n_assays >= 2 * n_streams and not plane_batch) else 1
         self.step_stats = []  # per sub-batch (device counters, host counters) of the last call
+        self.stage = None  # device staging buffer of the host-ingest path
         if self.n_streams > 1:
             # The stack is cut into contiguous sub-batches of assays; HIP stream / host thread k works
             # through sub-batches k, k + n_streams, ...: flat-field (mode P: every assay has its own
@@ -106,7 +107,16 @@ class StackProcessor:
         errors = []
         self.step_stats = []
         T, C, h, w = self.T, self.C, self.h, self.w
-        tiles = stack.view(T * C, 1, 1, 1, h, w) if stack is not None else None
+        host = stack is not None and not stack.is_cuda
+        if host:
+            # Host ingest: the stack sits in (pinned) host memory; every stream
+            # uploads its own sub-batch into a device staging buffer right before it needs it, so the
+            # PCIe transfer of one sub-batch overlaps the kernels of the others.
+            if self.stage is None:
+                self.stage = torch.empty((T, C, h, w), dtype=stack.dtype, device=self.dev)
+            tiles = self.stage.view(T * C, 1, 1, 1, h, w)
+        else:
+            tiles = stack.view(T * C, 1, 1, 1, h, w) if stack is not None else None
 
         def work(k):
             try:
@@ -114,6 +124,8 @@ class StackProcessor:
                 stream.wait_stream(main)  # the caller's stream produced the stack / the flat-field pass
                 with torch.cuda.stream(stream):
                     for lo, hi in self.ranges[k :: self.n_streams]:
+                        if host:
+                            self.stage[lo:hi].copy_(stack[lo:hi], non_blocking=True)
                         if tiles is not None:
                             hp.flatfield_stitch(tiles[lo * C : hi * C], 0, flatfield, darkfield, out=self.image[lo:hi],
                                                 minmax_out=self.minmax[lo:hi], n_groups=hi - lo)
@@ -156,6 +168,8 @@ class StackProcessor:
             beads = [np.empty((0, 3), dtype=np.int32) for _ in range(self.n_assays)]
             beads = self._detect_streams(seed, beads, stack, flatfield, darkfield)  # flat-field per sub-batch
         else:
+            if not stack.is_cuda:
+                stack = stack.to(self.dev, non_blocking=True)
             self.flatfield(stack, flatfield, darkfield)
             beads = self.detect(seed)
         out = self.segment_reduce(beads, want_roi=want_roi)

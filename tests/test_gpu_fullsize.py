@@ -72,6 +72,9 @@ def test_streamed_detection_is_identical(mg):
         assert proc.n_streams == n_streams
         if n_streams > 1:
             assert len(proc.ranges) == (sub or n_streams)
+    # host ingest: the same stack handed over in pinned host memory, uploaded per sub-batch
+    proc = StackProcessor(6, 2, 512, 640, num_iter=100000, search_channels=(0, 1), mode="P", n_streams=3)
+    outs.append(proc(stack.cpu().pin_memory(), 0.9, 100.0, seed=5))
     for other in outs[1:]:
         for a, b in zip(outs[0]["beads"], other["beads"]):
             np.testing.assert_array_equal(a, b)
