@@ -310,8 +310,9 @@ __device__ __forceinline__ void hist_add4(const Row12& ra, const Row12& rb, cons
 }
 
 __device__ __forceinline__ bool hist_group_interior(const uint8_t* pb, int h, int w, int tx0, int gy) {
-  const int y_first = gy * HIST_TILES * TH, y_end = y_first + HIST_TILES * TH;  // rows [y_first, y_end)
-  return tx0 >= 4 && tx0 + TW + 4 <= w && y_first >= 1 && y_end + 1 <= h && (w & 3) == 0 &&
+  // "interior" for the register-direct kernel = every tile of the group lies inside the image
+  // horizontally (rows and the image's left / right edge are reflected in the kernel itself)
+  return gy * HIST_TILES * TH < h && tx0 + TW <= w && (w & 3) == 0 && h >= 2 &&
          (reinterpret_cast<uintptr_t>(pb) & 3) == 0;
 }
 
@@ -348,23 +349,27 @@ __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ 
 #pragma unroll 1
     for (int sub = 0; sub < HIST_TILES; ++sub) {
       const int y0 = (blockIdx.y * HIST_TILES + sub) * TH + wave * RPW;  // first row of this wave's strip
+      if (y0 >= h) break;  // wave-uniform: this strip lies below the image
+      const bool at_left = tx0 == 0, at_right = tx0 + TW == w;  // image edges: BORDER_REFLECT_101
       uint32_t mid[RPW + 2], edge[RPW + 2];
 #pragma unroll
       for (int j = 0; j < RPW + 2; ++j) {
-        const uint32_t* rowp = reinterpret_cast<const uint32_t*>(pb + (int64_t)(y0 - 1 + j) * w + tx0);
+        const int ry = mg_reflect101(y0 - 1 + j, h);
+        const uint32_t* rowp = reinterpret_cast<const uint32_t*>(pb + (int64_t)ry * w + tx0);
         mid[j] = rowp[lane];
         edge[j] = 0;
-        if (lane == 0) edge[j] = rowp[-1];
-        else if (lane == 63) edge[j] = rowp[64];
+        if (lane == 0 && !at_left) edge[j] = rowp[-1];
+        else if (lane == 63 && !at_right) edge[j] = rowp[64];
       }
       Row12 ra, rb;
 #pragma unroll
       for (int j = 0; j < RPW + 2; ++j) {
         uint32_t d0 = (uint32_t)__shfl_up((int)mid[j], 1), d2 = (uint32_t)__shfl_down((int)mid[j], 1);
-        if (lane == 0) d0 = edge[j];
-        if (lane == 63) d2 = edge[j];
+        // pixel -1 of the image is pixel 1, pixel w is pixel w - 2 (only those two bytes are ever read)
+        if (lane == 0) d0 = at_left ? (mid[j] & 0x0000FF00u) << 16 : edge[j];
+        if (lane == 63) d2 = at_right ? (mid[j] >> 16) & 0xFFu : edge[j];
         const Row12 rc{d0, mid[j], d2};
-        if (j >= 2) hist_add4(ra, rb, rc, gx, w, mode, base, n_bins, hist, zeros);
+        if (j >= 2 && y0 + j - 2 < h) hist_add4(ra, rb, rc, gx, w, mode, base, n_bins, hist, zeros);
         ra = rb;
         rb = rc;
       }
