@@ -272,6 +272,7 @@ class CircleFinder:
         self.angle = torch.empty((P, h, w), dtype=torch.float32, device=dev)  # valid at edge pixels
         self.hist = torch.zeros((P, COMBINED_BINS), dtype=i32, device=dev)
         self.hist_base = torch.zeros((P,), dtype=i32, device=dev)
+        self._hyst_hint, self._nms_hint = 4, 2  # sweeps / rounds the previous call needed
         # per-workgroup histogram slots: plain stores + a reduce kernel instead of global atomics
         self.hist_scratch = torch.empty((int(nat.lib().mg_scharr_hist_scratch_words(P, h, w, 0)),), dtype=i32, device=dev)
         self.thresh = torch.zeros((P, 2), dtype=i32, device=dev)
@@ -380,8 +381,10 @@ class CircleFinder:
         _call("mg_canny_nms", self.blur.data_ptr(), P, h, w, self.thresh.data_ptr(), self.weak_bits.data_ptr(),
               self.edge_bits.data_ptr(), self.words, s)
         sweeps = 0
-        group = 4  # sweeps per host check: a sweep after convergence only runs the tile-flag test
-        if self.changed.shape[0] != group:
+        # sweeps per host check: first as many as the previous call needed (a sweep after convergence only
+        # runs the tile-flag test), then two at a time -- one host round trip in the steady state
+        group = max(2, min(int(self._hyst_hint), 64))
+        if self.changed.shape[0] < group:
             self.changed = torch.zeros((group, P), dtype=torch.int32, device=self.dev)
         while True:
             self.changed.zero_()
@@ -394,7 +397,9 @@ class CircleFinder:
                 sweeps += 1
             if int(self.changed[group - 1].sum().item()) == 0:
                 break
+            group = 2
         self.stats["hysteresis_sweeps"] = sweeps
+        self._hyst_hint = sweeps
         if self.keep_debug_maps:
             self.edges = torch.empty((P, h, w), dtype=torch.uint8, device=self.dev)
             _call("mg_unpack_bits", self.edge_bits.data_ptr(), self.words, P, h * w, self.edges.data_ptr(), s)
@@ -458,7 +463,9 @@ class CircleFinder:
                 self.nms_grid.fill_(-1)  # once: every call restores the cells it touched (mg_nms_cleanup)
                 self.state.zero_()
             ring = torch.from_numpy(nat.circle_points(min_dist, True)).to(self.dev)
-            group = 2  # rounds per host check (a round with nothing undecided does no work)
+            # rounds per host check: the previous call's count first (a round with nothing undecided does
+            # no work), then two at a time
+            group = max(2, min(int(self._nms_hint), 64))
             while True:
                 for _ in range(group):
                     _call("mg_nms_round", self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
@@ -468,8 +475,10 @@ class CircleFinder:
                     rounds += 1
                 if int(self.undecided.sum().item()) == 0:
                     break
+                group = 2
                 if rounds > 10000:
                     raise RuntimeError("greedy suppression did not converge")
+            self._nms_hint = rounds
             self._nms_ring, self._nms_dist = ring, min_dist
         self.stats["nms_rounds"] = rounds
         out = torch.empty((P, out_cap, 3), dtype=torch.int32, device=self.dev)
