@@ -934,7 +934,7 @@ extern "C" int mg_edge_angles(const uint8_t* d_blur, int n_planes, int h, int w,
   if (!d_blur || !d_coords || !d_num_edges || !d_angle || n_planes < 0 || n_planes > 65535 || coord_cap < 0)
     return MG_EINVAL;
   if (n_planes == 0 || coord_cap == 0) return MG_OK;
-  const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((coord_cap + NT - 1) / NT, 4096));
+  const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((coord_cap + NT - 1) / NT, 1 << 20));  // one edge per thread
   hipLaunchKernelGGL(k_edge_angles, dim3(bx, n_planes), dim3(NT), 0, mg_stream(stream), d_blur, h, w, d_coords,
                      coord_cap, d_num_edges, d_angle);
   MG_CHECK_LAUNCH();
