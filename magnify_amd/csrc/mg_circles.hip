@@ -469,7 +469,7 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
         const int x = v >> 16, y = (int)(int16_t)(v & 0xFFFF);  // entry (dr, dc) = (x, y)
         hits += MG_BIT(x, y) + MG_BIT(y, x) + MG_BIT(-x, y) + MG_BIT(-y, x) + MG_BIT(x, -y) + MG_BIT(y, -x) +
                 MG_BIT(-x, -y) + MG_BIT(-y, -x);
-        if (hits + (p1 - p - 8) < need) break;  // cannot get there any more
+        // (no early exit: a wave runs as long as its slowest lane anyway, and the test cost more than it saved)
       }
       if (p + 4 == p1) {
         const int v = tab[p];
