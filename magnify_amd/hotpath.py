@@ -336,19 +336,20 @@ class CircleFinder:
         self.hist.zero_()
         _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 0, 0, self.hist.data_ptr(), self.hist_scratch.data_ptr(),
               self.hist_scratch.numel(), s)
-        ccum = torch.cumsum(self.hist.to(torch.int64), dim=1).cpu().numpy()
         n = h * w
-        want = []
-        for q in (low_q, high_q):
-            a, b, _ = quantile_indexes(n, q)
-            want += [a, b]
-        ranks = sorted(set(want))
-        # bin of every needed rank, per plane: fine bins give the order statistic directly
-        bins = np.stack([np.array([np.searchsorted(ccum[p], r, side="right") for r in ranks]) for p in range(P)])
+        idx = [quantile_indexes(n, q) for q in (low_q, high_q)]  # (prev, next, gamma) per quantile
+        ranks = sorted({i for a, b, _ in idx for i in (a, b)})
+        # bin of every needed rank, per plane (searched on the device: only P x 4 integers come back);
+        # fine bins give the order statistic directly
+        ccum_d = torch.cumsum(self.hist.to(torch.int64), dim=1)
+        ranks_d = torch.tensor(ranks, dtype=torch.int64, device=self.dev).expand(P, -1).contiguous()
+        bins = torch.searchsorted(ccum_d, ranks_d, right=True).cpu().numpy()
         order_stat = np.where(bins < FINE_BINS, bins, -1).astype(np.int64)
-        todo = [sorted({int(b) - FINE_BINS for b in bins[p] if b >= FINE_BINS}) for p in range(P)]
+        todo = [sorted({int(b) - FINE_BINS for b in bins[p] if b >= FINE_BINS}) for p in range(P)] \
+            if (bins >= FINE_BINS).any() else [[] for _ in range(P)]
         n_pass = max(len(t) for t in todo)
         self.stats["hist_passes"] = 1 + n_pass
+        ccum = ccum_d.cpu().numpy() if n_pass else None
         for k in range(n_pass):
             # window pass(es): resolve ranks that fell into a coarse bin (rare: strong gradients)
             base_bins = np.array([t[min(k, len(t) - 1)] if t else 0 for t in todo], dtype=np.int64)
@@ -366,17 +367,21 @@ class CircleFinder:
                 for j, r in enumerate(ranks):
                     if bins[p, j] == FINE_BINS + b:
                         order_stat[p, j] = (b << COARSE_SHIFT) + np.searchsorted(fcum[p], r - below, side="right")
-        thresh = np.zeros((P, 2), dtype=np.int32)
-        self.quantiles = np.zeros((P, 2), dtype=np.float32)
-        for p in range(P):
-            vals = []
-            for q in (low_q, high_q):
-                a, b, gamma = quantile_indexes(n, q)
-                ga = _grad_of(int(order_stat[p, ranks.index(a)]))
-                gb = _grad_of(int(order_stat[p, ranks.index(b)]))
-                vals.append(lerp_f32(ga, gb, gamma))
-            self.quantiles[p] = vals
-            thresh[p] = canny_int_thresholds(vals[0], vals[1])
+        # np.quantile's interpolation and cv::Canny's threshold preparation, vectorised over the planes
+        # (same float32 / float64 operations as quantile_indexes / lerp_f32 / canny_int_thresholds)
+        vals = []
+        for a, b, gamma in idx:
+            ga = np.sqrt(order_stat[:, ranks.index(a)].astype(np.float32))  # _grad_of
+            gb = np.sqrt(order_stat[:, ranks.index(b)].astype(np.float32))
+            diff = (gb - ga).astype(np.float32)
+            vals.append((gb - diff * np.float32(1 - gamma)).astype(np.float32) if gamma >= 0.5
+                        else (ga + diff * gamma).astype(np.float32))
+        self.quantiles = np.stack(vals, axis=1).astype(np.float32)
+        lo = np.minimum(vals[0], vals[1]).astype(np.float64)
+        hi = np.maximum(vals[0], vals[1]).astype(np.float64)
+        lo, hi = np.minimum(lo, 32767.0), np.minimum(hi, 32767.0)
+        lo, hi = np.where(lo > 0, lo * lo, lo), np.where(hi > 0, hi * hi, hi)
+        thresh = np.stack([np.floor(lo), np.floor(hi)], axis=1).astype(np.int32)
         self.thresh.copy_(torch.from_numpy(thresh))
         _call("mg_canny_nms", self.blur.data_ptr(), P, h, w, self.thresh.data_ptr(), self.weak_bits.data_ptr(),
               self.edge_bits.data_ptr(), self.words, s)
