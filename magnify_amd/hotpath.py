@@ -508,7 +508,9 @@ class CircleFinder:
         self.circle_stage(seeds, min_roundness, keep_raw=keep_raw)
         out, out_scores, num_out = self.nms_stage(min_dist)
         counts = num_out.cpu().numpy()
-        out_h, sc_h = out.cpu().numpy(), out_scores.cpu().numpy()
+        # only the filled prefix comes back (the full-capacity copies left the GPU idle for ~0.5 ms)
+        mx = max(int(counts.max()) if self.P else 0, 1)
+        out_h, sc_h = out[:, :mx].contiguous().cpu().numpy(), out_scores[:, :mx].contiguous().cpu().numpy()
         res = [(out_h[p, : counts[p]].copy(), sc_h[p, : counts[p]].copy()) for p in range(self.P)]
         self.stats["n_edges"] = n_edges
         return res, (out, out_scores, num_out)
