@@ -462,11 +462,16 @@ __global__ __launch_bounds__(256) void k_apply_stitch_aligned(const T* __restric
 #pragma unroll
         for (int j = 0; j < N; ++j) rr[j] = refined_rcp(fl[j]);
       }
+      // all planes' loads are issued before the first pixel is corrected (more bytes in flight per lane)
+      T xin[PB][N];
+#pragma unroll
+      for (int b = 0; b < PB; ++b)
+        if (b < np) load_vec<T, N>(tiles + (int64_t)(plane0 + b) * plane_elems + src0, xin[b]);
 #pragma unroll
       for (int b = 0; b < PB; ++b) {
         if (b >= np) break;
-        T x[N], o[N];
-        load_vec<T, N>(tiles + (int64_t)(plane0 + b) * plane_elems + src0, x);
+        T o[N];
+        T(&x)[N] = xin[b];
         if (APPLY) {
           const int group = (plane0 + b) / planes_per_group;
           const double m1 = d_max2[2 * group], m2 = d_max2[2 * group + 1];
