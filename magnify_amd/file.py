@@ -1,0 +1,136 @@
+"""``mg.save`` / ``mg.load`` (reference: src/magnify/file.py:6-17).
+
+The reference writes with ``xarray.Dataset.to_netcdf``.  Neither xarray nor a NetCDF-4 library is
+available to this build, so the file is NetCDF-3 (64-bit offset) written through
+``scipy.io.netcdf_file`` -- the format xarray's own ``scipy`` engine produces -- using xarray's
+encoding conventions, so that ``xr.open_dataset`` (and therefore the reference's ``mg.load``)
+decodes it: unsigned integers as the signed type of the same width with ``_Unsigned = "true"``,
+booleans as int8 with ``dtype = "bool"``, strings as char arrays over a ``string<N>`` dimension with
+``_Encoding = "utf-8"``, int64 narrowed to int32 when it fits, non-index coordinates listed in the
+``coordinates`` attribute.  NetCDF-3 limits a variable to 4 GiB: larger ROI stacks must be saved per
+shard (ROI pixels stay sharded by GPU anyway).
+
+As in the reference, a chip dataset is unstacked (mark -> mark_row, mark_col) before saving and
+restacked on load.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .xr_lite import DataArray, Dataset
+
+_LIMIT = (1 << 32) - 4
+
+
+def _encode(name, arr: np.ndarray):
+    """-> (array NetCDF-3 can hold, extra dims, attributes)."""
+    attrs = {}
+    extra = ()
+    if arr.dtype == np.bool_:
+        arr, attrs["dtype"] = arr.astype(np.int8), "bool"
+    elif arr.dtype.kind == "u":
+        signed = {1: np.int8, 2: np.int16, 4: np.int32}.get(arr.dtype.itemsize)
+        if signed is None:
+            raise TypeError(f"{name}: uint64 cannot be stored in NetCDF-3")
+        arr, attrs["_Unsigned"] = arr.view(signed), "true"
+    elif arr.dtype == np.int64:
+        if arr.size and (arr.min() < -(2**31) or arr.max() >= 2**31):
+            raise ValueError(f"{name}: int64 values do not fit the int32 of NetCDF-3")
+        arr = arr.astype(np.int32)
+    elif arr.dtype.kind in "US":
+        raw = np.char.encode(arr.astype(str), "utf-8") if arr.dtype.kind == "U" else arr
+        width = max(raw.dtype.itemsize, 1)
+        raw = raw.astype(f"S{width}")
+        arr = raw.view("S1").reshape(raw.shape + (width,))
+        extra = (f"string{width}",)
+        attrs["_Encoding"] = "utf-8"
+    elif arr.dtype.kind == "f" and arr.dtype.itemsize not in (4, 8):
+        arr = arr.astype(np.float32)
+    elif arr.dtype.kind not in "if":
+        raise TypeError(f"{name}: dtype {arr.dtype} cannot be stored in NetCDF-3")
+    if arr.nbytes > _LIMIT:
+        raise ValueError(f"{name}: {arr.nbytes} bytes exceed the 4 GiB variable limit of NetCDF-3; save per shard")
+    return np.ascontiguousarray(arr), extra, attrs
+
+
+def _decode(var, attrs):
+    arr = np.array(var.data)
+    dims = tuple(var.dimensions)
+    if arr.dtype.byteorder == ">":
+        arr = arr.astype(arr.dtype.newbyteorder("="))
+    if attrs.pop("_Unsigned", None) in ("true", b"true"):
+        arr = arr.view({1: np.uint8, 2: np.uint16, 4: np.uint32}[arr.dtype.itemsize])
+    if attrs.pop("dtype", None) in ("bool", b"bool"):
+        arr = arr.astype(bool)
+    if arr.dtype.kind == "S" and dims and dims[-1].startswith("string"):
+        attrs.pop("_Encoding", None)
+        width = arr.shape[-1]
+        arr = np.char.decode(np.ascontiguousarray(arr).view(f"S{width}").reshape(arr.shape[:-1]), "utf-8")
+        dims = dims[:-1]
+    return arr, dims
+
+
+def save(file, xp):
+    """file.py:6-8."""
+    from scipy.io import netcdf_file
+
+    ds = xp.unstack() if isinstance(xp, Dataset) else Dataset({xp.name or "data": xp})
+    coord_names = [k for k, c in ds.coords.items() if not (c.dims == (k,))]
+    with netcdf_file(str(file), "w", version=2) as nc:
+        def dim(name, size):
+            if name not in nc.dimensions:
+                nc.createDimension(name, int(size))
+
+        def put(name, v, is_data_var):
+            arr, extra, attrs = _encode(name, np.asarray(v.values))
+            dims = tuple(v.dims) + extra
+            for d, n in zip(dims, arr.shape):
+                dim(d, n)
+            var = nc.createVariable(name, "c" if arr.dtype.kind == "S" else arr.dtype, dims)
+            if arr.ndim:
+                var[...] = arr
+            else:
+                var.assignValue(arr)
+            for k, a in dict(v.attrs or {}, **attrs).items():
+                if isinstance(a, (str, bytes, int, float, np.integer, np.floating)):
+                    setattr(var, k, a)
+            if is_data_var:
+                mine = [c for c in coord_names if set(ds.coords[c].dims) <= set(v.dims)]
+                if mine:
+                    var.coordinates = " ".join(mine)
+
+        for k, v in ds.data_vars.items():
+            put(k, v, True)
+        for k, c in ds.coords.items():
+            put(k, c, False)
+        if coord_names:
+            nc.coordinates = " ".join(coord_names)
+        for k, a in ds.attrs.items():
+            if isinstance(a, (str, bytes, int, float, np.integer, np.floating)):
+                setattr(nc, k, a)
+            elif isinstance(a, (list, tuple)) and all(isinstance(x, str) for x in a):
+                setattr(nc, k, " ".join(a))
+
+
+def load(file):
+    """file.py:11-17."""
+    from scipy.io import netcdf_file
+
+    def text(a):
+        return a.decode() if isinstance(a, bytes) else a
+
+    with netcdf_file(str(file), "r", mmap=False) as nc:
+        listed = set(text(getattr(nc, "coordinates", "")).split())
+        decoded = {}
+        for name, var in nc.variables.items():
+            attrs = {k: text(v) for k, v in var._attributes.items()}
+            listed |= set(attrs.pop("coordinates", "").split())
+            arr, dims = _decode(var, attrs)
+            decoded[name] = DataArray(arr, dims, None, name, attrs)
+        global_attrs = {k: text(v) for k, v in nc._attributes.items() if k != "coordinates"}
+    coords = {k: v for k, v in decoded.items() if k in listed or v.dims == (k,)}
+    data_vars = {k: v for k, v in decoded.items() if k not in coords}
+    xp = Dataset(data_vars, coords=coords, attrs=global_attrs)
+    if "mark_row" in xp.sizes and "mark_col" in xp.sizes:
+        xp = xp.stack_mark()
+    return xp

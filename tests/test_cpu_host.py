@@ -218,3 +218,44 @@ def test_mark_stack_unstack():
     back = st.unstack()
     np.testing.assert_array_equal(back.x.values, x.values)
     assert back.x.dims == ("mark_row", "mark_col", "time")
+
+
+def test_save_load_roundtrip(tmp_path):
+    """mg.save / mg.load (file.py:6-17): NetCDF-3 with xarray's encoding conventions; a chip dataset
+    is unstacked on save and restacked on load."""
+    rng = np.random.default_rng(0)
+    nr, nc, L = 3, 4, 6
+    roi = rng.integers(0, 65535, size=(nr, nc, 2, 1, L, L)).astype(np.uint16)
+    fg = rng.random((nr, nc, 1, L, L)) > 0.5
+    tag = np.array([["a", "", "gfp-long-name", "x"]] * nr)
+    ds = mg.Dataset({"roi": mg.DataArray(roi, ("mark_row", "mark_col", "channel", "time", "roi_y", "roi_x")),
+                     "image": mg.DataArray(rng.integers(0, 9, (2, 1, 8, 9)).astype(np.uint16), ("channel", "time", "im_y", "im_x"))},
+                    coords={"fg": (("mark_row", "mark_col", "time", "roi_y", "roi_x"), fg),
+                            "x": (("mark_row", "mark_col", "time"), rng.random((nr, nc, 1))),
+                            "tag": (("mark_row", "mark_col"), tag), "channel": ["egfp", "dna"],
+                            "time": np.array([7], dtype=np.int64)},
+                    attrs={"name": "chip 1", "overlap": 102})
+    stacked = ds.stack_mark()
+    path = tmp_path / "assay.nc"
+    mg.save(path, stacked)
+    back = mg.load(path)
+    assert back.roi.dims[0] == "mark" and back.roi.shape == (nr * nc, 2, 1, L, L)
+    np.testing.assert_array_equal(back.roi.values, stacked.roi.values)
+    assert back.roi.dtype == np.uint16 and back.fg.dtype == np.bool_
+    np.testing.assert_array_equal(back.fg.values, stacked.fg.values)
+    np.testing.assert_array_equal(back.x.values, stacked.x.values)
+    np.testing.assert_array_equal(back.tag.values, stacked.tag.values)
+    np.testing.assert_array_equal(back.image.values, ds.image.values)
+    assert list(back.channel.values) == ["egfp", "dna"] and int(back.time.values[0]) == 7
+    assert back.attrs["name"] == "chip 1" and int(back.attrs["overlap"]) == 102
+    assert "fg" in back.coords and "roi" in back.data_vars and "tag" in back.coords
+    # the file is a plain NetCDF-3 that follows xarray's conventions
+    from scipy.io import netcdf_file
+
+    with netcdf_file(str(path), "r", mmap=False) as f:
+        assert f.variables["roi"].dimensions[:2] == ("mark_row", "mark_col")
+        assert f.variables["roi"]._attributes["_Unsigned"] in ("true", b"true")
+        assert f.variables["fg"]._attributes["dtype"] in ("bool", b"bool")
+        assert f.variables["tag"].dimensions[-1].startswith("string")
+    with pytest.raises(ValueError):
+        mg.save(tmp_path / "big.nc", mg.Dataset({"v": mg.DataArray(np.array([2**40]), ("n",))}))
