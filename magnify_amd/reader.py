@@ -1,13 +1,154 @@
-"""Reader (reference: src/magnify/reader.py:23-77).  Only the in-memory pass-through branch
-(reader.py:31-35) is on the hot path and implemented: DataArray / Dataset objects (magnify_amd's or
-real xarray's) or a sequence of them are yielded one assay at a time.  The path-pattern parser and
-the lazy TIFF reader (reader.py:80-324) are file I/O, out of scope for this build.
+"""Reader (reference: src/magnify/reader.py).
+
+In-memory inputs (DataArray / Dataset objects, magnify_amd's or real xarray's, or a sequence of
+them) pass straight through (reader.py:31-35).  Path patterns follow the reference's grammar
+(reader.py:80-160): named groups ``(assay)``, ``(channel)``, ``(time)`` / ``(time|%Y%m%d)``,
+``(row)``, ``(col)`` select the file's place in the tile array, ``(name_key|formatter|format)`` groups
+attach an alternative labelling ``name`` to dimension ``key``; ``*`` / ``?`` / ``**`` glob as usual.
+Files are TIFFs read with Pillow (tifffile / OME / MicroManager metadata are not available to this
+build): one 2-D page per file, or an ImageJ hyperstack whose description names ``channels`` /
+``frames``.  Reading is eager into one host array per assay -- SURVEY 8f N2's streaming half is the
+per-stream upload of ``StackProcessor`` (host-resident stack -> HBM, overlapped with compute).
 """
 from __future__ import annotations
 
+import collections
+import datetime
+import fnmatch
+import glob
 import os
+import re
+
+import numpy as np
 
 from . import registry, xr_lite
+from .utils import natural_sort_key
+
+_GROUP = re.compile(r"\(([^()|]*?)(?:\s*\|\s*([^()|]*?))?(?:\s*\|\s*([^()|]*?))?\)")
+_FORMAT = {
+    "": lambda text, fmt: text,
+    "str": lambda text, fmt: text,
+    "int": lambda text, fmt: int(text),
+    "float": lambda text, fmt: float(text),
+    "time": lambda text, fmt: datetime.datetime.strptime(text, fmt if fmt else "%Y%m%d-%H%M%S"),
+}
+
+
+def _glob_to_regex(literal: str) -> str:
+    """fnmatch's translation of a literal pattern piece, without its anchors."""
+    full = fnmatch.translate(literal)
+    return full[len("(?s:") : full.rindex(")")]
+
+
+def extract_paths(pattern, **keys):
+    """reader.py:80-160.  Returns (path_dict, meta_dict): ``path_dict[idx tuple over all keys] = path``
+    (None where the pattern has no group for a key), ``meta_dict[(name, key)][key value] = meta value``."""
+    pattern = os.path.expanduser(str(pattern))
+    kinds = {k: (f if callable(f) else _FORMAT[f]) for k, f in keys.items()}
+    glob_parts, regex_parts, pos = [], [], 0
+    dim_fmt, metas = {}, []  # key -> format string;  (name, key, formatter, format string)
+    for m in _GROUP.finditer(pattern):
+        head, a, b = m.group(1).strip(), m.group(2), m.group(3)
+        owner = next((k for k in keys if head == k), None)
+        meta_of = next((k for k in keys if head.endswith("_" + k) and len(head) > len(k) + 1), None)
+        if owner is None and meta_of is None:
+            continue  # an ordinary parenthesis in a file name
+        glob_parts.append(pattern[pos : m.start()] + "*")
+        regex_parts.append(_glob_to_regex(pattern[pos : m.start()]))
+        if owner is not None:
+            dim_fmt[owner] = a
+            regex_parts.append(f"(?P<{owner}>[^/\\\\]*?)")
+        else:
+            name = head[: -len(meta_of) - 1]
+            metas.append((name, meta_of, _FORMAT[(a or "").strip()], b))
+            regex_parts.append(f"(?P<{name}>[^/\\\\]*?)")
+        pos = m.end()
+    glob_parts.append(pattern[pos:])
+    regex_parts.append(_glob_to_regex(pattern[pos:]))
+    regex = re.compile("(?s:" + "".join(regex_parts) + r")\Z", re.IGNORECASE)
+    path_dict, meta_dict = {}, collections.defaultdict(dict)
+    for path in glob.glob("".join(glob_parts), recursive=True):
+        match = regex.fullmatch(path)
+        if match is None:
+            continue
+        idx = tuple(kinds[k](match.group(k), dim_fmt[k]) if k in dim_fmt else None for k in keys)
+        for name, key, formatter, fmt in metas:
+            if key in dim_fmt:
+                meta_dict[name, key][idx[list(keys).index(key)]] = formatter(match.group(name), fmt)
+        if idx in path_dict:
+            raise ValueError(f"{path} and {path_dict[idx]} map to the same index.")
+        path_dict[idx] = os.path.abspath(path)
+    return path_dict, meta_dict
+
+
+def _open_tiff(path):
+    """-> (pages as a list of 2-D arrays, dims of the page axis: [] / ['time'] / ['channel'] / both)."""
+    from PIL import Image
+
+    with Image.open(path) as im:
+        n = getattr(im, "n_frames", 1)
+        desc = im.tag_v2.get(270, "") if hasattr(im, "tag_v2") else ""
+        pages = []
+        for i in range(n):
+            im.seek(i)
+            pages.append(np.array(im))
+    if n == 1:
+        return pages, [], ()
+    found = {k: int(v) for k, v in re.findall(r"(channels|frames|slices)=(\d+)", desc if isinstance(desc, str) else "")}
+    if found.get("slices", 1) > 1:
+        raise ValueError("tiff files with a Z dimension are not yet supported.")
+    n_c, n_t = found.get("channels", 1), found.get("frames", 1)
+    if n_c * n_t != n:
+        raise ValueError(f"{path}: {n} pages but no ImageJ hyperstack description that explains them "
+                         "(OME / MicroManager metadata are not readable in this build)")
+    dims, shape = [], ()
+    if n_t > 1:
+        dims, shape = dims + ["time"], shape + (n_t,)
+    if n_c > 1:
+        dims, shape = dims + ["channel"], shape + (n_c,)
+    return pages, dims, shape
+
+
+def read_tiffs(xp_dict, name, meta_dict):
+    """reader.py:163-324: one Dataset with ``tile`` over the dimensions found in the paths and inside
+    the files, in the standard order (channel, time, tile_row, tile_col, tile_y, tile_x)."""
+    channel_idx, time_idx, row_idx, col_idx = (sorted(set(i)) for i in zip(*xp_dict.keys()))
+    in_path, outer = [], ()
+    for dim, values in (("channel", channel_idx), ("time", time_idx), ("tile_row", row_idx), ("tile_col", col_idx)):
+        if values[0] != -1:
+            in_path.append(dim)
+            outer += (len(values),)
+    files = [p for _, p in sorted(xp_dict.items())]
+    pages0, in_file, inner = _open_tiff(files[0])
+    if set(in_file) & set(in_path):
+        raise ValueError("Dimensions specified in the path names and inside the tiff file overlap.")
+    ty, tx = pages0[0].shape[:2]
+    if len(files) != int(np.prod(outer, dtype=np.int64)):
+        raise ValueError(f"{name or 'assay'}: {len(files)} files do not fill the {outer} array the pattern describes")
+    tiles = np.empty(outer + inner + (ty, tx), dtype=pages0[0].dtype)
+    flat = tiles.reshape((-1,) + (ty, tx))
+    per_file = int(np.prod(inner, dtype=np.int64)) if inner else 1
+    for f, path in enumerate(files):
+        pages = pages0 if f == 0 else _open_tiff(path)[0]
+        if len(pages) != per_file or pages[0].shape[:2] != (ty, tx):
+            raise ValueError(f"{path}: page count / size differs from {files[0]}")
+        for k, page in enumerate(pages):
+            flat[f * per_file + k] = page
+    coords = {}
+    if "channel" in in_path:
+        coords["channel"] = list(channel_idx)
+    if "time" in in_path:
+        coords["time"] = [int(t.timestamp()) if isinstance(t, datetime.datetime) else t for t in time_idx]
+    xp = xr_lite.Dataset({"tile": xr_lite.DataArray(tiles, tuple(in_path + in_file + ["tile_y", "tile_x"]))},
+                         coords=coords, attrs={"name": name})
+    order = [d for d in ("channel", "time", "tile_row", "tile_col", "tile_y", "tile_x") if d in xp.tile.dims]
+    xp = xp.transpose(*order)
+    for (meta_name, dim), table in meta_dict.items():
+        keys = time_idx if dim == "time" else {"channel": channel_idx, "row": row_idx, "col": col_idx}.get(dim, [])
+        axis = {"row": "tile_row", "col": "tile_col"}.get(dim, dim)
+        if axis in xp.sizes:
+            xp = xp.assign_coords({meta_name: ((axis,), [table[k] for k in keys])})
+    return xp
 
 
 class Reader:
@@ -15,12 +156,18 @@ class Reader:
         single = isinstance(data, (str, bytes, os.PathLike, xr_lite.DataArray, xr_lite.Dataset)) or \
             type(data).__module__.startswith("xarray")
         for d in ([data] if single else data):
-            if isinstance(d, (str, bytes, os.PathLike)):
-                if not os.path.exists(os.fspath(d)) and not any(ch in str(d) for ch in "*?({"):
-                    raise FileNotFoundError(f"The pattern {d} did not lead to any files.")
-                raise NotImplementedError("reading image files is outside the MI355X hot path (SURVEY.md 8f, N2); "
-                                          "pass an in-memory DataArray")
-            yield xr_lite.from_any(d)
+            if not isinstance(d, (str, bytes, os.PathLike)):
+                yield xr_lite.from_any(d)
+                continue
+            path_dict, meta_dict = extract_paths(os.fspath(d), assay="str", channel="str", time="time", row="int",
+                                                 col="int")
+            if len(path_dict) == 0:
+                raise FileNotFoundError(f"The pattern {d} did not lead to any files.")
+            path_dict = {(("",) + k[1:]) if k[0] is None else k: v for k, v in path_dict.items()}
+            for xp_name in sorted({k[0] for k in path_dict}, key=natural_sort_key):
+                xp_dict = {tuple(-1 if x is None else x for x in k[1:]): v for k, v in path_dict.items()
+                           if k[0] == xp_name}
+                yield read_tiffs(xp_dict, name=xp_name, meta_dict=meta_dict)
 
     @registry.readers.register("read")
     def make():

@@ -259,3 +259,67 @@ def test_save_load_roundtrip(tmp_path):
         assert f.variables["tag"].dimensions[-1].startswith("string")
     with pytest.raises(ValueError):
         mg.save(tmp_path / "big.nc", mg.Dataset({"v": mg.DataArray(np.array([2**40]), ("n",))}))
+
+
+def _write_tiff(path, arr, pages=None, description=None):
+    from PIL import Image
+
+    if pages is None:
+        Image.fromarray(arr).save(path)
+    else:
+        ims = [Image.fromarray(p) for p in pages]
+        ims[0].save(path, save_all=True, append_images=ims[1:], description=description)
+
+
+def test_reader_path_patterns(tmp_path):
+    """The reference's pattern grammar (reader.py:80-160) and tile assembly (reader.py:163-324) on
+    TIFF files written with Pillow."""
+    from magnify_amd import reader
+
+    rng = np.random.default_rng(1)
+    truth = {}
+    for assay in ("chipA", "chipB"):
+        for ch in ("egfp", "dna"):
+            for day, conc in (("20240102", "0.5"), ("20240105", "2.0")):
+                for r in range(2):
+                    for c in range(3):
+                        img = rng.integers(0, 60000, (5, 7)).astype(np.uint16)
+                        truth[assay, ch, day, r, c] = img
+                        _write_tiff(tmp_path / f"{assay}_{ch}_{day}_{conc}uM_r{r}c{c}.tif", img)
+    pattern = str(tmp_path / "(assay)_(channel)_(time|%Y%m%d)_(conc_time|float)uM_r(row)c(col).tif")
+    assays = list(reader.Reader()(pattern))
+    assert [a.attrs["name"] for a in assays] == ["chipA", "chipB"]
+    xp = assays[1]
+    assert xp.tile.dims == ("channel", "time", "tile_row", "tile_col", "tile_y", "tile_x")
+    assert xp.tile.shape == (2, 2, 2, 3, 5, 7) and xp.tile.dtype == np.uint16
+    assert list(xp.channel.values) == ["dna", "egfp"]
+    import datetime
+
+    assert list(xp.time.values) == [int(datetime.datetime(2024, 1, 2).timestamp()), int(datetime.datetime(2024, 1, 5).timestamp())]
+    assert list(xp.conc.values) == [0.5, 2.0] and xp.conc.dims == ("time",)
+    for (assay, ch, day, r, c), img in truth.items():
+        if assay == "chipB":
+            np.testing.assert_array_equal(
+                xp.tile.values[["dna", "egfp"].index(ch), ["20240102", "20240105"].index(day), r, c], img)
+    # no assay / time groups: a nameless experiment with the dimensions that are in the pattern
+    one = list(reader.Reader()(str(tmp_path / "chipA_(channel)_20240102_0.5uM_r(row)c(col).tif")))
+    assert len(one) == 1 and one[0].attrs["name"] == "" and one[0].tile.dims == ("channel", "tile_row", "tile_col", "tile_y", "tile_x")
+    with pytest.raises(FileNotFoundError):
+        list(reader.Reader()(str(tmp_path / "nothing_(channel).tif")))
+    with pytest.raises(ValueError):  # two files for one index
+        list(reader.Reader()(str(tmp_path / "chipA_(channel)_*_r0c0.tif")))
+    # ImageJ hyperstack: time and channel inside the file
+    pages = [rng.integers(0, 255, (4, 6)).astype(np.uint8) for _ in range(6)]
+    _write_tiff(tmp_path / "stack_r0c0.tif", None, pages, "ImageJ=1.53t\nimages=6\nchannels=2\nframes=3\nhyperstack=true")
+    hs = list(reader.Reader()(str(tmp_path / "stack_r(row)c(col).tif")))[0]
+    assert hs.tile.dims == ("channel", "time", "tile_row", "tile_col", "tile_y", "tile_x") and hs.tile.shape == (2, 3, 1, 1, 4, 6)
+    np.testing.assert_array_equal(hs.tile.values[1, 2, 0, 0], pages[2 * 2 + 1])  # channel is the fastest page axis
+    # and the pipeline entry point accepts the pattern (the stitch itself needs the GPU)
+    import torch
+
+    call = lambda: mg.image(str(tmp_path / "chipA_(channel)_20240102_0.5uM_r(row)c(col).tif"), overlap=0)  # noqa: E731
+    if torch.cuda.is_available():
+        assert call().image.shape == (2, 10, 21)
+    else:
+        with pytest.raises(RuntimeError):
+            call()
