@@ -242,17 +242,19 @@ int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, int64_t 
  * alive circles; d_undecided[n_planes] is overwritten with the number still undecided.
  * Ring = 4-connected perimeter of radius min_dist (d_ring_rc, ring_len); indices wrap
  * modulo the claim grid extent like negative numba indices do. */
+/* max_alive (both calls): an upper bound of d_num_alive known to the caller, used only to size the
+ * launch grid (0 = unknown: a grid for circle_cap). */
 int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
                  const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist,
                  const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
-                 int32_t* d_undecided, void* stream);
+                 int32_t* d_undecided, int64_t max_alive, void* stream);
 
 /* After the rounds have converged: restore the all-ones claim grid under the rings of all alive
  * circles, so that the grid needs its full initialisation only once. */
 int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
                    const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist,
                    const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
-                   void* stream);
+                   int64_t max_alive, void* stream);
 
 /* Gather the kept circles in priority order (utils.py:195-199 output order):
  * d_out[n_planes][out_cap][3] int32 (row, col, r), d_out_scores, d_num_out[n_planes].

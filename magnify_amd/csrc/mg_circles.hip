@@ -841,7 +841,7 @@ extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bit
 extern "C" int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
                             const int32_t* d_alive, const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes,
                             int min_dist, const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap,
-                            uint8_t* d_state, int32_t* d_undecided, void* stream) {
+                            uint8_t* d_state, int32_t* d_undecided, int64_t max_alive, void* stream) {
   if (!d_circles || !d_scores || !d_alive || !d_num_alive || !d_max_rc || !d_ring_rc || !d_grid || !d_state ||
       !d_undecided)
     return MG_EINVAL;
@@ -849,7 +849,9 @@ extern "C" int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const 
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
   hipStream_t s = mg_stream(stream);
   if (hipMemsetAsync(d_undecided, 0, sizeof(int32_t) * n_planes, s) != hipSuccess) return MG_ELAUNCH;
-  const dim3 g(grid_x(circle_cap), n_planes);
+  // the kernels walk d_alive with a grid-stride loop: max_alive (> 0: the caller's upper bound of
+  // d_num_alive) only sizes the grid -- an all-capacity grid of empty blocks costs ~0.1 ms per launch
+  const dim3 g(grid_x(max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap), n_planes);
   hipLaunchKernelGGL((k_nms<0>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
                      min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided);
   MG_CHECK_LAUNCH();
@@ -862,12 +864,13 @@ extern "C" int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const 
 extern "C" int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
                               const int32_t* d_alive, const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes,
                               int min_dist, const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap,
-                              uint8_t* d_state, void* stream) {
+                              uint8_t* d_state, int64_t max_alive, void* stream) {
   if (!d_circles || !d_scores || !d_alive || !d_num_alive || !d_max_rc || !d_ring_rc || !d_grid || !d_state)
     return MG_EINVAL;
   if (n_planes < 0 || n_planes > 65535 || min_dist <= 0 || ring_len <= 0) return MG_EINVAL;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
-  hipLaunchKernelGGL((k_nms<2>), dim3(grid_x(circle_cap), n_planes), dim3(NT), 0, mg_stream(stream), d_circles,
+  hipLaunchKernelGGL((k_nms<2>), dim3(grid_x(max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap), n_planes),
+                     dim3(NT), 0, mg_stream(stream), d_circles,
                      circle_cap, d_scores, d_alive, d_num_alive, d_max_rc, min_dist, d_ring_rc, ring_len, d_grid,
                      grid_cap, d_state, (int32_t*)nullptr);
   MG_CHECK_LAUNCH();
@@ -885,7 +888,9 @@ extern "C" int mg_collect_circles(const int32_t* d_circles, int64_t circle_cap, 
   hipStream_t s = mg_stream(stream);
   if (hipMemsetAsync(d_num_out, 0, sizeof(int32_t) * n_planes, s) != hipSuccess) return MG_ELAUNCH;
   if (circle_cap == 0 || out_cap == 0) return MG_OK;
-  hipLaunchKernelGGL(k_collect_list, dim3(grid_x(circle_cap), n_planes), dim3(NT), 0, s, d_alive, d_num_alive, d_state,
+  // out_cap bounds the alive counts in practice; the grid-stride loop covers the rest otherwise
+  hipLaunchKernelGGL(k_collect_list, dim3(grid_x(std::min(circle_cap, std::max<int64_t>(out_cap, NT))), n_planes),
+                     dim3(NT), 0, s, d_alive, d_num_alive, d_state,
                      keep_all, circle_cap, out_cap, d_scratch, d_num_out);
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_collect_rank, dim3(grid_x(out_cap), n_planes), dim3(NT), 0, s, d_circles, circle_cap, d_scores,

@@ -476,7 +476,7 @@ class CircleFinder:
                     _call("mg_nms_round", self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
                           self.alive.data_ptr(), self.num_alive.data_ptr(), self.max_rc.data_ptr(), P,
                           min_dist, ring.data_ptr(), ring.shape[0], self.nms_grid.data_ptr(),
-                          self.nms_grid.shape[1], self.state.data_ptr(), self.undecided.data_ptr(), s)
+                          self.nms_grid.shape[1], self.state.data_ptr(), self.undecided.data_ptr(), out_cap, s)
                     rounds += 1
                 if int(self.undecided.sum().item()) == 0:
                     break
@@ -497,7 +497,8 @@ class CircleFinder:
         if rounds:
             _call("mg_nms_cleanup", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
                   self.num_alive.data_ptr(), self.max_rc.data_ptr(), P, min_dist, self._nms_ring.data_ptr(),
-                  self._nms_ring.shape[0], self.nms_grid.data_ptr(), self.nms_grid.shape[1], self.state.data_ptr(), s)
+                  self._nms_ring.shape[0], self.nms_grid.data_ptr(), self.nms_grid.shape[1], self.state.data_ptr(),
+                  out_cap, s)
         return out, out_scores, num_out
 
     def find(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw=False, keep_u8=False,
