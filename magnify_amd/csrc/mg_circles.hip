@@ -277,20 +277,25 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
 
 __global__ __launch_bounds__(1024) void k_layer_scan(int32_t* __restrict__ d_layer_offsets, int n_layers,
                                                      int32_t* __restrict__ d_num_circles, int64_t cap) {
+  // one workgroup per plane; every thread owns a contiguous run of counts: sum it, one block-wide
+  // scan of the 1024 run sums, then write the run's exclusive prefixes (2 barriers instead of 2 per
+  // 1024 elements -- with ~88 k layers per plane the chunked version spent 0.3 ms per step here)
   const int plane = blockIdx.x;
   int32_t* cnt = d_layer_offsets + (int64_t)plane * (n_layers + 1);
-  int carry = 0;
-  for (int base = 0; base < n_layers; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < n_layers ? cnt[i] : 0;
-    int total;
-    const int ex = mg_block_exscan(v, &total);
-    if (i < n_layers) cnt[i] = carry + ex;
-    carry += total;
+  const int per = (n_layers + 1023) / 1024;
+  const int lo = min((int)threadIdx.x * per, n_layers), hi = min(lo + per, n_layers);
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += cnt[i];
+  int total;
+  int run = mg_block_exscan(sum, &total);
+  for (int i = lo; i < hi; ++i) {
+    const int v = cnt[i];
+    cnt[i] = run;
+    run += v;
   }
   if (threadIdx.x == 0) {
-    cnt[n_layers] = carry;
-    d_num_circles[plane] = (int32_t)min((int64_t)carry, cap);
+    cnt[n_layers] = total;
+    d_num_circles[plane] = (int32_t)min((int64_t)total, cap);
   }
 }
 

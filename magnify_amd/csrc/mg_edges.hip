@@ -662,16 +662,18 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const int32_t* __restrict__ 
   const int plane = blockIdx.x;
   const int32_t* cnt = d_counts + (int64_t)plane * n_cells;
   int32_t* st = d_starts + (int64_t)plane * n_cells;
-  int carry = 0;
-  for (int base = 0; base < n_cells; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < n_cells ? cnt[i] : 0;
-    int total;
-    const int ex = mg_block_exscan(v, &total);
-    if (i < n_cells) st[i] = carry + ex;
-    carry += total;
+  // every thread owns a contiguous run of cells: run sums, one block-wide scan, run prefixes
+  const int per = (n_cells + 1023) / 1024;
+  const int lo = min((int)threadIdx.x * per, n_cells), hi = min(lo + per, n_cells);
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += cnt[i];
+  int total;
+  int run = mg_block_exscan(sum, &total);
+  for (int i = lo; i < hi; ++i) {
+    st[i] = run;
+    run += cnt[i];
   }
-  if (threadIdx.x == 0) d_num_edges[plane] = carry;
+  if (threadIdx.x == 0) d_num_edges[plane] = total;
 }
 
 __global__ __launch_bounds__(NT) void k_cell_fill(const uint32_t* __restrict__ d_bits, int64_t words_per_plane, int h,
