@@ -290,7 +290,7 @@ __device__ __forceinline__ T correct_pixel(double t, double fl, double r, double
   return cast_trunc<T>(e);
 }
 
-constexpr int PLANES_PER_BLOCK = 4;
+constexpr int PLANES_PER_BLOCK = 8;
 
 // Block = 256 lanes x N pixels of ROWS_PER_BLOCK output rows, for PLANES_PER_BLOCK consecutive
 // planes: the dark/flat operands of a pixel chunk are loaded once and reused across those planes.
