@@ -11,7 +11,6 @@ table over RCCL.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

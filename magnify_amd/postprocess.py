@@ -1,7 +1,6 @@
 """drop and restore_format (reference: src/magnify/postprocess.py:6-49)."""
 from __future__ import annotations
 
-import numpy as np
 
 from . import registry
 from .xr_lite import DataArray, Dataset

@@ -3,7 +3,6 @@ plus the trivial view components that keep their registry names (rotate is a no-
 reference as well, preprocess.py:54-59)."""
 from __future__ import annotations
 
-import math
 import os
 
 import numpy as np

@@ -1,9 +1,7 @@
 """Micro-benchmark of the ROI stage alone: label-map masks vs disk masks on the same beads."""
 import os
 import sys
-import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,5 +35,3 @@ t_lab = timeit(lambda: hp.roi_gather_reduce(images, beads, 100, labels, reuse_bu
 t_disk = timeit(lambda: hp.roi_gather_reduce(images, beads, 100, None, reuse_buffers=True, disks=True))
 t_none = timeit(lambda: hp.roi_gather_reduce(images, beads, 100, None, reuse_buffers=True))
 print(f"labels {t_lab:.3f} ms  disks {t_disk:.3f} ms  no-masks {t_none:.3f} ms  (host+device, {T} assays)")
-for extra in sys.argv[1:]:
-    os.environ["MG_ROI_VARIANT"] = extra
