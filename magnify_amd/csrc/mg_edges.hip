@@ -584,20 +584,24 @@ __global__ __launch_bounds__(NT) void k_hysteresis(const uint32_t* __restrict__ 
     pending |= (wk[r][k] & ~st[r + 1][k + 1]) != 0;
   }
   if (!__syncthreads_or(pending)) return;
-  uint32_t first[TH * HW / NT];  // this thread's strong words before the sweep
+  // A thread owns two vertically adjacent words (rows 2g, 2g + 1 of word column k).  Per iteration it
+  // grows each of them from the 3 x 3 neighbourhood and then along the word itself until nothing
+  // moves (weak runs inside a word are absorbed at once), the second row already seeing the first
+  // row's update: fewer block-wide iterations than one Jacobi dilation step per barrier.
+  constexpr int WPT = TH * HW / NT;  // words per thread (2)
+  static_assert(WPT == 2, "the row-pair mapping below assumes two words per thread");
+  const int k = (threadIdx.x & (HW - 1)) + 1, r0 = 2 * (threadIdx.x / HW) + 1;  // st coordinates
+  uint32_t first[WPT];  // this thread's strong words before the sweep
 #pragma unroll
-  for (int j = 0; j < TH * HW / NT; ++j) {
-    const int i = threadIdx.x + j * NT;
-    first[j] = st[i / HW + 1][i % HW + 1];
-  }
+  for (int j = 0; j < WPT; ++j) first[j] = st[r0 + j][k];
   int again;
   do {
     int changed = 0;
 #pragma unroll
-    for (int j = 0; j < TH * HW / NT; ++j) {
-      const int i = threadIdx.x + j * NT;
-      const int r = i / HW + 1, k = i % HW + 1;
-      const uint32_t cand = wk[r - 1][k - 1] & ~st[r][k];
+    for (int j = 0; j < WPT; ++j) {
+      const int r = r0 + j;
+      uint32_t cur = st[r][k];
+      uint32_t cand = wk[r - 1][k - 1] & ~cur;
       if (!cand) continue;
       uint32_t dil = 0;
 #pragma unroll
@@ -605,22 +609,25 @@ __global__ __launch_bounds__(NT) void k_hysteresis(const uint32_t* __restrict__ 
         const uint32_t c = st[r + dr][k], l = st[r + dr][k - 1], rt = st[r + dr][k + 1];
         dil |= c | (c << 1) | (c >> 1) | (l >> 31) | (rt << 31);
       }
-      const uint32_t nw = cand & dil;
-      if (nw) {
-        st[r][k] |= nw;
-        changed = 1;
+      uint32_t nw = cand & dil;
+      if (!nw) continue;
+      cur |= nw;
+      cand &= ~nw;
+      for (uint32_t g = cand & ((cur << 1) | (cur >> 1)); g; g = cand & ((cur << 1) | (cur >> 1))) {
+        cur |= g;
+        cand &= ~g;
       }
+      st[r][k] = cur;
+      changed = 1;
     }
     again = __syncthreads_or(changed);
   } while (again);
   int wrote = 0;
 #pragma unroll
-  for (int j = 0; j < TH * HW / NT; ++j) {
-    const int i = threadIdx.x + j * NT;
-    const int r = i / HW, k = i % HW;
-    const uint32_t diff = st[r + 1][k + 1] & ~first[j];
+  for (int j = 0; j < WPT; ++j) {
+    const uint32_t diff = st[r0 + j][k] & ~first[j];
     if (diff) {
-      bits_or(strong, (int64_t)(ty0 + r) * w + tx0 + 32 * k, diff);  // only in-image bits can be set
+      bits_or(strong, (int64_t)(ty0 + r0 + j - 1) * w + tx0 + 32 * (k - 1), diff);  // only in-image bits can be set
       wrote = 1;
     }
   }
