@@ -712,7 +712,7 @@ int launch_candidates(const int32_t* d_coords, int64_t coord_cap, const int32_t*
   if (n_planes == 0 || num_iter == 0) return MG_OK;
   const int gr = (h + grid - 1) / grid, gc = (w + grid - 1) / grid;
   const bool fast = num_iter < (1ll << 31) && grid > 1 && h <= 65536 && w <= 65536;
-  hipLaunchKernelGGL(fast ? k_candidates<true> : k_candidates<false>, dim3(grid_x(num_iter), n_planes), dim3(NT), 0,
+  hipLaunchKernelGGL(fast ? k_candidates<true> : k_candidates<false>, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((num_iter + NT - 1) / NT, 2048)), n_planes), dim3(NT), 0,
                      mg_stream(stream), d_coords,
                      coord_cap, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gc, gr * gc, d_seeds, num_iter,
                      min_r, max_r, d_bitmap, bitmap_words, d_raw, d_keys);
