@@ -87,3 +87,59 @@ def marker_table(out: dict, assay_offset: int, n_channels: int, device) -> torch
     tab[:, 6 : 6 + n_channels] = sums[:, :, 0]
     tab[:, 6 + n_channels :] = sums[:, :, 1]
     return tab
+
+
+def broadcast_beads(beads, src: int = 0, device="cpu"):
+    """Broadcast a variable-length bead table (M, 3) int32 from rank ``src`` (collective 2:
+    in single-assay mode the beads found at time 0 serve every time shard).  ``beads`` is ignored on the
+    other ranks.  Returns a numpy (M, 3) int32 array on every rank."""
+    import numpy as np
+
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return np.asarray(beads, dtype=np.int32).reshape(-1, 3)
+    dev = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device(device)
+    me = dist.get_rank()
+    count = torch.tensor([len(beads) if me == src else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(count, src)
+    table = torch.zeros((int(count.item()), 3), dtype=torch.int32, device=dev)
+    if me == src and len(beads):
+        table.copy_(torch.from_numpy(np.ascontiguousarray(beads, dtype=np.int32).reshape(-1, 3)))
+    if table.numel():
+        dist.broadcast(table, src)
+    return table.cpu().numpy()
+
+
+def run_mode_r(proc, stack_local: torch.Tensor, flatfield=1.0, darkfield=0.0, seed=0, want_roi=True):
+    """One single-assay (mode "R") step with the TIME axis sharded over the ranks:
+
+    1. the flat-field maxima span the whole array (preprocess.py:84,86): local maxima, then a max
+       all-reduce of the two doubles;
+    2. detection happens on global time 0 only (find.py:477): the rank that owns it (rank 0 under
+       ``shard_range``) detects and broadcasts the bead table;
+    3. every rank gathers and reduces the windows of its own timepoints with those beads.
+
+    ``proc`` is a ``StackProcessor(mode="R")`` sized for the local shard ``stack_local (T_local, C, H, W)``.
+    Returns the local result dict (``roi`` is (M, C, T_local, L, L)); identical, shard for shard, to the
+    single-process result on the whole stack."""
+    from . import hotpath as hp
+
+    if proc.mode != "R":
+        raise ValueError("run_mode_r needs a StackProcessor(mode='R')")
+    t, c, h, w = stack_local.shape
+    tiles = stack_local.view(t * c, 1, 1, 1, h, w)
+    max2 = hp.flatfield_max(tiles, flatfield, darkfield, 1)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo":
+            host = max2.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX)
+            max2.copy_(host)
+        else:
+            dist.all_reduce(max2, op=dist.ReduceOp.MAX)
+    proc.flatfield(stack_local, flatfield, darkfield, max2=max2)
+    owner = 0
+    me = dist.get_rank() if dist.is_initialized() else 0
+    beads = proc.detect(seed)[0] if me == owner else None
+    beads = broadcast_beads(beads, owner, device=stack_local.device)
+    out = proc.segment_reduce([beads], want_roi=want_roi)
+    out["beads"] = [beads]
+    return out

@@ -34,6 +34,9 @@ def _worker(rank, world, port, ret):
            "sums": torch.arange(m * 3 * 2, dtype=torch.float64).reshape(m, 3, 1, 2)}
     table = mgd.gather_marker_table(mgd.marker_table(out, lo, 3, torch.device("cpu")))
     mx = mgd.allreduce_max_(torch.tensor([float(r), 10.0 - r], dtype=torch.float64))
+    shared = mgd.broadcast_beads(np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]]) if r == 1 else None, src=1)
+    empty = mgd.broadcast_beads(np.empty((0, 3), np.int32) if r == 0 else None, src=0)
+    assert shared.tolist() == [[1, 2, 3], [4, 5, 6], [7, 8, 9]] and empty.shape == (0, 3)
     ret[rank] = (table.numpy().copy(), mx.numpy().copy(), (lo, hi))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
