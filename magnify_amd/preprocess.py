@@ -8,6 +8,7 @@ import os
 import numpy as np
 import torch
 
+from . import _native as nat
 from . import hotpath, registry, xr_lite
 from .xr_lite import DataArray, Dataset
 
@@ -139,3 +140,41 @@ def vertical_flip(xp):
     data = torch.flip(data, (ax,)) if isinstance(data, torch.Tensor) else np.flip(data, ax)
     xp.data_vars[name] = DataArray(data, v.dims, name=name)
     return xp
+
+
+@registry.component("circle_mask")
+def circle_mask(xp, center, diameter, mask_inner=False):
+    """preprocess.py:136-153: keep (or, with ``mask_inner``, blank) the filled ``cv.circle`` of the
+    given diameter about ``center = (row, col)`` in every plane of ``image`` (or ``tile``)."""
+    name = "image" if "image" in xp else "tile"
+    v = xp.data_vars[name]
+    h, w = v.shape[-2:]
+    radius = int(diameter) // 2
+    half = nat.cv_disk_halfwidths(radius)  # max |dx| for |dy| = 0..radius (cv.circle, thickness=-1)
+    mask = np.zeros((h, w), dtype=bool)
+    cy, cx = int(center[0]), int(center[1])
+    for ady in range(radius + 1):
+        if half[ady] < 0:
+            continue
+        for y in {cy - ady, cy + ady}:
+            if 0 <= y < h:
+                x0, x1 = max(cx - int(half[ady]), 0), min(cx + int(half[ady]), w - 1)
+                if x0 <= x1:
+                    mask[y, x0 : x1 + 1] = True
+    if mask_inner:
+        mask = ~mask
+    data = v.data
+    if isinstance(data, torch.Tensor):
+        keep = torch.from_numpy(mask).to(data.device)
+        data = torch.where(keep, data, torch.zeros((), dtype=data.dtype, device=data.device))
+    else:
+        data = data * mask.astype(data.dtype)
+    xp.data_vars[name] = DataArray(data, v.dims, name=name)
+    return xp
+
+
+@registry.component("basic_correct")
+def basic_correct(xp):
+    """preprocess.py:91-115 fits a BaSiC illumination model with the third-party ``basicpy``; not part of
+    this build (use ``flatfield_correct`` with measured flat / dark images)."""
+    raise NotImplementedError("basic_correct needs the basicpy package; use flatfield_correct")

@@ -323,3 +323,23 @@ def test_reader_path_patterns(tmp_path):
     else:
         with pytest.raises(RuntimeError):
             call()
+
+
+def test_circle_mask_component_matches_cv_circle():
+    """preprocess.py:136-153: the kept region is cv.circle's filled disk (oracle restatement), also
+    when it runs over the image border; ``mask_inner`` inverts it."""
+    import magnify_amd as mg
+    from oracle import ref_opencv as ro
+
+    rng = np.random.default_rng(3)
+    img = rng.integers(1, 60000, (2, 90, 120), dtype=np.uint16)
+    for center, diameter in (((40, 60), 50), ((5, 110), 41), ((89, 0), 30)):
+        want = ro.filled_circle_mask((90, 120), center, diameter // 2)
+        for inner in (False, True):
+            xp = mg.Dataset({"image": mg.DataArray(img.copy(), ("channel", "im_y", "im_x"))})
+            got = mg.components.get("circle_mask")(center=center, diameter=diameter, mask_inner=inner)(xp).image.values
+            keep = ~want if inner else want
+            np.testing.assert_array_equal(got, img * keep)
+            assert got.dtype == np.uint16
+    with pytest.raises(NotImplementedError):
+        mg.components.get("basic_correct")()(None)
