@@ -112,6 +112,27 @@ def stage_report(stages, steps, p, pmc, stream_bytes):
     return breakdown, roofline, streaming, total_ms
 
 
+def hbm_copy_ceiling(dev, n_bytes=1 << 30, reps=10):
+    """Measured streaming ceiling of this box: device-to-device copy of 1 GiB, bytes read +
+    bytes written over the HIP-event time of ``reps`` copies.  Outside the timed region."""
+    import torch
+
+    try:
+        src = torch.empty(n_bytes, dtype=torch.uint8, device=dev).fill_(1)
+        dst = torch.empty_like(src)
+    except RuntimeError:
+        return None
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {"GBs": 2 * n_bytes / ms / 1e6, "what": f"torch device-to-device copy of {n_bytes >> 20} MiB, read + write bytes"}
+
+
 def per_assay_fg_sums(out, n_assays):
     """Sum of the foreground sums of every assay's markers (exact integers held in float64)."""
     import numpy as np
@@ -273,6 +294,11 @@ def main():
                       "hysteresis_sweeps": p["sweeps"], "nms_rounds": p["nms_rounds"],
                       "kernel_ms_per_step": total_ms / args.steps},
         }
+        result["hbm_copy_ceiling"] = hbm_copy_ceiling(dev)
+        for part in (roofline, streaming):
+            if part and result["hbm_copy_ceiling"]:
+                gbs = part.get("achieved", part.get("achieved_GBs"))
+                part["frac_of_measured_copy"] = gbs / result["hbm_copy_ceiling"]["GBs"]
         if not args.no_cpu and world == 1:
             last = args.warmup + args.steps - 1  # seed of the step whose results are in `out`
             seeds = [(last + 1000003 * a) & 0xFFFFFFFFFFFFFFFF for a in range(T)]
