@@ -126,9 +126,13 @@ int64_t mg_scharr_hist_scratch_words(int n_planes, int h, int w, int mode);
 
 /* cv.Canny(dx, dy, L2gradient=True) non-maximum suppression + double threshold with the
  * already prepared integer thresholds d_thresh[n_planes][2] = {low, high}.  Output: two bitmaps,
- * d_weak (local maxima with m > low: OpenCV map values 0 and 2) and d_strong (m > high: value 2). */
+ * d_weak (local maxima with m > low: OpenCV map values 0 and 2) and d_strong (m > high: value 2).
+ * d_class (optional, [n_planes][2][words_per_plane]): bit planes c0, c1 of every pixel's gradient
+ * orientation class floor((atan2(dy, dx) mod pi) / (pi / 4)), decided exactly on the integer Scharr
+ * gradient (same sign: |dy| < |dx| -> 0 else 1; opposite sign: |dy| > |dx| -> 2 else 3); consumed by
+ * mg_score_circles' prefilter. */
 int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_thresh, uint32_t* d_weak,
-                 uint32_t* d_strong, int64_t words_per_plane, void* stream);
+                 uint32_t* d_strong, uint32_t* d_class, int64_t words_per_plane, void* stream);
 
 /* One sweep of 8-connected hysteresis, bit-parallel on the bitmaps: every 256 x 64 tile grows its
  * strong set into its weak set to a fixed point in LDS (halo from global memory) and ORs the new
@@ -220,7 +224,10 @@ int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, int n_planes,
  * tile's window of the 1-bit edge map staged in LDS.
  * Pass A (exact prefilter): every term of the sum is <= 1, so circles with fewer than
  * min_roundness * P edge pixels on their perimeter cannot pass (they get MG_SCORE_SKIPPED when
- * write_skipped != 0, else their score is left unwritten).
+ * write_skipped != 0, else their score is left unwritten).  With d_class_bits (optional, from
+ * mg_canny_nms) an edge pixel only counts where its gradient orientation class is not the one
+ * perpendicular to the perimeter point's radial direction: such a pixel is at least pi/4 away from
+ * radial, its term 4 |d - pi/2| / pi - 1 is <= 0, and the bound stays exact.
  * Pass B: the reference's float64 sum, sequential in perimeter order, stored float32 and divided
  * by the perimeter length in float32; d_angle holds the gradient angle at edge pixels
  * (mg_edge_angles); per_total = number of entries of the perimeter tables.
@@ -229,11 +236,12 @@ int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, int n_planes,
  * d_max_rc[n_planes][2] (pre-set to INT32_MIN) receives max row / max col of the alive circles
  * (the claim-grid extent of utils.py:268-270).  d_num_scored (optional, [n_planes], pre-zeroed)
  * counts the circles that reached pass B. */
-int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, int64_t words_per_plane, int n_planes, int h,
-                     int w, const int32_t* d_circles, int64_t circle_cap, const int32_t* d_layer_offsets, int min_r,
-                     int max_r, const int32_t* d_per_rc, const double* d_per_expected, const int32_t* d_per_starts,
-                     int per_total, float min_roundness, int write_skipped, float* d_scores, int32_t* d_alive,
-                     int32_t* d_num_alive, int32_t* d_max_rc, int32_t* d_num_scored, void* stream);
+int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, const uint32_t* d_class_bits,
+                     int64_t words_per_plane, int n_planes, int h, int w, const int32_t* d_circles, int64_t circle_cap,
+                     const int32_t* d_layer_offsets, int min_r, int max_r, const int32_t* d_per_rc,
+                     const double* d_per_expected, const int32_t* d_per_starts, int per_total, float min_roundness,
+                     int write_skipped, float* d_scores, int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc,
+                     int32_t* d_num_scored, void* stream);
 
 /* One round of the parallel-but-equivalent greedy suppression of filter_neighbors
  * (utils.py:254-292).  Priority = (score desc, index in d_circles asc) -- the build's

@@ -415,10 +415,19 @@ __device__ __forceinline__ uint32_t bits_at(const uint32_t* __restrict__ bits, i
   return n >= 32 ? v : (v & ((1u << n) - 1u));
 }
 
-constexpr int CHUNK = 1024;  // circles per prefilter/exact round (bounds the LDS survivor list)
+constexpr int CHUNK = 1024;        // capacity of the LDS survivor list of one prefilter/exact round
+constexpr int SURV_IDX_BITS = 20;  // list entry: circle index within the round | hits << 20 (perimeters < 2048 points)
 
+//   Orientation windows: a perimeter point whose radial direction theta lies in the quarter
+//     [k pi/4, (k+1) pi/4] (mod pi) gets a term <= 0 from every edge pixel whose gradient
+//     orientation class is (k + 2) & 3 (at least pi/4 away), so the prefilter counts it in window
+//     W_k = edges & (class != (k + 2) & 3).  The 8 symmetric points of a group always fall into
+//     the same quarters (3, 2, 0, 1, 0, 1, 3, 2 for the table's (x > 0, y < 0, x < -y) entries), so
+//     with a compile-time slot size WS the window is an immediate offset of the LDS read.
+template <int WS>
 __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_angle,
-                                                    const uint32_t* __restrict__ d_bits, int64_t words_per_plane,
+                                                    const uint32_t* __restrict__ d_bits,
+                                                    const uint32_t* __restrict__ d_class, int64_t words_per_plane,
                                                     int h, int w, const int32_t* __restrict__ d_circles,
                                                     int64_t circle_cap, const int32_t* __restrict__ d_layer_offsets,
                                                     int n_layers, int nr, int ntc, int min_r, int max_r,
@@ -439,107 +448,167 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
   int wsh = 0;
   while ((32 << wsh) < side) ++wsh;  // words per window row, rounded up to a power of two
   const int wpr = 1 << wsh;
-  uint32_t* win = lds;                                    // [side][wpr]
-  int32_t* tab = reinterpret_cast<int32_t*>(lds + side * wpr);  // packed (dr << 16) | (dc & 0xFFFF)
+  const int slot = WS ? WS : side * wpr;
+  uint32_t* win = lds;                                    // [4][slot]: W_0 .. W_3, each [side][wpr]
+  int32_t* tab = reinterpret_cast<int32_t*>(lds + 4 * slot);  // packed (dr << 16) | (dc & 0xFFFF)
   int32_t* list = tab + per_total;                        // [CHUNK]
   const int wy0 = (tile / ntc) * TS - 2 * max_r, wx0 = (tile % ntc) * TS - 2 * max_r;
   const uint32_t* bits = d_bits + plane * words_per_plane;
+  const uint32_t* cls0 = d_class ? d_class + (2 * plane) * words_per_plane : nullptr;
+  const uint32_t* cls1 = d_class ? d_class + (2 * plane + 1) * words_per_plane : nullptr;
   for (int i = threadIdx.x; i < side * wpr; i += NT) {
     const int j = i >> wsh, k = i & (wpr - 1);
     const int y = wy0 + j, xs = wx0 + 32 * k;
-    uint32_t v = 0;
+    uint32_t v = 0, c0 = 0, c1 = 0;
     if (y >= 0 && y < h) {
       const int x_lo = max(xs, 0), x_hi = min(min(xs + 32, wx0 + side), w);
-      if (x_lo < x_hi) v = bits_at(bits, (int64_t)y * w + x_lo, x_hi - x_lo) << (x_lo - xs);
+      if (x_lo < x_hi) {
+        v = bits_at(bits, (int64_t)y * w + x_lo, x_hi - x_lo) << (x_lo - xs);
+        if (d_class && v) {
+          c0 = bits_at(cls0, (int64_t)y * w + x_lo, x_hi - x_lo) << (x_lo - xs);
+          c1 = bits_at(cls1, (int64_t)y * w + x_lo, x_hi - x_lo) << (x_lo - xs);
+        }
+      }
     }
-    win[i] = v;
+    if (d_class) {
+      win[i] = v & ~(c1 & ~c0);             // W_0: without class 2
+      win[slot + i] = v & ~(c1 & c0);       // W_1: without class 3
+      win[2 * slot + i] = v & (c1 | c0);    // W_2: without class 0
+      win[3 * slot + i] = v & (c1 | ~c0);   // W_3: without class 1
+    } else {
+      win[i] = win[slot + i] = win[2 * slot + i] = win[3 * slot + i] = v;
+    }
   }
-  for (int i = threadIdx.x; i < per_total; i += NT) tab[i] = (d_per_rc[2 * i] << 16) | (d_per_rc[2 * i + 1] & 0xFFFF);
+  for (int i = threadIdx.x; i < per_total; i += NT) {
+    // (dr << 16) | (quarter << 14) | (dc & 0x3FFF); the quarter of theta = atan2(dr, dc) mod pi by the same
+    // integer rule as the pixels' classes (on a boundary either side is valid, but the prefilter's
+    // count and the exact pass must use the same window)
+    const int dr = d_per_rc[2 * i], dc = d_per_rc[2 * i + 1];
+    const int ay = abs(dr), ax = abs(dc);
+    const int quarter = ((dr ^ dc) < 0) ? (ay > ax ? 2 : 3) : (ay < ax ? 0 : 1);
+    tab[i] = (dr << 16) | (quarter << 14) | (dc & 0x3FFF);
+  }
   __syncthreads();
+#define MG_TAB_DR(v) ((v) >> 16)
+#define MG_TAB_DC(v) (((int)((uint32_t)(v) << 18)) >> 18)
+#define MG_TAB_Q(v) (((v) >> 14) & 3)
   const int32_t* circles = d_circles + (int64_t)plane * circle_cap * 3;
   const float* ang = d_angle + (int64_t)plane * h * w;
   float* scores = d_scores + (int64_t)plane * circle_cap;
   const double PI = 3.141592653589793, INV_PI = 1.0 / 3.141592653589793;
-  for (int64_t chunk = first; chunk < last; chunk += CHUNK) {
+  // Rounds: prefilter batches of BATCH circles until the survivor list is nearly full (or the tile is
+  // done), then the exact pass over the list -- with few survivors per batch the exact pass would
+  // otherwise run on mostly idle waves.
+  constexpr int BATCH = 2 * NT;
+  for (int64_t chunk = first; chunk < last;) {
     if (threadIdx.x == 0) n_surv = 0;
     __syncthreads();
-    for (int64_t i = chunk + threadIdx.x; i < min(chunk + CHUNK, last); i += NT) {
+    int64_t pos = chunk;
+    for (;;) {
+    for (int64_t i = pos + threadIdx.x; i < min(pos + BATCH, last); i += NT) {
       const int row = circles[3 * i], col = circles[3 * i + 1], rad = circles[3 * i + 2];
       const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
       const int len = p1 - p0;
       // need: hits >= min_roundness * len - 1e-3 (margin far above any rounding of the real sum)
       const int need = (int)ceil((double)min_roundness * len - 1e-3);
       const int by = row - wy0, bx = col - wx0;
-#define MG_BIT(yy, xx) ((win[((by + (yy)) << wsh) + ((bx + (xx)) >> 5)] >> ((bx + (xx)) & 31)) & 1u)
+#define MG_BIT(k, yy, xx) \
+  ((win[(k) * slot + ((by + (yy)) << wsh) + ((bx + (xx)) >> 5)] >> ((bx + (xx)) & 31)) & 1u)
       // The midpoint circle is emitted as 4 axis points, groups of 8 symmetric points sharing one
       // (x, y), and possibly 4 diagonal points (utils.py:441-464): one table read per group.
-      int hits = MG_BIT(0, -rad) + MG_BIT(-rad, 0) + MG_BIT(0, rad) + MG_BIT(rad, 0);
+      // Axis points (quarters by the table's rule): theta = pi, pi/2, 0, pi/2.
+      int hits = MG_BIT(3, 0, -rad) + MG_BIT(2, -rad, 0) + MG_BIT(0, 0, rad) + MG_BIT(1, rad, 0);
       int p = p0 + 4;
       for (; p + 8 <= p1; p += 8) {
         const int v = tab[p];
-        const int x = v >> 16, y = (int)(int16_t)(v & 0xFFFF);  // entry (dr, dc) = (x, y)
-        hits += MG_BIT(x, y) + MG_BIT(y, x) + MG_BIT(-x, y) + MG_BIT(-y, x) + MG_BIT(x, -y) + MG_BIT(y, -x) +
-                MG_BIT(-x, -y) + MG_BIT(-y, -x);
+        const int x = MG_TAB_DR(v), y = MG_TAB_DC(v);  // entry (dr, dc) = (x, y), x > 0 > y, x < -y
+        hits += MG_BIT(3, x, y) + MG_BIT(2, y, x) + MG_BIT(0, -x, y) + MG_BIT(1, -y, x) + MG_BIT(0, x, -y) +
+                MG_BIT(1, y, -x) + MG_BIT(3, -x, -y) + MG_BIT(2, -y, -x);
         // (no early exit: a wave runs as long as its slowest lane anyway, and the test cost more than it saved)
       }
-      if (p + 4 == p1) {
+      if (p + 4 == p1) {  // diagonal points: theta = pi/4 (quarter 1) where dr, dc have the same sign, else 3 pi/4 (3)
         const int v = tab[p];
-        const int x = v >> 16, y = (int)(int16_t)(v & 0xFFFF);
-        hits += MG_BIT(x, y) + MG_BIT(-x, -y) + MG_BIT(-x, y) + MG_BIT(x, -y);
+        const int x = MG_TAB_DR(v), y = MG_TAB_DC(v);
+        const uint32_t* wa = win + (((x ^ y) < 0) ? 3 : 1) * slot;  // (x, y), (-x, -y)
+        const uint32_t* wb = win + (((x ^ y) < 0) ? 1 : 3) * slot;  // (-x, y), (x, -y)
+#define MG_BITW(ww, yy, xx) ((ww[((by + (yy)) << wsh) + ((bx + (xx)) >> 5)] >> ((bx + (xx)) & 31)) & 1u)
+        hits += MG_BITW(wa, x, y) + MG_BITW(wa, -x, -y) + MG_BITW(wb, -x, y) + MG_BITW(wb, x, -y);
+#undef MG_BITW
       }
 #undef MG_BIT
       if (hits >= need) {
-        list[atomicAdd(&n_surv, 1)] = (int32_t)(i - chunk) | (hits << 10);  // CHUNK = 1024; hits = all of them
+        list[atomicAdd(&n_surv, 1)] = (int32_t)(i - chunk) | (hits << SURV_IDX_BITS);
       } else if (write_skipped) {
         scores[i] = MG_SCORE_SKIPPED;
       }
     }
-    __syncthreads();
+      pos += BATCH;
+      __syncthreads();
+      const int so_far = n_surv;
+      if (pos >= last || so_far > CHUNK - BATCH || pos - chunk > (1 << SURV_IDX_BITS) - BATCH) break;
+      __syncthreads();  // everyone has read the count before the next batch adds to it
+    }
     const int ns = n_surv;
     if (threadIdx.x == 0 && d_num_scored) atomicAdd(&d_num_scored[plane], ns);
     for (int a = threadIdx.x; a < ns; a += NT) {
-      const int64_t i = chunk + (list[a] & (CHUNK - 1));
+      const int64_t i = chunk + (list[a] & ((1 << SURV_IDX_BITS) - 1));
       const int row = circles[3 * i], col = circles[3 * i + 1], rad = circles[3 * i + 2];
       const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
       const int by = row - wy0, bx = col - wx0;
       double acc = 0.0;
-      // Early abort (exact): every remaining edge pixel adds at most 1, so once
+      // Early abort (exact): every remaining counted pixel adds at most 1, so once
       // acc + remaining < min_roundness * len - 1e-3 the circle cannot pass any more.  Most circles
       // that survive the count-only prefilter sit just above it and their terms average ~0 (noise
       // edges point anywhere): they are ruled out after a handful of terms.
-      double left = (double)(list[a] >> 10);  // edge pixels on the perimeter not yet summed
+      double left = (double)(list[a] >> SURV_IDX_BITS);  // prefilter hits on the perimeter not yet summed
       const double floor_sum = (double)min_roundness * (double)(p1 - p0) - 1e-3;
       bool dead = false;
       // 32 perimeter points at a time: hit mask from LDS, then only the hits (in perimeter order)
       // pay for the angle gather and the float64 arithmetic
       for (int base = p0; base < p1 && !dead; base += 32) {
-        uint32_t mask = 0;
+        uint32_t mask = 0, counted = 0;  // edge pixels / those the prefilter counted (its window W_quarter)
         const int cnt = min(32, p1 - base);
         for (int j = 0; j < cnt; ++j) {
           const int v = tab[base + j];
-          const int y = by + (v >> 16), x = bx + (int)(int16_t)(v & 0xFFFF);
-          mask |= ((win[(y << wsh) + (x >> 5)] >> (x & 31)) & 1u) << j;
+          const int y = by + MG_TAB_DR(v), x = bx + MG_TAB_DC(v);
+          const int wi = (y << wsh) + (x >> 5);  // every edge pixel is in W_0 or in W_2
+          mask |= (((win[wi] | win[2 * slot + wi]) >> (x & 31)) & 1u) << j;
+          counted |= ((win[MG_TAB_Q(v) * slot + wi] >> (x & 31)) & 1u) << j;
         }
-        while (mask) {
-          const int j = __ffs(mask) - 1;
-          mask &= mask - 1;
-          const int p = base + j;
-          const int v = tab[p];
-          // hits lie inside the image: 24-bit multiply (h, w < 2^24 guaranteed by the launcher)
-          const float an = ang[(int64_t)(__umul24(row + (v >> 16), w) + (col + (int)(int16_t)(v & 0xFFFF)))];
-          double d = fabs((double)an - d_per_expected[p]);
-          if (d > PI) d = d - PI;
-          // x / pi, correctly rounded without the division (Markstein: y = RN(1/pi), q0 = RN(x y),
-          // r = x - q0 pi exactly by FMA, q = RN(q0 + r y) == RN(x / pi) because pi's significand is
-          // not all ones; verified against x / pi on 1e9 operands of exactly this form)
-          const double x4 = 4.0 * fabs(d - PI / 2.0);
-          const double q0 = x4 * INV_PI;
-          const double q = fma(fma(-q0, PI, x4), INV_PI, q0);
-          acc += q - 1.0;
-          left -= 1.0;
-          if (acc + left < floor_sum) {
-            dead = true;
-            break;
+        // The gathers of up to PF hits are issued together (their latency, not the arithmetic, is what
+        // a lane waits for), then summed in perimeter order.
+        constexpr int PF = 8;
+        while (mask && !dead) {
+          int jj[PF];
+          float an[PF];
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+            jj[u] = __ffs(mask) - 1;  // -1 once the block's hits are used up
+            mask &= mask - 1;
+            an[u] = 0.0f;
+            if (jj[u] >= 0) {
+              const int v = tab[base + jj[u]];
+              // hits lie inside the image: 24-bit multiply (h, w < 2^24 guaranteed by the launcher)
+              an[u] = ang[(int64_t)(__umul24(row + MG_TAB_DR(v), w) + (col + MG_TAB_DC(v)))];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+            if (jj[u] < 0 || dead) continue;
+            const int p = base + jj[u];
+            double d = fabs((double)an[u] - d_per_expected[p]);
+            if (d > PI) d = d - PI;
+            // x / pi, correctly rounded without the division (Markstein: y = RN(1/pi), q0 = RN(x y),
+            // r = x - q0 pi exactly by FMA, q = RN(q0 + r y) == RN(x / pi) because pi's significand is
+            // not all ones; verified against x / pi on 1e9 operands of exactly this form)
+            const double x4 = 4.0 * fabs(d - PI / 2.0);
+            const double q0 = x4 * INV_PI;
+            const double q = fma(fma(-q0, PI, x4), INV_PI, q0);
+            acc += q - 1.0;
+            // `left` = the prefilter's hits still to come; the other edge pixels (perpendicular class)
+            // add <= 0 (+6e-8 at worst when exactly pi/4 off radial: inside the 1e-3 margin)
+            left -= (double)((counted >> jj[u]) & 1u);
+            if (acc + left < floor_sum) dead = true;
           }
         }
       }
@@ -557,8 +626,13 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
       }
     }
     __syncthreads();
+    chunk = pos;
   }
 }
+
+#undef MG_TAB_DR
+#undef MG_TAB_DC
+#undef MG_TAB_Q
 
 // ---- K10: greedy suppression in parallel rounds ------------------------------------------------------
 // Priority key: smaller = earlier in the reference's score-descending order; ties broken by
@@ -814,16 +888,17 @@ extern "C" int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, cons
   return MG_OK;
 }
 
-extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, int64_t words_per_plane,
-                                int n_planes, int h, int w, const int32_t* d_circles, int64_t circle_cap,
-                                const int32_t* d_layer_offsets, int min_r, int max_r, const int32_t* d_per_rc,
-                                const double* d_per_expected, const int32_t* d_per_starts, int per_total,
-                                float min_roundness, int write_skipped, float* d_scores, int32_t* d_alive,
-                                int32_t* d_num_alive, int32_t* d_max_rc, int32_t* d_num_scored, void* stream) {
+extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, const uint32_t* d_class_bits,
+                                int64_t words_per_plane, int n_planes, int h, int w, const int32_t* d_circles,
+                                int64_t circle_cap, const int32_t* d_layer_offsets, int min_r, int max_r,
+                                const int32_t* d_per_rc, const double* d_per_expected, const int32_t* d_per_starts,
+                                int per_total, float min_roundness, int write_skipped, float* d_scores,
+                                int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc, int32_t* d_num_scored,
+                                void* stream) {
   if (!d_angle || !d_edge_bits || !d_circles || !d_layer_offsets || !d_per_rc || !d_per_expected || !d_per_starts ||
       !d_scores || !d_alive || !d_num_alive || !d_max_rc)
     return MG_EINVAL;
-  if (n_planes < 0 || n_planes > 65535 || per_total <= 0 || max_r > 16000) return MG_EINVAL;
+  if (n_planes < 0 || n_planes > 65535 || per_total <= 0 || max_r > 8000) return MG_EINVAL;
   int ntr, ntc;
   int64_t n_layers, words;
   if (mg_dedup_layout(h, w, min_r, max_r, &ntr, &ntc, &n_layers, &words) != MG_OK) return MG_EINVAL;
@@ -832,17 +907,20 @@ extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bit
   int wpr = 1;
   while (32 * wpr < side) wpr <<= 1;
   if (h >= (1 << 24) || w >= (1 << 24) || (int64_t)h * w >= (1LL << 31)) return MG_EINVAL;
-  const size_t lds_bytes = ((size_t)side * wpr + per_total + CHUNK) * 4;
-  if (lds_bytes > 150 * 1024) return MG_EINVAL;  // radii beyond ~300 px: outside this build's envelope
+  constexpr int SMALL_SLOT = 512;  // words: windows up to 128 x 128 (max_r <= 32)
+  const bool small = side * wpr <= SMALL_SLOT;
+  const size_t lds_bytes = ((size_t)4 * (small ? SMALL_SLOT : side * wpr) + per_total + CHUNK) * 4;
+  if (lds_bytes > 150 * 1024) return MG_EINVAL;  // radii beyond ~150 px: outside this build's envelope
   static bool attr_set = false;
   if (lds_bytes > 48 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_tiles), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            150 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_tiles<0>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
       return MG_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_score_tiles, dim3(ntr * ntc, n_planes), dim3(NT), lds_bytes, mg_stream(stream), d_angle,
-                     d_edge_bits, words_per_plane, h, w, d_circles, circle_cap, d_layer_offsets, (int)n_layers,
+  auto kernel = small ? k_score_tiles<SMALL_SLOT> : k_score_tiles<0>;
+  hipLaunchKernelGGL(kernel, dim3(ntr * ntc, n_planes), dim3(NT), lds_bytes, mg_stream(stream), d_angle, d_edge_bits,
+                     d_class_bits, words_per_plane, h, w, d_circles, circle_cap, d_layer_offsets, (int)n_layers,
                      max_r - min_r + 1, ntc, min_r, max_r, d_per_rc, per_total, d_per_expected, d_per_starts,
                      min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc, d_num_scored);
   MG_CHECK_LAUNCH();

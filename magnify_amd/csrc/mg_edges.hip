@@ -452,7 +452,8 @@ __device__ __forceinline__ uint32_t row_word(const uint32_t* __restrict__ bits, 
 // ---- K3: Canny non-maximum suppression + double threshold -> weak / strong bitmaps --------------
 __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_blur, int h, int w,
                                                   const int32_t* __restrict__ d_thresh, int64_t words_per_plane,
-                                                  uint32_t* __restrict__ d_weak, uint32_t* __restrict__ d_strong) {
+                                                  uint32_t* __restrict__ d_weak, uint32_t* __restrict__ d_strong,
+                                                  uint32_t* __restrict__ d_class) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[TH + 4][LS];
   const int plane = blockIdx.z;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
@@ -465,6 +466,11 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
   const int c0 = 4 * lane, gx = tx0 + c0;
   uint32_t* weak = d_weak + plane * words_per_plane;
   uint32_t* strong = d_strong + plane * words_per_plane;
+  // Orientation class of the gradient, phi = atan2(dy, dx) mod pi in quarters of pi (exact, from the
+  // integer gradient): bit planes c0, c1 of the class index; the scoring prefilter drops the edge
+  // pixels whose class is perpendicular to a perimeter point's radial direction (their term is <= 0).
+  uint32_t* cls0 = d_class ? d_class + (2 * plane) * words_per_plane : nullptr;
+  uint32_t* cls1 = d_class ? d_class + (2 * plane + 1) * words_per_plane : nullptr;
   constexpr int TG22 = 13573;
   // mag rows: 6 magnitudes (cols c0-1 .. c0+4) of image rows y-1, y, y+1; zero outside the image
   int mg[3][6];
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
     if (jr < 4) continue;
     // NMS of image row yo = ym - 1 (mag rows 0, 1, 2 = yo - 1, yo, yo + 1; gradients in cd*[0])
     const int yo = ym - 1;
-    uint32_t wb = 0, sb = 0;
+    uint32_t wb = 0, sb = 0, cb0 = 0, cb1 = 0;
     if (yo < h) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -520,24 +526,43 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
         const bool cand = is_max && m > low && gx + q < w;
         wb |= (cand ? 1u : 0u) << q;
         sb |= ((cand && m > high) ? 1u : 0u) << q;
+        // class 0: [0, pi/4), 1: [pi/4, pi/2), 2: [pi/2, 3pi/4), 3: [3pi/4, pi)
+        const int ay = abs(ys);
+        const bool inside = gx + q < w;
+        cb0 |= ((inside && (neg ? ay <= x : ay >= x)) ? 1u : 0u) << q;
+        cb1 |= ((inside && neg) ? 1u : 0u) << q;
       }
     }
     // 8 lanes x 4 bits -> one 32-bit word
     wb <<= 4 * (lane & 7);
     sb <<= 4 * (lane & 7);
+    cb0 <<= 4 * (lane & 7);
+    cb1 <<= 4 * (lane & 7);
 #pragma unroll
     for (int off = 1; off < 8; off <<= 1) {
       wb |= (uint32_t)__shfl_xor((int)wb, off);
       sb |= (uint32_t)__shfl_xor((int)sb, off);
+      if (d_class) {
+        cb0 |= (uint32_t)__shfl_xor((int)cb0, off);
+        cb1 |= (uint32_t)__shfl_xor((int)cb1, off);
+      }
     }
     if ((lane & 7) == 0 && yo < h && gx < w) {
       const int64_t bit0 = (int64_t)yo * w + gx;
       if ((bit0 & 31) == 0 && gx + 32 <= w) {  // the word belongs to this lane group alone
         weak[bit0 >> 5] = wb;
         strong[bit0 >> 5] = sb;
+        if (d_class) {
+          cls0[bit0 >> 5] = cb0;
+          cls1[bit0 >> 5] = cb1;
+        }
       } else {
         bits_or(weak, bit0, wb);
         bits_or(strong, bit0, sb);
+        if (d_class) {
+          bits_or(cls0, bit0, cb0);
+          bits_or(cls1, bit0, cb1);
+        }
       }
     }
   }
@@ -856,7 +881,8 @@ extern "C" int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w,
 }
 
 extern "C" int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_thresh,
-                            uint32_t* d_weak, uint32_t* d_strong, int64_t words_per_plane, void* stream) {
+                            uint32_t* d_weak, uint32_t* d_strong, uint32_t* d_class, int64_t words_per_plane,
+                            void* stream) {
   if (!d_blur || !d_thresh || !d_weak || !d_strong || n_planes < 0 || h < 0 || w < 0) return MG_EINVAL;
   if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
   if (!words_ok(words_per_plane, h, w)) return MG_EINVAL;
@@ -866,7 +892,9 @@ extern "C" int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, c
   const size_t bytes = (size_t)n_planes * words_per_plane * 4;
   if (hipMemsetAsync(d_weak, 0, bytes, s) != hipSuccess || hipMemsetAsync(d_strong, 0, bytes, s) != hipSuccess)
     return MG_ELAUNCH;
-  hipLaunchKernelGGL(k_canny_nms, g, dim3(NT), 0, s, d_blur, h, w, d_thresh, words_per_plane, d_weak, d_strong);
+  if (d_class && (w & 31) && hipMemsetAsync(d_class, 0, 2 * bytes, s) != hipSuccess) return MG_ELAUNCH;
+  hipLaunchKernelGGL(k_canny_nms, g, dim3(NT), 0, s, d_blur, h, w, d_thresh, words_per_plane, d_weak, d_strong,
+                     d_class);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

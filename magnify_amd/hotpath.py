@@ -9,6 +9,7 @@ flow of the reference's ``utils.find_circles`` (src/magnify/utils.py:102-222),
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -283,6 +284,10 @@ class CircleFinder:
         self.words = 2 * ((h * w + 63) // 64) + 2  # bitmap words per plane (even, one spare)
         self.edge_bits = torch.zeros((P, self.words), dtype=i32, device=dev)  # strong bits = edges
         self.weak_bits = torch.zeros((P, self.words), dtype=i32, device=dev)
+        # gradient orientation classes (two bit planes per image plane) for the scoring prefilter;
+        # MG_NO_CLASS_BITS=1 switches the orientation test off (A/B measurements)
+        self.class_bits = (None if os.environ.get("MG_NO_CLASS_BITS") else
+                           torch.zeros((P, 2, self.words), dtype=i32, device=dev))
         self.keep_debug_maps = False  # True: also produce the {0,1} byte map and the angle map (tests)
         self.cell_counts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
         self.cell_starts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
@@ -384,7 +389,7 @@ class CircleFinder:
         thresh = np.stack([np.floor(lo), np.floor(hi)], axis=1).astype(np.int32)
         self.thresh.copy_(torch.from_numpy(thresh))
         _call("mg_canny_nms", self.blur.data_ptr(), P, h, w, self.thresh.data_ptr(), self.weak_bits.data_ptr(),
-              self.edge_bits.data_ptr(), self.words, s)
+              self.edge_bits.data_ptr(), _ptr(self.class_bits), self.words, s)
         sweeps = 0
         # sweeps per host check: first as many as the previous call needed (a sweep after convergence only
         # runs the tile-flag test), then two at a time -- one host round trip in the steady state
@@ -448,7 +453,7 @@ class CircleFinder:
         self.num_alive.zero_()
         self.num_scored.zero_()
         self.max_rc.fill_(-(2**31))
-        _call("mg_score_circles", self.angle.data_ptr(), self.edge_bits.data_ptr(), self.words, P, h, w,
+        _call("mg_score_circles", self.angle.data_ptr(), self.edge_bits.data_ptr(), _ptr(self.class_bits), self.words, P, h, w,
               self.circles.data_ptr(), self.cap, self.layer_offsets.data_ptr(), self.min_r, self.max_r,
               self.per_rc.data_ptr(), self.per_exp.data_ptr(), self.per_starts.data_ptr(), int(self.per_rc.shape[0]),
               float(min_roundness), int(self.keep_debug_maps), self.scores.data_ptr(), self.alive.data_ptr(),

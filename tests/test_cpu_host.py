@@ -343,3 +343,33 @@ def test_circle_mask_component_matches_cv_circle():
             assert got.dtype == np.uint16
     with pytest.raises(NotImplementedError):
         mg.components.get("basic_correct")()(None)
+
+
+def test_perimeter_table_structure_for_orientation_windows():
+    """mg_score_circles' prefilter hard-codes the orientation quarter of each symmetric point of a
+    perimeter group (3, 2, 0, 1, 0, 1, 3, 2 for (x,y), (y,x), (-x,y), (-y,x), (x,-y), (y,-x), (-x,-y),
+    (-y,-x)): that needs every group's first entry (dr, dc) = (x, y) to satisfy x > 0 > y, x < -y."""
+    from magnify_amd import _native as nat
+
+    rc, expected, starts = nat.perimeter_table(2, 64)
+    quarter = [3, 2, 0, 1, 0, 1, 3, 2]
+    for i in range(len(starts) - 1):
+        pts = rc[starts[i]:starts[i + 1]]
+        r = 2 + i
+        assert [tuple(p) for p in pts[:4]] == [(0, -r), (-r, 0), (0, r), (r, 0)]
+        body = pts[4:]
+        n_groups, rest = divmod(len(body), 8)
+        assert rest in (0, 4)
+        for g in range(n_groups):
+            grp = body[8 * g: 8 * g + 8]
+            x, y = int(grp[0][0]), int(grp[0][1])
+            assert x > 0 > y and x < -y
+            derived = [(x, y), (y, x), (-x, y), (-y, x), (x, -y), (y, -x), (-x, -y), (-y, -x)]
+            assert sorted(derived) == sorted(tuple(int(v) for v in p) for p in grp)
+            for (dr, dc), k in zip(derived, quarter):
+                theta = np.arctan2(dr, dc) % np.pi
+                assert k * np.pi / 4 <= theta <= (k + 1) * np.pi / 4
+        if rest:
+            x, y = int(body[-4][0]), int(body[-4][1])
+            assert abs(x) == abs(y)
+            assert sorted([(x, y), (-x, -y), (-x, y), (x, -y)]) == sorted(tuple(int(v) for v in p) for p in body[-4:])

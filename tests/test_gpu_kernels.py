@@ -189,6 +189,21 @@ def test_edge_stage(hp, quantiles):
         nms_map = rcv.canny_nms(dx.astype(np.int16), dy.astype(np.int16), *rcv.canny_thresholds(lo, hi))
         weak = np.unpackbits(cf.weak_bits[k].cpu().numpy().view(np.uint8), bitorder="little")[: h * w].reshape(h, w)
         np.testing.assert_array_equal(weak, (nms_map != 1).astype(np.uint8))
+        # orientation class planes (for the scoring prefilter): floor((atan2(dy, dx) mod pi) / (pi / 4)),
+        # decided on the integer gradient; checked where the class is unambiguous (off the boundaries)
+        cb = cf.class_bits[k].cpu().numpy().view(np.uint32)
+        c0 = np.unpackbits(cb[0].view(np.uint8), bitorder="little")[: h * w].reshape(h, w)
+        c1 = np.unpackbits(cb[1].view(np.uint8), bitorder="little")[: h * w].reshape(h, w)
+        idx, idy = dx.astype(np.int64), dy.astype(np.int64)
+        phi = np.arctan2(idy.astype(np.float64), idx.astype(np.float64)) % np.pi
+        interior = (idx != 0) & (idy != 0) & (np.abs(idx) != np.abs(idy))
+        want_class = np.floor(phi / (np.pi / 4)).astype(np.int64)
+        np.testing.assert_array_equal((2 * c1 + c0)[interior], want_class[interior])
+        # on the boundaries either neighbouring class is acceptable
+        got = (2 * c1 + c0).astype(np.int64)
+        on_b = ~interior & ((idx != 0) | (idy != 0))
+        near = np.round(phi / (np.pi / 4)).astype(np.int64) % 4  # the boundary index k: classes k-1 and k
+        assert np.all((got[on_b] == near[on_b]) | (got[on_b] == (near[on_b] - 1) % 4))
         # angle map: sentinel off-edge; on edges the correctly rounded float32 arctan2, which is
         # within 2 ulp of NumPy's SIMD float32 arctan2 (itself not correctly rounded: e.g.
         # arctan2(-1, 1) comes out 1 ulp above float32(-pi/4) on AVX-512 hosts)
