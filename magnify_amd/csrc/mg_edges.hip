@@ -449,6 +449,15 @@ __device__ __forceinline__ uint32_t row_word(const uint32_t* __restrict__ bits, 
   return bits_at(bits, (int64_t)y * w + lo, hi - lo) << (lo - x0);
 }
 
+// OR over each aligned group of 8 lanes, on the VALU's data-parallel-primitive paths (no LDS
+// crossbar trip): xor 1 and xor 2 inside the quads, then lane i <-> 7 - i swaps the two quads.
+__device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2, 3, 0, 1]
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  return v;
+}
+
 // ---- K3: Canny non-maximum suppression + double threshold -> weak / strong bitmaps --------------
 __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_blur, int h, int w,
                                                   const int32_t* __restrict__ d_thresh, int64_t words_per_plane,
@@ -472,6 +481,7 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
   uint32_t* cls0 = d_class ? d_class + (2 * plane) * words_per_plane : nullptr;
   uint32_t* cls1 = d_class ? d_class + (2 * plane + 1) * words_per_plane : nullptr;
   constexpr int TG22 = 13573;
+  const uint32_t in_row = gx + 4 <= w ? 0xFu : ((1u << max(w - gx, 0)) - 1u);  // the lane's pixels left of the row end
   // mag rows: 6 magnitudes (cols c0-1 .. c0+4) of image rows y-1, y, y+1; zero outside the image
   int mg[3][6];
   int cdx[2][4], cdy[2][4];  // gradients of the lane's 4 pixels for the two newest mag rows
@@ -528,24 +538,16 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
         sb |= ((cand && m > high) ? 1u : 0u) << q;
         // class 0: [0, pi/4), 1: [pi/4, pi/2), 2: [pi/2, 3pi/4), 3: [3pi/4, pi)
         const int ay = abs(ys);
-        const bool inside = gx + q < w;
-        cb0 |= ((inside && (neg ? ay <= x : ay >= x)) ? 1u : 0u) << q;
-        cb1 |= ((inside && neg) ? 1u : 0u) << q;
+        cb0 |= ((neg ? ay <= x : ay >= x) ? 1u : 0u) << q;
+        cb1 |= (neg ? 1u : 0u) << q;
       }
     }
     // 8 lanes x 4 bits -> one 32-bit word
-    wb <<= 4 * (lane & 7);
-    sb <<= 4 * (lane & 7);
-    cb0 <<= 4 * (lane & 7);
-    cb1 <<= 4 * (lane & 7);
-#pragma unroll
-    for (int off = 1; off < 8; off <<= 1) {
-      wb |= (uint32_t)__shfl_xor((int)wb, off);
-      sb |= (uint32_t)__shfl_xor((int)sb, off);
-      if (d_class) {
-        cb0 |= (uint32_t)__shfl_xor((int)cb0, off);
-        cb1 |= (uint32_t)__shfl_xor((int)cb1, off);
-      }
+    wb = or_reduce8(wb << (4 * (lane & 7)));
+    sb = or_reduce8(sb << (4 * (lane & 7)));
+    if (d_class) {
+      cb0 = or_reduce8((cb0 & in_row) << (4 * (lane & 7)));
+      cb1 = or_reduce8((cb1 & in_row) << (4 * (lane & 7)));
     }
     if ((lane & 7) == 0 && yo < h && gx < w) {
       const int64_t bit0 = (int64_t)yo * w + gx;
