@@ -364,7 +364,9 @@ __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ 
       Row12 ra, rb;
 #pragma unroll
       for (int j = 0; j < RPW + 2; ++j) {
-        uint32_t d0 = (uint32_t)__shfl_up((int)mid[j], 1), d2 = (uint32_t)__shfl_down((int)mid[j], 1);
+        // neighbours' words by whole-wave DPP shifts (wave_shr:1 / wave_shl:1), not LDS permutes
+        uint32_t d0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mid[j], 0x138, 0xF, 0xF, false);
+        uint32_t d2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mid[j], 0x130, 0xF, 0xF, false);
         // pixel -1 of the image is pixel 1, pixel w is pixel w - 2 (only those two bytes are ever read)
         if (lane == 0) d0 = at_left ? (mid[j] & 0x0000FF00u) << 16 : edge[j];
         if (lane == 63) d2 = at_right ? (mid[j] >> 16) & 0xFFu : edge[j];
