@@ -365,19 +365,12 @@ __global__ __launch_bounds__(NT) void k_tile_emit(const uint32_t* __restrict__ d
   }
   const int row = (tile / ntc) * TS + lane - max_r, col0 = (tile % ntc) * TS - max_r;
   int32_t* out = d_circles + (int64_t)plane * circle_cap * 3;
-  // the prefix scans of all of this wave's layers first, interleaved (independent shuffle chains hide
-  // each other's latency), then the stores
+  // the prefix scans of all of this wave's layers first (DPP, no LDS permutes), then the stores
   int cnt[EMIT_LAYERS_PER_WAVE], incl[EMIT_LAYERS_PER_WAVE];
 #pragma unroll
   for (int u = 0; u < EMIT_LAYERS_PER_WAVE; ++u) incl[u] = cnt[u] = __popc(v[u].x) + __popc(v[u].y);
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-    for (int u = 0; u < EMIT_LAYERS_PER_WAVE; ++u) {
-      const int t = __shfl_up(incl[u], off);
-      if (lane >= off) incl[u] += t;
-    }
-  }
+  for (int u = 0; u < EMIT_LAYERS_PER_WAVE; ++u) incl[u] = mg_wave_scan_incl_i32(incl[u]);
 #pragma unroll
   for (int u = 0; u < EMIT_LAYERS_PER_WAVE; ++u) {
     const int ri = wave + u * (NT / 64);

@@ -78,6 +78,17 @@ __device__ __forceinline__ void mg_atomic_nanmin(double* addr, double v) {
   }
 }
 
+// Inclusive prefix sum over the 64 lanes on the VALU's DPP paths: Kogge-Stone inside each row of 16
+// (row_shr 1, 2, 4, 8), then the row totals (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2, 3).
+__device__ __forceinline__ int mg_wave_scan_incl_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+  return v;
+}
 __device__ __forceinline__ int mg_wave_sum_i32(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
