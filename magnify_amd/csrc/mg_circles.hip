@@ -732,29 +732,45 @@ __global__ __launch_bounds__(NT) void k_collect_list(const int32_t* __restrict__
   }
 }
 
+// Rank of every kept circle in the (score desc, index asc) order = number of kept circles with a
+// smaller key; the keys are staged through LDS in chunks so that the m comparisons per circle are
+// LDS broadcasts instead of dependent global gathers.
+constexpr int RANK_CHUNK = 2048;
+
 __global__ __launch_bounds__(NT) void k_collect_rank(const int32_t* __restrict__ d_circles, int64_t circle_cap,
                                                      const float* __restrict__ d_scores,
                                                      const int32_t* __restrict__ d_scratch,
                                                      int32_t* __restrict__ d_num_out, int64_t out_cap,
                                                      int32_t* __restrict__ d_out, float* __restrict__ d_out_scores) {
+  __shared__ uint64_t keys[RANK_CHUNK];
   const int plane = blockIdx.y;
   const int m = (int)min((int64_t)d_num_out[plane], out_cap);
   const int32_t* list = d_scratch + (int64_t)plane * out_cap;
   const float* scores = d_scores + (int64_t)plane * circle_cap;
-  for (int64_t a = (int64_t)blockIdx.x * NT + threadIdx.x; a < m; a += (int64_t)gridDim.x * NT) {
-    const int idx = list[a];
-    const uint64_t key = nms_key(scores[idx], (uint32_t)idx);
+  // block-uniform trip count: every thread takes part in the staging barriers
+  for (int64_t a0 = (int64_t)blockIdx.x * NT; a0 < m; a0 += (int64_t)gridDim.x * NT) {
+    const int64_t a = a0 + threadIdx.x;
+    const int idx = a < m ? list[a] : 0;
+    const uint64_t key = a < m ? nms_key(scores[idx], (uint32_t)idx) : 0;
     int rank = 0;
-    for (int b = 0; b < m; ++b) {
-      const int j = list[b];
-      rank += nms_key(scores[j], (uint32_t)j) < key;
+    for (int c0 = 0; c0 < m; c0 += RANK_CHUNK) {
+      const int cn = min(RANK_CHUNK, m - c0);
+      __syncthreads();
+      for (int b = threadIdx.x; b < cn; b += NT) {
+        const int j = list[c0 + b];
+        keys[b] = nms_key(scores[j], (uint32_t)j);
+      }
+      __syncthreads();
+      for (int b = 0; b < cn; ++b) rank += keys[b] < key;
     }
-    const int32_t* c = d_circles + ((int64_t)plane * circle_cap + idx) * 3;
-    int32_t* o = d_out + ((int64_t)plane * out_cap + rank) * 3;
-    o[0] = c[0];
-    o[1] = c[1];
-    o[2] = c[2];
-    if (d_out_scores) d_out_scores[(int64_t)plane * out_cap + rank] = scores[idx];
+    if (a < m) {
+      const int32_t* c = d_circles + ((int64_t)plane * circle_cap + idx) * 3;
+      int32_t* o = d_out + ((int64_t)plane * out_cap + rank) * 3;
+      o[0] = c[0];
+      o[1] = c[1];
+      o[2] = c[2];
+      if (d_out_scores) d_out_scores[(int64_t)plane * out_cap + rank] = scores[idx];
+    }
   }
 }
 

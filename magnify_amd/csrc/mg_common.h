@@ -139,7 +139,22 @@ __device__ __forceinline__ int mg_block_exscan(int v, int* total) {
 
 // float32 gradient angle at an edge pixel: Scharr on the blurred image (BORDER_REFLECT_101),
 // arctan2(dy, dx) evaluated in float64 and rounded once (utils.py:118-119, 170).
+struct __attribute__((packed)) MgUnaligned32 {
+  uint32_t v;
+};
 __device__ __forceinline__ float mg_edge_angle(const uint8_t* __restrict__ pb, int h, int w, int y, int x) {
+  if (y >= 1 && y < h - 1 && x >= 1 && x < w - 2) {
+    // interior: one (unaligned) 4-byte load per row covers columns x - 1 .. x + 2
+    const uint32_t r0 = reinterpret_cast<const MgUnaligned32*>(pb + (int64_t)(y - 1) * w + x - 1)->v;
+    const uint32_t r1 = reinterpret_cast<const MgUnaligned32*>(pb + (int64_t)y * w + x - 1)->v;
+    const uint32_t r2 = reinterpret_cast<const MgUnaligned32*>(pb + (int64_t)(y + 1) * w + x - 1)->v;
+    const int a = r0 & 0xFF, b = (r0 >> 8) & 0xFF, c = (r0 >> 16) & 0xFF;
+    const int d = r1 & 0xFF, f = (r1 >> 16) & 0xFF;
+    const int g = r2 & 0xFF, hh = (r2 >> 8) & 0xFF, ii = (r2 >> 16) & 0xFF;
+    const int dx = 3 * (c - a) + 10 * (f - d) + 3 * (ii - g);
+    const int dy = 3 * (g - a) + 10 * (hh - b) + 3 * (ii - c);
+    return (float)atan2((double)dy, (double)dx);
+  }
   const int ym = mg_reflect101(y - 1, h), yp = mg_reflect101(y + 1, h);
   const int xm = mg_reflect101(x - 1, w), xp = mg_reflect101(x + 1, w);
   const int a = pb[(int64_t)ym * w + xm], b = pb[(int64_t)ym * w + x], c = pb[(int64_t)ym * w + xp];
