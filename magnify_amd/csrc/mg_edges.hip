@@ -574,16 +574,18 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
 
 // ---- K4: hysteresis sweep, bit-parallel ---------------------------------------------------------
 constexpr int HW = TW / 32;  // interior words per tile row (8)
+constexpr int HTH = 256;     // tile rows: taller than the stencil tiles -- growth crosses a tile border only
+                             // once per sweep, and a sweep is a launch plus a host check
 
 __global__ __launch_bounds__(NT) void k_hysteresis(const uint32_t* __restrict__ d_weak, uint32_t* __restrict__ d_strong,
                                                    int64_t words_per_plane, int h, int w,
                                                    uint32_t* __restrict__ d_changed,
                                                    const uint8_t* __restrict__ d_flags_in,
                                                    uint8_t* __restrict__ d_flags_out) {
-  __shared__ uint32_t st[TH + 2][HW + 2];
-  __shared__ uint32_t wk[TH][HW];
+  __shared__ uint32_t st[HTH + 2][HW + 2];
+  __shared__ uint32_t wk[HTH][HW];
   const int plane = blockIdx.z;
-  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * HTH;
   const int ntx = gridDim.x, nty = gridDim.y;
   if (d_flags_in) {
     // A tile can only gain edges if it or one of its 8 neighbours changed in the previous sweep.
@@ -599,27 +601,27 @@ __global__ __launch_bounds__(NT) void k_hysteresis(const uint32_t* __restrict__ 
   const uint32_t* weak = d_weak + plane * words_per_plane;
   uint32_t* strong = d_strong + plane * words_per_plane;
   int pending = 0;
-  for (int i = threadIdx.x; i < (TH + 2) * (HW + 2); i += NT) {
+  for (int i = threadIdx.x; i < (HTH + 2) * (HW + 2); i += NT) {
     const int r = i / (HW + 2), k = i - r * (HW + 2);
     st[r][k] = row_word(strong, h, w, ty0 - 1 + r, tx0 - 32 + 32 * k);
   }
-  for (int i = threadIdx.x; i < TH * HW; i += NT) {
+  for (int i = threadIdx.x; i < HTH * HW; i += NT) {
     const int r = i / HW, k = i - r * HW;
     wk[r][k] = row_word(weak, h, w, ty0 + r, tx0 + 32 * k);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TH * HW; i += NT) {
+  for (int i = threadIdx.x; i < HTH * HW; i += NT) {
     const int r = i / HW, k = i - r * HW;
     pending |= (wk[r][k] & ~st[r + 1][k + 1]) != 0;
   }
   if (!__syncthreads_or(pending)) return;
-  // A thread owns two vertically adjacent words (rows 2g, 2g + 1 of word column k).  Per iteration it
-  // grows each of them from the 3 x 3 neighbourhood and then along the word itself until nothing
-  // moves (weak runs inside a word are absorbed at once), the second row already seeing the first
-  // row's update: fewer block-wide iterations than one Jacobi dilation step per barrier.
-  constexpr int WPT = TH * HW / NT;  // words per thread (2)
-  static_assert(WPT == 2, "the row-pair mapping below assumes two words per thread");
-  const int k = (threadIdx.x & (HW - 1)) + 1, r0 = 2 * (threadIdx.x / HW) + 1;  // st coordinates
+  // A thread owns WPT vertically adjacent words (rows WPT g .. WPT g + WPT - 1 of word column k).  Per
+  // iteration it grows each of them from the 3 x 3 neighbourhood and then along the word itself until
+  // nothing moves (weak runs inside a word are absorbed at once), every row already seeing the update
+  // of the row above: fewer block-wide iterations than one Jacobi dilation step per barrier.
+  constexpr int WPT = HTH * HW / NT;  // words per thread
+  static_assert(WPT * NT == HTH * HW, "the tile's words must divide evenly over the threads");
+  const int k = (threadIdx.x & (HW - 1)) + 1, r0 = WPT * (threadIdx.x / HW) + 1;  // st coordinates
   uint32_t first[WPT];  // this thread's strong words before the sweep
 #pragma unroll
   for (int j = 0; j < WPT; ++j) first[j] = st[r0 + j][k];
@@ -909,7 +911,7 @@ extern "C" int mg_canny_hysteresis(const uint32_t* d_weak, uint32_t* d_strong, i
   if (!d_weak || !d_strong || !d_changed || n_planes < 0 || h < 0 || w < 0) return MG_EINVAL;
   if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
   if (!words_ok(words_per_plane, h, w)) return MG_EINVAL;
-  const dim3 g = tile_grid(h, w, n_planes);
+  const dim3 g((w + TW - 1) / TW, (h + HTH - 1) / HTH, n_planes);
   if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
   hipLaunchKernelGGL(k_hysteresis, g, dim3(NT), 0, mg_stream(stream), d_weak, d_strong, words_per_plane, h, w,
                      d_changed, d_flags_in, d_flags_out);
@@ -920,7 +922,7 @@ extern "C" int mg_canny_hysteresis(const uint32_t* d_weak, uint32_t* d_strong, i
 extern "C" int mg_hysteresis_tiles(int h, int w, int* tiles_x, int* tiles_y) {
   if (!tiles_x || !tiles_y) return MG_EINVAL;
   *tiles_x = (w + TW - 1) / TW;
-  *tiles_y = (h + TH - 1) / TH;
+  *tiles_y = (h + HTH - 1) / HTH;
   return MG_OK;
 }
 

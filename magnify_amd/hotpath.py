@@ -405,11 +405,14 @@ class CircleFinder:
                 _call("mg_canny_hysteresis", self.weak_bits.data_ptr(), self.edge_bits.data_ptr(), self.words, P, h, w,
                       self.changed[g].data_ptr(), _ptr(prev), cur.data_ptr(), s)
                 sweeps += 1
-            if int(self.changed[group - 1].sum().item()) == 0:
+            per_sweep = self.changed[:group].sum(dim=1).cpu().numpy()
+            if per_sweep[group - 1] == 0:
+                # sweeps this image needed = up to and including the first one that changed nothing
+                needed = sweeps - group + int(np.argmax(per_sweep == 0)) + 1
                 break
             group = 2
         self.stats["hysteresis_sweeps"] = sweeps
-        self._hyst_hint = sweeps
+        self._hyst_hint = needed
         if self.keep_debug_maps:
             self.edges = torch.empty((P, h, w), dtype=torch.uint8, device=self.dev)
             _call("mg_unpack_bits", self.edge_bits.data_ptr(), self.words, P, h * w, self.edges.data_ptr(), s)
