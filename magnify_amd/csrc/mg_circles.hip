@@ -689,13 +689,24 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
       }
     } else {  // decide
       bool all_mine = true, hit_kept = false;
-      for (int j = 0; j < ring_len; ++j) {
-        const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
-        const uint64_t g = grid[(int64_t)rr * n_cols + cc];
-        if (g != key) {
-          all_mine = false;
-          if (g != ~0ull && reinterpret_cast<volatile uint8_t*>(state)[(uint32_t)g] == 1)
-            hit_kept = true;
+      constexpr int RB = 8;  // ring cells loaded together (the loop is a chain of cache misses otherwise)
+      for (int j0 = 0; j0 < ring_len; j0 += RB) {
+        uint64_t g[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          g[u] = key;
+          if (j0 + u < ring_len) {
+            const int rr = wrap(d_ring_rc[2 * (j0 + u)] + row + pad, n_rows);
+            const int cc = wrap(d_ring_rc[2 * (j0 + u) + 1] + col + pad, n_cols);
+            g[u] = grid[(int64_t)rr * n_cols + cc];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          if (g[u] != key) {
+            all_mine = false;
+            if (g[u] != ~0ull && reinterpret_cast<volatile uint8_t*>(state)[(uint32_t)g[u]] == 1) hit_kept = true;
+          }
         }
       }
       if (all_mine) {
