@@ -36,9 +36,9 @@ def algorithmic_bytes(stage, p):
         "mg_edge_angles": p["edges"] * (8 + 9 + 4),          # coordinate, 3x3 blurred neighbourhood, angle
         "mg_edge_grid": 2 * planes * n / 8 + 8 * p["edges"],  # bitmap twice (count, fill), write coords
         "mg_candidate_circles": 28 * planes * p["num_iter"],  # 3 coordinate reads (8 B) + the 32-bit key
-        # keys read once, tile layers written and read back once, the (row, col, r) list written
-        "mg_bitmap_to_circles": 4 * planes * p["num_iter"] + 2 * 4 * p["bitmap_words"] * planes + 12 * p["unique"],
-        "mg_score_circles": p["unique"] * (12 + p["mean_perimeter"] / 8 + 4),  # circle + perimeter edge bits + score
+        # keys read once, the unique keys written once (tile by tile, from LDS)
+        "mg_bitmap_to_circles": 4 * planes * p["num_iter"] + 4 * p["unique"],
+        "mg_score_circles": p["unique"] * (4 + p["mean_perimeter"] / 8 + 4),  # key + perimeter edge bits + score
         "mg_nms_round": p["alive"] * p["ring_len"] * 16 * p["nms_rounds"],
         "mg_collect_circles": p["alive"] * 4 + p["markers"] * 16,
         "mg_circle_labels": p["markers"] * p["mean_disk"] * 8,

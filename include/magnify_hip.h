@@ -199,17 +199,21 @@ int mg_candidate_keys(const int32_t* d_coords, int64_t coord_cap, const int32_t*
                       const uint64_t* d_seeds, int64_t num_iter, int min_r, int max_r, uint32_t* d_keys, float* d_raw,
                       void* stream);
 
-/* Keys -> bitmap -> unique circle list.  Because p0 is a stratified draw over the cell-major edge
+/* Keys -> unique keys, grouped by tile.  Because p0 is a stratified draw over the cell-major edge
  * list, the iterations that can place a centre in a given 64 x 64 tile form one contiguous key range
- * per cell row within max_r + 2 of the tile; one workgroup per tile scans them, ORs its own keys into
- * an LDS copy of the tile's layers, writes the layers (every word of d_bitmap is overwritten: no
- * pre-zeroing) and their bit counts, then the scan and the ordered emission of mg_bitmap_to_circles
- * run.  Outputs exactly as mg_bitmap_to_circles.  d_cell_* / d_num_edges / grid / num_iter must be
- * those the keys were generated with. */
+ * per cell row within max_r + 2 of the tile; one workgroup per pair of tiles scans them, ORs its own
+ * keys into an LDS copy of the tiles' layers, counts, reserves its slice of the plane's list with one
+ * atomicAdd on d_num_circles (zeroed by this call) and stores the unique keys of each tile in
+ * (r, row, col) order:
+ *   d_unique_keys[n_planes][circle_cap] uint32, d_tile_ranges[n_planes][n_tiles][2] int32 = (first, count)
+ *   of every tile (n_tiles = tile rows x tile cols of mg_dedup_layout), d_num_circles[n_planes].
+ * The slices of different workgroups land in arrival order: list positions are not canonical, the
+ * keys are (mg_nms_round / mg_collect_circles take them as tie-breakers).  d_cell_* / d_num_edges /
+ * grid / num_iter must be those the keys were generated with. */
 int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, const int32_t* d_cell_starts,
                        const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w, int grid,
-                       int min_r, int max_r, uint32_t* d_bitmap, int64_t bitmap_words, int32_t* d_layer_offsets,
-                       int32_t* d_circles, int64_t circle_cap, int32_t* d_num_circles, void* stream);
+                       int min_r, int max_r, uint32_t* d_unique_keys, int64_t circle_cap, int32_t* d_tile_ranges,
+                       int32_t* d_num_circles, void* stream);
 
 /* Ordered compaction of the bitmap into the unique circle list in the build's canonical order
  * (tile_row, tile_col, r, row, col): d_circles[n_planes][circle_cap][3] int32 (row, col, r),
@@ -235,17 +239,24 @@ int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, int n_planes,
  * d_alive[n_planes][circle_cap] (indices into d_circles), d_num_alive[n_planes] pre-zeroed;
  * d_max_rc[n_planes][2] (pre-set to INT32_MIN) receives max row / max col of the alive circles
  * (the claim-grid extent of utils.py:268-270).  d_num_scored (optional, [n_planes], pre-zeroed)
- * counts the circles that reached pass B. */
+ * counts the circles that reached pass B.
+ * Input, one of: (a) d_unique_keys + d_tile_ranges from mg_keys_to_circles (d_layer_offsets unused):
+ * the circles are decoded from the keys and d_circles[n_planes][circle_cap][3] is an OUTPUT, written
+ * only at the positions of the circles that pass the threshold (all that suppression and the ordered
+ * output read); (b) d_unique_keys == NULL: d_circles + d_layer_offsets from mg_bitmap_to_circles. */
 int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, const uint32_t* d_class_bits,
-                     int64_t words_per_plane, int n_planes, int h, int w, const int32_t* d_circles, int64_t circle_cap,
-                     const int32_t* d_layer_offsets, int min_r, int max_r, const int32_t* d_per_rc,
-                     const double* d_per_expected, const int32_t* d_per_starts, int per_total, float min_roundness,
-                     int write_skipped, float* d_scores, int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc,
+                     int64_t words_per_plane, int n_planes, int h, int w, int32_t* d_circles, int64_t circle_cap,
+                     const int32_t* d_layer_offsets, const uint32_t* d_unique_keys, const int32_t* d_tile_ranges,
+                     int min_r, int max_r, const int32_t* d_per_rc, const double* d_per_expected,
+                     const int32_t* d_per_starts, int per_total, float min_roundness, int write_skipped,
+                     float* d_scores, int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc,
                      int32_t* d_num_scored, void* stream);
 
 /* One round of the parallel-but-equivalent greedy suppression of filter_neighbors
- * (utils.py:254-292).  Priority = (score desc, index in d_circles asc) -- the build's
- * canonical tie order (tile_row, tile_col, r, row, col).  d_grid[n_planes][grid_cap] uint64 claim grid pre-set to all-ones;
+ * (utils.py:254-292).  Priority = (score desc, tie key asc) -- the build's canonical tie order
+ * (tile_row, tile_col, r, row, col): d_tie_keys[n_planes][circle_cap] (the unique keys of
+ * mg_keys_to_circles) or, when NULL, the index in d_circles (canonical after mg_bitmap_to_circles).
+ * d_grid[n_planes][grid_cap] uint64 claim grid pre-set to all-ones;
  * d_state[n_planes][circle_cap] uint8 (0 undecided, 1 kept, 2 dropped) pre-zeroed for
  * alive circles; d_undecided[n_planes] is overwritten with the number still undecided.
  * Ring = 4-connected perimeter of radius min_dist (d_ring_rc, ring_len); indices wrap
@@ -255,7 +266,7 @@ int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, const ui
 int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
                  const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist,
                  const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
-                 int32_t* d_undecided, int64_t max_alive, void* stream);
+                 int32_t* d_undecided, const uint32_t* d_tie_keys, int64_t max_alive, void* stream);
 
 /* After the rounds have converged: restore the all-ones claim grid under the rings of all alive
  * circles, so that the grid needs its full initialisation only once. */
@@ -270,7 +281,7 @@ int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, const float* d_
 int mg_collect_circles(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
                        const int32_t* d_num_alive, const uint8_t* d_state, int keep_all, int n_planes,
                        int32_t* d_out, float* d_out_scores, int64_t out_cap, int32_t* d_num_out,
-                       int32_t* d_scratch, void* stream);
+                       int32_t* d_scratch, const uint32_t* d_tie_keys, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * A12-A15, A18 labels, ROI gather, fg/bg masks, masked reductions

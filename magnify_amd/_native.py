@@ -44,13 +44,13 @@ PROTOTYPES = {
     "mg_edge_grid": [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p],
     "mg_candidate_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _p, _p],
     "mg_candidate_keys": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _i, _p, _p, _p],
-    "mg_keys_to_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _l, _p, _p, _l, _p, _p],
+    "mg_keys_to_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _l, _p, _p, _p],
     "mg_bitmap_to_circles": [_p, _l, _i, _i, _i, _i, _i, _p, _p, _l, _p, _p],
     "mg_edge_angles": [_p, _i, _i, _i, _p, _l, _p, _p, _p],
     "mg_dedup_layout": [_i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
-    "mg_score_circles": [_p, _p, _p, _l, _i, _i, _i, _p, _l, _p, _i, _i, _p, _p, _p, _i, _f, _i, _p, _p, _p, _p, _p, _p],
-    "mg_nms_round": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _l, _p],
-    "mg_collect_circles": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p],
+    "mg_score_circles": [_p, _p, _p, _l, _i, _i, _i, _p, _l, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _i, _p, _p, _p, _p, _p, _p],
+    "mg_nms_round": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _p, _l, _p],
+    "mg_collect_circles": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p],
     "mg_circle_labels": [_p, _l, _p, _i, _i, _i, _p, _i, _p, _i, _p],
     "mg_nms_cleanup": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _l, _p],
     "mg_roi_gather_reduce": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],

@@ -197,11 +197,14 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
                                                    const int32_t* __restrict__ d_counts,
                                                    const int32_t* __restrict__ d_num_edges, int h, int w, int grid,
                                                    int gr, int gc, int ntc, int nr, int max_r,
-                                                   uint32_t* __restrict__ d_bitmap, int64_t bitmap_words, int n_layers,
-                                                   int32_t* __restrict__ d_layer_offsets) {
+                                                   uint32_t* __restrict__ d_ukeys, int64_t circle_cap,
+                                                   int32_t* __restrict__ d_tile_ranges, int n_tiles,
+                                                   int32_t* __restrict__ d_num_circles) {
   extern __shared__ uint32_t lbits[];  // [TX][nr][LAYER_WORDS]
   __shared__ long long s_lo[MAX_RANGES];
   __shared__ int s_pre[MAX_RANGES + 1];
+  __shared__ int s_cnt[TX * 32 + 1];  // circles per (tile, layer), then their exclusive prefix (nr <= 32)
+  __shared__ int s_base;
   const int plane = blockIdx.z, tr = blockIdx.y, tc0 = blockIdx.x * TX;
   const int ntx = min(TX, ntc - tc0);  // tiles of this group that exist
   const int tile0 = tr * ntc + tc0;
@@ -226,8 +229,8 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
       long long lo = 0, hi = 0;
       if (eb > ea) {
         const double kpe = (double)num_iter / (double)n_edges;
-        lo = max((long long)((double)ea * kpe) - 2, 0ll);
         hi = min((long long)((double)eb * kpe) + 3, (long long)num_iter);
+        lo = min(max((long long)((double)ea * kpe) - 2, 0ll), hi);
       }
       s_lo[threadIdx.x] = lo;
       s_pre[threadIdx.x + 1] = (int)(hi - lo);
@@ -263,16 +266,51 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
     }
   }
   __syncthreads();
-  // per-layer counts (one wave per layer, as k_layer_count) and the layers themselves; the tiles of
-  // a group are consecutive in the bitmap and in the layer table
+  // Ordered emission straight from LDS: count every (tile, layer), reserve the group's slice of the
+  // plane's unique-key list with one atomicAdd (d_num_circles is the cursor), then every wave walks
+  // its layers -- lane = tile row, prefix by DPP scan -- and stores the keys in (tile, r, row, col)
+  // order.  Slices of different groups land in arrival order; everything downstream that needs the
+  // canonical order compares the keys themselves, never list positions.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int li = wave; li < ntx * nr; li += NT / 64) {
+  const int n_li = ntx * nr;
+  for (int li = wave; li < n_li; li += NT / 64) {
     const uint2 v = reinterpret_cast<const uint2*>(lbits + li * LAYER_WORDS)[lane];
     const int c = mg_wave_sum_i32(__popc(v.x) + __popc(v.y));
-    if (lane == 0) d_layer_offsets[(int64_t)plane * (n_layers + 1) + (int64_t)tile0 * nr + li] = c;
+    if (lane == 0) s_cnt[li] = c;
   }
-  uint4* dst = reinterpret_cast<uint4*>(d_bitmap + (int64_t)plane * bitmap_words + (int64_t)tile0 * words);
-  for (int i = threadIdx.x; i < ntx * words / 4; i += NT) dst[i] = reinterpret_cast<const uint4*>(lbits)[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int li = 0; li < n_li; ++li) {
+      const int c = s_cnt[li];
+      s_cnt[li] = run;
+      run += c;
+    }
+    s_cnt[n_li] = run;
+    s_base = run ? atomicAdd(&d_num_circles[plane], run) : 0;
+  }
+  __syncthreads();
+  const int64_t base = s_base;
+  if ((int)threadIdx.x < ntx) {
+    int32_t* tr2 = d_tile_ranges + ((int64_t)plane * n_tiles + tile0 + threadIdx.x) * 2;
+    tr2[0] = (int32_t)min(base + s_cnt[threadIdx.x * nr], circle_cap);
+    tr2[1] = s_cnt[(threadIdx.x + 1) * nr] - s_cnt[threadIdx.x * nr];
+  }
+  uint32_t* out = d_ukeys + (int64_t)plane * circle_cap;
+  for (int li = wave; li < n_li; li += NT / 64) {
+    const uint2 v = reinterpret_cast<const uint2*>(lbits + li * LAYER_WORDS)[lane];
+    uint64_t bits = ((uint64_t)v.y << 32) | v.x;
+    const int cnt = __popc(v.x) + __popc(v.y);
+    int64_t pos = base + s_cnt[li] + mg_wave_scan_incl_i32(cnt) - cnt;
+    const int t = li / nr, ri = li - t * nr;
+    const uint32_t hi = ((uint32_t)(tile0 + t) << 17) | ((uint32_t)ri << 12) | ((uint32_t)lane << 6);
+    while (bits) {
+      const int b = __ffsll((unsigned long long)bits) - 1;
+      bits &= bits - 1;
+      if (pos < circle_cap) out[pos] = hi | (uint32_t)b;
+      ++pos;
+    }
+  }
 }
 
 __global__ __launch_bounds__(1024) void k_layer_scan(int32_t* __restrict__ d_layer_offsets, int n_layers,
@@ -336,60 +374,6 @@ __global__ __launch_bounds__(NT) void k_layer_emit(uint32_t* __restrict__ d_bitm
   }
 }
 
-// Emission for the keyed path: one workgroup per tile, a wave takes the tile's radius layers
-// w, w + 4, ... with all of its bitmap rows loaded up front (5x fewer, fatter waves than
-// k_layer_emit; the bitmap is left as it is -- the next k_tile_dedup overwrites every word).
-constexpr int EMIT_LAYERS_PER_WAVE = 8;  // nr <= 32 on the keyed path
-
-__global__ __launch_bounds__(NT) void k_tile_emit(const uint32_t* __restrict__ d_bitmap, int64_t bitmap_words,
-                                                  int n_layers, const int32_t* __restrict__ d_layer_offsets, int ntc,
-                                                  int nr, int min_r, int max_r, int32_t* __restrict__ d_circles,
-                                                  int64_t circle_cap) {
-  const int plane = blockIdx.y, tile = blockIdx.x;
-  const int32_t* lo = d_layer_offsets + (int64_t)plane * (n_layers + 1) + (int64_t)tile * nr;
-  if (lo[nr] == lo[0]) return;  // empty tile (block-uniform)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint2* words = reinterpret_cast<const uint2*>(d_bitmap + (int64_t)plane * bitmap_words +
-                                                      (int64_t)tile * nr * LAYER_WORDS);
-  uint2 v[EMIT_LAYERS_PER_WAVE];
-  int start[EMIT_LAYERS_PER_WAVE];
-#pragma unroll
-  for (int u = 0; u < EMIT_LAYERS_PER_WAVE; ++u) {
-    const int ri = wave + u * (NT / 64);
-    v[u] = make_uint2(0u, 0u);
-    start[u] = 0;
-    if (ri < nr) {
-      v[u] = words[ri * (LAYER_WORDS / 2) + lane];
-      start[u] = lo[ri];
-    }
-  }
-  const int row = (tile / ntc) * TS + lane - max_r, col0 = (tile % ntc) * TS - max_r;
-  int32_t* out = d_circles + (int64_t)plane * circle_cap * 3;
-  // the prefix scans of all of this wave's layers first (DPP, no LDS permutes), then the stores
-  int cnt[EMIT_LAYERS_PER_WAVE], incl[EMIT_LAYERS_PER_WAVE];
-#pragma unroll
-  for (int u = 0; u < EMIT_LAYERS_PER_WAVE; ++u) incl[u] = cnt[u] = __popc(v[u].x) + __popc(v[u].y);
-#pragma unroll
-  for (int u = 0; u < EMIT_LAYERS_PER_WAVE; ++u) incl[u] = mg_wave_scan_incl_i32(incl[u]);
-#pragma unroll
-  for (int u = 0; u < EMIT_LAYERS_PER_WAVE; ++u) {
-    const int ri = wave + u * (NT / 64);
-    uint64_t bits = ((uint64_t)v[u].y << 32) | v[u].x;
-    if (ri >= nr || !bits) continue;
-    int64_t pos = (int64_t)start[u] + incl[u] - cnt[u];
-    while (bits) {
-      const int b = __ffsll((unsigned long long)bits) - 1;
-      bits &= bits - 1;
-      if (pos < circle_cap) {
-        out[3 * pos] = row;
-        out[3 * pos + 1] = col0 + b;
-        out[3 * pos + 2] = min_r + ri;
-      }
-      ++pos;
-    }
-  }
-}
-
 // ---- K9: scoring, one workgroup per centre tile ------------------------------------------------------
 // All circles of a tile (centres in a 64 x 64 block, radius <= max_r) touch only the
 // (64 + 2 max_r)^2 window around it, so the window of the 1-bit edge map is staged in LDS once
@@ -417,12 +401,18 @@ constexpr int SURV_IDX_BITS = 20;  // list entry: circle index within the round 
 //     W_k = edges & (class != (k + 2) & 3).  The 8 symmetric points of a group always fall into
 //     the same quarters (3, 2, 0, 1, 0, 1, 3, 2 for the table's (x > 0, y < 0, x < -y) entries), so
 //     with a compile-time slot size WS the window is an immediate offset of the LDS read.
-template <int WS>
-__global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_angle,
+//   KEYED: the tile's circles are the 32-bit keys k_tile_dedup emitted (d_ukeys, d_tile_ranges); the
+//     (row, col, r) triple of a circle is written to d_circles only when it passes the threshold.
+//     Otherwise: the (row, col, r) list and layer table of mg_bitmap_to_circles.
+// (96 SGPRs: the allocation step above would cost one of the 8 waves per SIMD.)
+template <int WS, bool KEYED>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(96))) void k_score_tiles(const float* __restrict__ d_angle,
                                                     const uint32_t* __restrict__ d_bits,
                                                     const uint32_t* __restrict__ d_class, int64_t words_per_plane,
-                                                    int h, int w, const int32_t* __restrict__ d_circles,
+                                                    int h, int w, int32_t* __restrict__ d_circles,
                                                     int64_t circle_cap, const int32_t* __restrict__ d_layer_offsets,
+                                                    const uint32_t* __restrict__ d_ukeys,
+                                                    const int32_t* __restrict__ d_tile_ranges, int n_tiles,
                                                     int n_layers, int nr, int ntc, int min_r, int max_r,
                                                     const int32_t* __restrict__ d_per_rc, int per_total,
                                                     const double* __restrict__ d_per_expected,
@@ -433,9 +423,16 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
   extern __shared__ uint32_t lds[];
   __shared__ int n_surv;
   const int plane = blockIdx.y, tile = blockIdx.x;
-  const int32_t* lo = d_layer_offsets + (int64_t)plane * (n_layers + 1);
-  const int64_t first = lo[(int64_t)tile * nr];
-  const int64_t last = min((int64_t)lo[(int64_t)(tile + 1) * nr], circle_cap);
+  int64_t first, last;
+  if (KEYED) {
+    const int32_t* tr2 = d_tile_ranges + ((int64_t)plane * n_tiles + tile) * 2;
+    first = tr2[0];
+    last = min(first + tr2[1], circle_cap);
+  } else {
+    const int32_t* lo = d_layer_offsets + (int64_t)plane * (n_layers + 1);
+    first = lo[(int64_t)tile * nr];
+    last = min((int64_t)lo[(int64_t)(tile + 1) * nr], circle_cap);
+  }
   if (first >= last) return;
   const int side = TS + 2 * max_r;
   int wsh = 0;
@@ -485,7 +482,19 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
 #define MG_TAB_DR(v) ((v) >> 16)
 #define MG_TAB_DC(v) (((int)((uint32_t)(v) << 18)) >> 18)
 #define MG_TAB_Q(v) (((v) >> 14) & 3)
-  const int32_t* circles = d_circles + (int64_t)plane * circle_cap * 3;
+  int32_t* circles = d_circles + (int64_t)plane * circle_cap * 3;
+  const uint32_t* ukeys = KEYED ? d_ukeys + (int64_t)plane * circle_cap : nullptr;
+  const int trow0 = (tile / ntc) * TS - max_r, tcol0 = (tile % ntc) * TS - max_r;  // centre of tile position (0, 0)
+#define MG_CIRCLE(i, row, col, rad)                                         \
+  int row, col, rad;                                                        \
+  if (KEYED) {                                                              \
+    const uint32_t key_ = ukeys[i];                                         \
+    row = trow0 + (int)((key_ >> 6) & 63u);                                 \
+    col = tcol0 + (int)(key_ & 63u);                                        \
+    rad = min_r + (int)((key_ >> 12) & 31u);                                \
+  } else {                                                                  \
+    row = circles[3 * (i)], col = circles[3 * (i) + 1], rad = circles[3 * (i) + 2]; \
+  }
   const float* ang = d_angle + (int64_t)plane * h * w;
   float* scores = d_scores + (int64_t)plane * circle_cap;
   const double PI = 3.141592653589793, INV_PI = 1.0 / 3.141592653589793;
@@ -499,7 +508,7 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
     int64_t pos = chunk;
     for (;;) {
     for (int64_t i = pos + threadIdx.x; i < min(pos + BATCH, last); i += NT) {
-      const int row = circles[3 * i], col = circles[3 * i + 1], rad = circles[3 * i + 2];
+      MG_CIRCLE(i, row, col, rad)
       const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
       const int len = p1 - p0;
       // need: hits >= min_roundness * len - 1e-3 (margin far above any rounding of the real sum)
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
     if (threadIdx.x == 0 && d_num_scored) atomicAdd(&d_num_scored[plane], ns);
     for (int a = threadIdx.x; a < ns; a += NT) {
       const int64_t i = chunk + (list[a] & ((1 << SURV_IDX_BITS) - 1));
-      const int row = circles[3 * i], col = circles[3 * i + 1], rad = circles[3 * i + 2];
+      MG_CIRCLE(i, row, col, rad)
       const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
       const int by = row - wy0, bx = col - wx0;
       double acc = 0.0;
@@ -614,6 +623,7 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
       if (score >= min_roundness) {
         const int k = atomicAdd(&d_num_alive[plane], 1);
         d_alive[(int64_t)plane * circle_cap + k] = (int32_t)i;
+        if (KEYED) circles[3 * i] = row, circles[3 * i + 1] = col, circles[3 * i + 2] = rad;
         atomicMax(&d_max_rc[2 * plane], row);
         atomicMax(&d_max_rc[2 * plane + 1], col);
       }
@@ -626,10 +636,13 @@ __global__ __launch_bounds__(NT) void k_score_tiles(const float* __restrict__ d_
 #undef MG_TAB_DR
 #undef MG_TAB_DC
 #undef MG_TAB_Q
+#undef MG_CIRCLE
 
 // ---- K10: greedy suppression in parallel rounds ------------------------------------------------------
-// Priority key: smaller = earlier in the reference's score-descending order; ties broken by
-// the canonical (r, row, col) index.
+// Priority key: smaller = earlier in the reference's score-descending order; ties broken by the
+// canonical (tile, r, row, col) order -- the circle's 32-bit de-duplication key on the keyed path
+// (list positions are arrival-ordered there), its list index otherwise.  The score field of a real
+// key is never 0, which leaves (0, tie) as the mark a kept circle puts on its ring cells.
 __device__ __forceinline__ uint64_t nms_key(float score, uint32_t idx) {
   uint32_t b = __float_as_uint(score);
   b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // ascending-sortable
@@ -659,10 +672,12 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
                                             const int32_t* __restrict__ d_max_rc, int min_dist,
                                             const int32_t* __restrict__ d_ring_rc, int ring_len,
                                             uint64_t* __restrict__ d_grid, int64_t grid_cap,
-                                            uint8_t* __restrict__ d_state, int32_t* __restrict__ d_undecided) {
+                                            uint8_t* __restrict__ d_state, int32_t* __restrict__ d_undecided,
+                                            const uint32_t* __restrict__ d_tie) {
   const int plane = blockIdx.y;
   const int n = d_num_alive[plane];
   if (n == 0) return;
+  const uint32_t* tie = d_tie ? d_tie + (int64_t)plane * circle_cap : nullptr;
   const int pad = 2 * min_dist + 1;
   const int n_rows = d_max_rc[2 * plane] + 2 * pad, n_cols = d_max_rc[2 * plane + 1] + 2 * pad;
   if ((int64_t)n_rows * n_cols > grid_cap) return;  // caller sized the grid from the image extent
@@ -675,7 +690,8 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
     const int idx = alive[a];
     if (PHASE != 2 && state[idx] != 0) continue;
     const int row = circles[3 * (int64_t)idx], col = circles[3 * (int64_t)idx + 1];
-    const uint64_t key = nms_key(scores[idx], (uint32_t)idx);
+    const uint32_t tk = tie ? tie[idx] : (uint32_t)idx;
+    const uint64_t key = nms_key(scores[idx], tk);
     if (PHASE == 2) {  // cleanup (after convergence): restore the all-ones grid under every ring
       for (int j = 0; j < ring_len; ++j) {
         const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
@@ -705,14 +721,19 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
         for (int u = 0; u < RB; ++u) {
           if (g[u] != key) {
             all_mine = false;
-            if (g[u] != ~0ull && reinterpret_cast<volatile uint8_t*>(state)[(uint32_t)g[u]] == 1) hit_kept = true;
+            if ((g[u] >> 32) == 0) hit_kept = true;  // a kept circle's mark
           }
         }
       }
       if (all_mine) {
-        reinterpret_cast<volatile uint8_t*>(state)[idx] = 1;
+        state[idx] = 1;
+        // mark the ring as kept: (0, tie) is below every real key, so no later bid replaces it
+        for (int j = 0; j < ring_len; ++j) {
+          const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
+          atomicMin(reinterpret_cast<unsigned long long*>(&grid[(int64_t)rr * n_cols + cc]), (unsigned long long)tk);
+        }
       } else if (hit_kept) {
-        reinterpret_cast<volatile uint8_t*>(state)[idx] = 2;
+        state[idx] = 2;
         // withdraw this circle's bids so that later circles can win these pixels
         for (int j = 0; j < ring_len; ++j) {
           const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
@@ -752,24 +773,26 @@ __global__ __launch_bounds__(NT) void k_collect_rank(const int32_t* __restrict__
                                                      const float* __restrict__ d_scores,
                                                      const int32_t* __restrict__ d_scratch,
                                                      int32_t* __restrict__ d_num_out, int64_t out_cap,
-                                                     int32_t* __restrict__ d_out, float* __restrict__ d_out_scores) {
+                                                     int32_t* __restrict__ d_out, float* __restrict__ d_out_scores,
+                                                     const uint32_t* __restrict__ d_tie) {
   __shared__ uint64_t keys[RANK_CHUNK];
   const int plane = blockIdx.y;
   const int m = (int)min((int64_t)d_num_out[plane], out_cap);
   const int32_t* list = d_scratch + (int64_t)plane * out_cap;
   const float* scores = d_scores + (int64_t)plane * circle_cap;
+  const uint32_t* tie = d_tie ? d_tie + (int64_t)plane * circle_cap : nullptr;
   // block-uniform trip count: every thread takes part in the staging barriers
   for (int64_t a0 = (int64_t)blockIdx.x * NT; a0 < m; a0 += (int64_t)gridDim.x * NT) {
     const int64_t a = a0 + threadIdx.x;
     const int idx = a < m ? list[a] : 0;
-    const uint64_t key = a < m ? nms_key(scores[idx], (uint32_t)idx) : 0;
+    const uint64_t key = a < m ? nms_key(scores[idx], tie ? tie[idx] : (uint32_t)idx) : 0;
     int rank = 0;
     for (int c0 = 0; c0 < m; c0 += RANK_CHUNK) {
       const int cn = min(RANK_CHUNK, m - c0);
       __syncthreads();
       for (int b = threadIdx.x; b < cn; b += NT) {
         const int j = list[c0 + b];
-        keys[b] = nms_key(scores[j], (uint32_t)j);
+        keys[b] = nms_key(scores[j], tie ? tie[j] : (uint32_t)j);
       }
       __syncthreads();
       for (int b = 0; b < cn; ++b) rank += keys[b] < key;
@@ -877,51 +900,50 @@ extern "C" int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, in
 
 extern "C" int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, const int32_t* d_cell_starts,
                                   const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w,
-                                  int grid, int min_r, int max_r, uint32_t* d_bitmap, int64_t bitmap_words,
-                                  int32_t* d_layer_offsets, int32_t* d_circles, int64_t circle_cap,
-                                  int32_t* d_num_circles, void* stream) {
-  if (!d_keys || !d_cell_starts || !d_cell_counts || !d_num_edges || !d_bitmap || !d_layer_offsets || !d_circles ||
+                                  int grid, int min_r, int max_r, uint32_t* d_unique_keys, int64_t circle_cap,
+                                  int32_t* d_tile_ranges, int32_t* d_num_circles, void* stream) {
+  if (!d_keys || !d_cell_starts || !d_cell_counts || !d_num_edges || !d_unique_keys || !d_tile_ranges ||
       !d_num_circles || n_planes < 0 || n_planes > 65535 || circle_cap < 0 || num_iter < 0 || grid <= 0)
     return MG_EINVAL;
   int ntr, ntc;
   int64_t n_layers, need_words;
   if (mg_dedup_layout(h, w, min_r, max_r, &ntr, &ntc, &n_layers, &need_words) != MG_OK) return MG_EINVAL;
   const int nr = max_r - min_r + 1;
-  if (bitmap_words < need_words || n_layers > 0x7FFFFFF0 || (int64_t)ntr * ntc >= 32768 || nr > 32) return MG_EINVAL;
+  if ((int64_t)ntr * ntc >= 32768 || nr > 32) return MG_EINVAL;  // the 32-bit key: 15 + 5 + 12 bits
   if ((TS + 2 * (max_r + 2)) / grid + 2 > MAX_RANGES || num_iter >= (1ll << 31)) return MG_EINVAL;
   if (n_planes == 0) return MG_OK;
-  const int nl = (int)n_layers;
   const int gr = (h + grid - 1) / grid, gc = (w + grid - 1) / grid;
   hipStream_t s = mg_stream(stream);
   if (ntr > 65535) return MG_EINVAL;
+  if (hipMemsetAsync(d_num_circles, 0, (size_t)n_planes * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
   const int tx = DEDUP_TX;  // 1 / 2 / 4 measured: 4.4 / 4.1 / 5.4 ms per step for the whole compaction
   hipLaunchKernelGGL(k_tile_dedup<DEDUP_TX>,
                      dim3((ntc + tx - 1) / tx, ntr, n_planes), dim3(NT), (size_t)tx * nr * LAYER_WORDS * 4, s, d_keys,
-                     num_iter, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gr, gc, ntc, nr, max_r, d_bitmap,
-                     bitmap_words, nl, d_layer_offsets);
+                     num_iter, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gr, gc, ntc, nr, max_r,
+                     d_unique_keys, circle_cap, d_tile_ranges, ntr * ntc, d_num_circles);
   MG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_layer_scan, dim3(n_planes), dim3(1024), 0, s, d_layer_offsets, nl, d_num_circles, circle_cap);
-  MG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_tile_emit, dim3(ntr * ntc, n_planes), dim3(NT), 0, s, d_bitmap, bitmap_words, nl,
-                     d_layer_offsets, ntc, nr, min_r, max_r, d_circles, circle_cap);
+  hipLaunchKernelGGL(k_clamp_counts, dim3((n_planes + 255) / 256), dim3(256), 0, s, d_num_circles, n_planes, circle_cap);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
 
 extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, const uint32_t* d_class_bits,
-                                int64_t words_per_plane, int n_planes, int h, int w, const int32_t* d_circles,
-                                int64_t circle_cap, const int32_t* d_layer_offsets, int min_r, int max_r,
-                                const int32_t* d_per_rc, const double* d_per_expected, const int32_t* d_per_starts,
-                                int per_total, float min_roundness, int write_skipped, float* d_scores,
-                                int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc, int32_t* d_num_scored,
-                                void* stream) {
-  if (!d_angle || !d_edge_bits || !d_circles || !d_layer_offsets || !d_per_rc || !d_per_expected || !d_per_starts ||
-      !d_scores || !d_alive || !d_num_alive || !d_max_rc)
+                                int64_t words_per_plane, int n_planes, int h, int w, int32_t* d_circles,
+                                int64_t circle_cap, const int32_t* d_layer_offsets, const uint32_t* d_unique_keys,
+                                const int32_t* d_tile_ranges, int min_r, int max_r, const int32_t* d_per_rc,
+                                const double* d_per_expected, const int32_t* d_per_starts, int per_total,
+                                float min_roundness, int write_skipped, float* d_scores, int32_t* d_alive,
+                                int32_t* d_num_alive, int32_t* d_max_rc, int32_t* d_num_scored, void* stream) {
+  if (!d_angle || !d_edge_bits || !d_circles || !d_per_rc || !d_per_expected || !d_per_starts || !d_scores ||
+      !d_alive || !d_num_alive || !d_max_rc)
     return MG_EINVAL;
+  const bool keyed = d_unique_keys != nullptr;
+  if (keyed ? !d_tile_ranges : !d_layer_offsets) return MG_EINVAL;
   if (n_planes < 0 || n_planes > 65535 || per_total <= 0 || max_r > 8000) return MG_EINVAL;
   int ntr, ntc;
   int64_t n_layers, words;
   if (mg_dedup_layout(h, w, min_r, max_r, &ntr, &ntc, &n_layers, &words) != MG_OK) return MG_EINVAL;
+  if (keyed && ((int64_t)ntr * ntc >= 32768 || max_r - min_r + 1 > 32)) return MG_EINVAL;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
   const int side = TS + 2 * max_r;
   int wpr = 1;
@@ -931,18 +953,20 @@ extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bit
   const bool small = side * wpr <= SMALL_SLOT;
   const size_t lds_bytes = ((size_t)4 * (small ? SMALL_SLOT : side * wpr) + per_total + CHUNK) * 4;
   if (lds_bytes > 150 * 1024) return MG_EINVAL;  // radii beyond ~150 px: outside this build's envelope
-  static bool attr_set = false;
-  if (lds_bytes > 48 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_tiles<0>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+  auto kernel = small ? (keyed ? k_score_tiles<SMALL_SLOT, true> : k_score_tiles<SMALL_SLOT, false>)
+                      : (keyed ? k_score_tiles<0, true> : k_score_tiles<0, false>);
+  static bool attr_set[2] = {false, false};
+  if (lds_bytes > 48 * 1024 && !attr_set[keyed]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            150 * 1024) != hipSuccess)
       return MG_ELAUNCH;
-    attr_set = true;
+    attr_set[keyed] = true;
   }
-  auto kernel = small ? k_score_tiles<SMALL_SLOT> : k_score_tiles<0>;
   hipLaunchKernelGGL(kernel, dim3(ntr * ntc, n_planes), dim3(NT), lds_bytes, mg_stream(stream), d_angle, d_edge_bits,
-                     d_class_bits, words_per_plane, h, w, d_circles, circle_cap, d_layer_offsets, (int)n_layers,
-                     max_r - min_r + 1, ntc, min_r, max_r, d_per_rc, per_total, d_per_expected, d_per_starts,
-                     min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc, d_num_scored);
+                     d_class_bits, words_per_plane, h, w, d_circles, circle_cap, d_layer_offsets, d_unique_keys,
+                     d_tile_ranges, ntr * ntc, (int)n_layers, max_r - min_r + 1, ntc, min_r, max_r, d_per_rc, per_total,
+                     d_per_expected, d_per_starts, min_roundness, write_skipped, d_scores, d_alive, d_num_alive,
+                     d_max_rc, d_num_scored);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -950,7 +974,8 @@ extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bit
 extern "C" int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
                             const int32_t* d_alive, const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes,
                             int min_dist, const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap,
-                            uint8_t* d_state, int32_t* d_undecided, int64_t max_alive, void* stream) {
+                            uint8_t* d_state, int32_t* d_undecided, const uint32_t* d_tie_keys, int64_t max_alive,
+                            void* stream) {
   if (!d_circles || !d_scores || !d_alive || !d_num_alive || !d_max_rc || !d_ring_rc || !d_grid || !d_state ||
       !d_undecided)
     return MG_EINVAL;
@@ -962,10 +987,10 @@ extern "C" int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const 
   // d_num_alive) only sizes the grid -- an all-capacity grid of empty blocks costs ~0.1 ms per launch
   const dim3 g(grid_x(max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap), n_planes);
   hipLaunchKernelGGL((k_nms<0>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                     min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided);
+                     min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided, d_tie_keys);
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_nms<1>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                     min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided);
+                     min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided, d_tie_keys);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -981,7 +1006,7 @@ extern "C" int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, cons
   hipLaunchKernelGGL((k_nms<2>), dim3(grid_x(max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap), n_planes),
                      dim3(NT), 0, mg_stream(stream), d_circles,
                      circle_cap, d_scores, d_alive, d_num_alive, d_max_rc, min_dist, d_ring_rc, ring_len, d_grid,
-                     grid_cap, d_state, (int32_t*)nullptr);
+                     grid_cap, d_state, (int32_t*)nullptr, (const uint32_t*)nullptr);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -989,7 +1014,7 @@ extern "C" int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, cons
 extern "C" int mg_collect_circles(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
                                   const int32_t* d_alive, const int32_t* d_num_alive, const uint8_t* d_state,
                                   int keep_all, int n_planes, int32_t* d_out, float* d_out_scores, int64_t out_cap,
-                                  int32_t* d_num_out, int32_t* d_scratch, void* stream) {
+                                  int32_t* d_num_out, int32_t* d_scratch, const uint32_t* d_tie_keys, void* stream) {
   if (!d_circles || !d_scores || !d_alive || !d_num_alive || !d_out || !d_num_out || !d_scratch) return MG_EINVAL;
   if (!keep_all && !d_state) return MG_EINVAL;
   if (n_planes < 0 || n_planes > 65535 || out_cap < 0) return MG_EINVAL;
@@ -1003,7 +1028,7 @@ extern "C" int mg_collect_circles(const int32_t* d_circles, int64_t circle_cap, 
                      keep_all, circle_cap, out_cap, d_scratch, d_num_out);
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_collect_rank, dim3(grid_x(out_cap), n_planes), dim3(NT), 0, s, d_circles, circle_cap, d_scores,
-                     d_scratch, d_num_out, out_cap, d_out, d_out_scores);
+                     d_scratch, d_num_out, out_cap, d_out, d_out_scores, d_tie_keys);
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_clamp_counts, dim3((n_planes + 255) / 256), dim3(256), 0, s, d_num_out, n_planes, out_cap);
   MG_CHECK_LAUNCH();

@@ -294,14 +294,18 @@ class CircleFinder:
         self.num_edges = torch.zeros((P,), dtype=i32, device=dev)
         self.coords = None
         ntr, ntc, self.n_layers, self.bitmap_words = nat.dedup_layout(h, w, self.min_r, self.max_r)
-        self.bitmap = torch.zeros((P, self.bitmap_words), dtype=i32, device=dev)
+        self.n_tiles = ntr * ntc
+        self.bitmap = self.layer_offsets = None  # only the atomicOr path needs them (allocated on first use)
         # keyed de-duplication (mg_candidate_keys + mg_keys_to_circles: no global atomics) whenever its
         # 32-bit key has room for the layout; else the atomicOr bitmap path
         self.keyed = (ntr * ntc < 32768 and self.max_r - self.min_r + 1 <= 32 and self.num_iter < 2**31
                       and (64 + 2 * (self.max_r + 2)) // self.grid + 2 <= 64)
         self.keys = torch.empty((P, self.num_iter), dtype=i32, device=dev) if self.keyed else None
-        self.layer_offsets = torch.zeros((P, self.n_layers + 1), dtype=i32, device=dev)
         self.cap = max(1, min(self.num_iter, self.bitmap_words * 32))
+        # keyed path: the unique keys per tile (arrival-ordered slices) and every tile's (first, count)
+        self.unique_keys = torch.empty((P, self.cap), dtype=i32, device=dev) if self.keyed else None
+        self.tile_ranges = torch.zeros((P, self.n_tiles, 2), dtype=i32, device=dev) if self.keyed else None
+        self._tie_keys = None  # unique_keys while they describe self.circles (tie-breakers of the suppression)
         self.circles = torch.empty((P, self.cap, 3), dtype=i32, device=dev)
         self.num_circles = torch.zeros((P,), dtype=i32, device=dev)
         self.scores = torch.empty((P, self.cap), dtype=torch.float32, device=dev)
@@ -443,9 +447,14 @@ class CircleFinder:
                   stage="mg_candidate_circles")
             _call("mg_keys_to_circles", self.keys.data_ptr(), self.num_iter, self.cell_starts.data_ptr(),
                   self.cell_counts.data_ptr(), self.num_edges.data_ptr(), P, h, w, self.grid, self.min_r, self.max_r,
-                  self.bitmap.data_ptr(), self.bitmap_words, self.layer_offsets.data_ptr(), self.circles.data_ptr(),
-                  self.cap, self.num_circles.data_ptr(), s, stage="mg_bitmap_to_circles")
+                  self.unique_keys.data_ptr(), self.cap, self.tile_ranges.data_ptr(), self.num_circles.data_ptr(), s,
+                  stage="mg_bitmap_to_circles")
+            self._tie_keys = self.unique_keys
         else:
+            if self.bitmap is None:
+                self.bitmap = torch.zeros((P, self.bitmap_words), dtype=torch.int32, device=self.dev)
+                self.layer_offsets = torch.zeros((P, self.n_layers + 1), dtype=torch.int32, device=self.dev)
+            self._tie_keys = None
             _call("mg_candidate_circles", self.coords.data_ptr(), self.coord_cap, self.cell_starts.data_ptr(),
                   self.cell_counts.data_ptr(), self.num_edges.data_ptr(), P, h, w, self.grid,
                   self.seeds.data_ptr(), self.num_iter, self.min_r, self.max_r,
@@ -457,7 +466,8 @@ class CircleFinder:
         self.num_scored.zero_()
         self.max_rc.fill_(-(2**31))
         _call("mg_score_circles", self.angle.data_ptr(), self.edge_bits.data_ptr(), _ptr(self.class_bits), self.words, P, h, w,
-              self.circles.data_ptr(), self.cap, self.layer_offsets.data_ptr(), self.min_r, self.max_r,
+              self.circles.data_ptr(), self.cap, _ptr(self.layer_offsets), _ptr(self._tie_keys),
+              _ptr(self.tile_ranges if self._tie_keys is not None else None), self.min_r, self.max_r,
               self.per_rc.data_ptr(), self.per_exp.data_ptr(), self.per_starts.data_ptr(), int(self.per_rc.shape[0]),
               float(min_roundness), int(self.keep_debug_maps), self.scores.data_ptr(), self.alive.data_ptr(),
               self.num_alive.data_ptr(), self.max_rc.data_ptr(), self.num_scored.data_ptr(), s)
@@ -484,7 +494,8 @@ class CircleFinder:
                     _call("mg_nms_round", self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
                           self.alive.data_ptr(), self.num_alive.data_ptr(), self.max_rc.data_ptr(), P,
                           min_dist, ring.data_ptr(), ring.shape[0], self.nms_grid.data_ptr(),
-                          self.nms_grid.shape[1], self.state.data_ptr(), self.undecided.data_ptr(), out_cap, s)
+                          self.nms_grid.shape[1], self.state.data_ptr(), self.undecided.data_ptr(),
+                          _ptr(self._tie_keys), out_cap, s)
                     rounds += 1
                 if int(self.undecided.sum().item()) == 0:
                     break
@@ -501,7 +512,7 @@ class CircleFinder:
         _call("mg_collect_circles", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
                                        self.num_alive.data_ptr(), self.state.data_ptr(), int(min_dist <= 0), P,
                                        out.data_ptr(), out_scores.data_ptr(), out_cap, num_out.data_ptr(),
-                                       scratch.data_ptr(), s)
+                                       scratch.data_ptr(), _ptr(self._tie_keys), s)
         if rounds:
             _call("mg_nms_cleanup", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
                   self.num_alive.data_ptr(), self.max_rc.data_ptr(), P, min_dist, self._nms_ring.data_ptr(),

@@ -255,6 +255,30 @@ def test_candidates_scores_nms(hp, keyed):
     angle = cf.angle.cpu().numpy()
     if not keyed:
         assert cf.bitmap.count_nonzero().item() == 0  # the atomic path's compaction leaves the bitmap clean
+    else:
+        # keyed path: unique 32-bit keys, one slice per tile (slices in arrival order, sorted inside);
+        # decode them, bring list and scores into the canonical order = ascending key
+        ukeys = cf.unique_keys.cpu().numpy().view(np.uint32)
+        ranges = cf.tile_ranges.cpu().numpy()
+        alive_idx, n_alive = cf.alive.cpu().numpy(), cf.num_alive.cpu().numpy()
+        ntc = (w + 2 * max_r + 63) // 64
+        dec_circles, dec_scores = [], []
+        for k in range(p):
+            n = n_circles[k]
+            kk = ukeys[k, :n]
+            assert ranges[k, :, 1].sum() == n and len(np.unique(kk)) == n
+            for t in np.nonzero(ranges[k, :, 1])[0][:50]:
+                sl = kk[ranges[k, t, 0]: ranges[k, t, 0] + ranges[k, t, 1]]
+                assert (sl >> 17 == t).all() and (np.diff(sl.astype(np.int64)) > 0).all()
+            tile = (kk >> 17).astype(np.int64)
+            dec = np.stack([(tile // ntc) * 64 + ((kk >> 6) & 63) - max_r, (tile % ntc) * 64 + (kk & 63) - max_r,
+                            min_r + ((kk >> 12) & 31)], axis=1).astype(np.int32)
+            # the (row, col, r) triples exist in cf.circles only for the circles that passed the threshold
+            ai = alive_idx[k, : n_alive[k]]
+            np.testing.assert_array_equal(circles[k, ai], dec[ai])
+            order = np.argsort(kk, kind="stable")
+            dec_circles.append(dec[order])
+            dec_scores.append(scores[k, :n][order])
     for k in range(p):
         u8 = rn.to_uint8(planes[k])
         _, dx, dy, edges, _ = rp.edge_stage(u8, 0.1, 0.9)
@@ -269,7 +293,7 @@ def test_candidates_scores_nms(hp, keyed):
         c = np.unique(c, axis=0)
         c = c[np.lexsort(rn.canonical_key(c, max_r))]  # tile-major emission order
         assert n_circles[k] == len(c)
-        np.testing.assert_array_equal(circles[k, : len(c)], c)
+        np.testing.assert_array_equal(dec_circles[k] if keyed else circles[k, : len(c)], c)
         # scores, given the GPU's own angle map as the oracle's grad_angles
         ang = np.where(edges > 0, angle[k], 0).astype(np.float32)
         pad = 2 * max_r
@@ -279,7 +303,7 @@ def test_candidates_scores_nms(hp, keyed):
             sel = c[:, 2] == r
             per = rn.circle_points(r)
             want_scores[sel] = rn.mean_grad(pa, pe, c[sel, :2] + pad, per) / len(per)
-        got = scores[k, : len(c)].copy()
+        got = (dec_scores[k] if keyed else scores[k, : len(c)]).copy()
         # circles the exact prefilter skipped are provably below the threshold
         skipped = got == np.float32(-2.0)
         assert (want_scores[skipped] < np.float32(0.3)).all()
