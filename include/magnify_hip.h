@@ -320,11 +320,14 @@ int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int64_t assay_s
  * assay-major; d_assay_offsets int32[n_assays + 1] delimits every assay's markers (marker g of assay
  * a has label value g - d_assay_offsets[a]); max_per_assay >= the largest per-assay marker count
  * (launch grid = max_per_assay x n_assays); d_halfwidths / max_r as for mg_circle_labels (disks with
- * r < 2 or r > max_r cover nothing, as there).  Outputs as mg_roi_gather_reduce. */
+ * r < 2 or r > max_r cover nothing, as there).  bead_stride = 0: d_beads is that compact list;
+ * bead_stride > 0: d_beads holds one padded row of bead_stride triples per assay (the layout
+ * mg_collect_circles writes: the ROI pass can start from the device-resident tables while the host
+ * is still fetching them); the outputs are compact either way.  Outputs as mg_roi_gather_reduce. */
 int mg_roi_segment_reduce(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h, int w,
-                          const int32_t* d_beads, const int32_t* d_assay_offsets, int n_assays, int max_per_assay,
-                          int m, int roi_len, const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg,
-                          uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream);
+                          const int32_t* d_beads, int64_t bead_stride, const int32_t* d_assay_offsets, int n_assays,
+                          int max_per_assay, int m, int roi_len, const int32_t* d_halfwidths, int max_r, void* d_roi,
+                          uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream);
 
 /* Masked median (numpy nanmedian semantics: mean of the two middle values) of an already
  * gathered roi (m, C, T, L, L) under mask (m, L, L): d_median double[m][C][T], NaN if the

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64
                                             const int32_t* __restrict__ d_marker_assay,
                                             const int32_t* __restrict__ d_marker_local, int len,
                                             const int32_t* __restrict__ d_labels,
-                                            const int32_t* __restrict__ d_assay_offsets,
+                                            const int32_t* __restrict__ d_assay_offsets, int64_t bead_stride,
                                             const int32_t* __restrict__ d_halfwidths, int max_r, T* __restrict__ d_roi,
                                             uint8_t* __restrict__ d_fg, uint8_t* __restrict__ d_bg,
                                             double* __restrict__ d_sums, int32_t* __restrict__ d_counts) {
@@ -173,17 +173,21 @@ __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64
   __shared__ int s_cnt[2][NT / 64];
   // label mode: one block per marker of a flat list; disk mode: grid (local index, assay)
   int g = blockIdx.x, assay, first = 0, local;
+  int64_t bead0 = 0, gb = g;  // the assay's first bead / this marker's bead in d_beads
   if (d_assay_offsets) {
     assay = blockIdx.y;
     first = d_assay_offsets[assay];
     local = blockIdx.x;
     if (local >= d_assay_offsets[assay + 1] - first) return;
     g = first + local;
+    // bead table: compact (markers and beads share the index) or one padded row per assay
+    bead0 = bead_stride ? (int64_t)assay * bead_stride : first;
+    gb = bead0 + local;
   } else {
     assay = d_marker_assay ? d_marker_assay[g] : 0;
     local = d_marker_local ? d_marker_local[g] : g;
   }
-  const int cy = d_beads[3 * (int64_t)g], cx = d_beads[3 * (int64_t)g + 1];
+  const int cy = d_beads[3 * gb], cx = d_beads[3 * gb + 1];
   int top, left;
   window(cy, len, h, top);
   window(cx, len, w, left);
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64
   DiskMasks dm{};
   if (d_halfwidths)
     dm = build_disk_masks(reinterpret_cast<uint32_t*>(flags + ((n + 3) & ~3)), len, top, left,
-                          d_beads + 3 * (int64_t)first, d_assay_offsets[assay + 1] - first, local, d_halfwidths, max_r);
+                          d_beads + 3 * bead0, d_assay_offsets[assay + 1] - first, local, d_halfwidths, max_r);
   int cf = 0, cb = 0;
   for (int p = threadIdx.x; p < n; p += NT) {
     const int ry = p / len, rx = p - ry * len;
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
                                                      const int32_t* __restrict__ d_marker_assay,
                                                      const int32_t* __restrict__ d_marker_local, int len,
                                                      const int32_t* __restrict__ d_labels,
-                                                     const int32_t* __restrict__ d_assay_offsets,
+                                                     const int32_t* __restrict__ d_assay_offsets, int64_t bead_stride,
                                                      const int32_t* __restrict__ d_halfwidths, int max_r,
                                                      uint16_t* __restrict__ d_roi, uint8_t* __restrict__ d_fg,
                                                      uint8_t* __restrict__ d_bg, double* __restrict__ d_sums,
@@ -281,19 +285,23 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
   __shared__ int s_cnt[2][NT / 64];
   // label mode: one block per marker of a flat list; disk mode: grid (local index, assay)
   int g = blockIdx.x, assay, first = 0, local;
+  int64_t bead0 = 0, gb = g;  // the assay's first bead / this marker's bead in d_beads
   if (d_assay_offsets) {
     assay = blockIdx.y;
     first = d_assay_offsets[assay];
     local = blockIdx.x;
     if (local >= d_assay_offsets[assay + 1] - first) return;
     g = first + local;
+    // bead table: compact (markers and beads share the index) or one padded row per assay
+    bead0 = bead_stride ? (int64_t)assay * bead_stride : first;
+    gb = bead0 + local;
   } else {
     assay = d_marker_assay ? d_marker_assay[g] : 0;
     local = d_marker_local ? d_marker_local[g] : g;
   }
   int top, left;
-  window(d_beads[3 * (int64_t)g], len, h, top);
-  window(d_beads[3 * (int64_t)g + 1], len, w, left);
+  window(d_beads[3 * gb], len, h, top);
+  window(d_beads[3 * gb + 1], len, w, left);
   const int n = len * len, half = len >> 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = 2 * lane;
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
   DiskMasks dm{};
   if (d_halfwidths)
     dm = build_disk_masks(reinterpret_cast<uint32_t*>(flags + ((n + 3) & ~3)), len, top, left,
-                          d_beads + 3 * (int64_t)first, d_assay_offsets[assay + 1] - first, local, d_halfwidths, max_r);
+                          d_beads + 3 * bead0, d_assay_offsets[assay + 1] - first, local, d_halfwidths, max_r);
   int cf = 0, cb = 0;
   for (int ry = wave; ry < len; ry += NT / 64) {
     if (!act) continue;
@@ -460,11 +468,11 @@ __global__ __launch_bounds__(NT) void k_masked_median_u16(const uint16_t* __rest
 template <typename T, typename ACC>
 int launch_roi(const void* d_image, int64_t assay_stride, int n_c, int n_t, int h, int w, const int32_t* d_beads,
                const int32_t* d_marker_assay, const int32_t* d_marker_local, dim3 grid, int len,
-               const int32_t* d_labels, const int32_t* d_assay_offsets, const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg,
-               uint8_t* d_bg, double* d_sums, int32_t* d_counts, hipStream_t s) {
+               const int32_t* d_labels, const int32_t* d_assay_offsets, int64_t bead_stride, const int32_t* d_halfwidths,
+               int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, hipStream_t s) {
   hipLaunchKernelGGL((k_roi<T, ACC>), grid, dim3(NT), roi_lds_bytes(len, d_halfwidths != nullptr), s,
                      (const T*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, len,
-                     d_labels, d_assay_offsets, d_halfwidths, max_r, (T*)d_roi, d_fg, d_bg, d_sums, d_counts);
+                     d_labels, d_assay_offsets, bead_stride, d_halfwidths, max_r, (T*)d_roi, d_fg, d_bg, d_sums, d_counts);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -487,8 +495,9 @@ extern "C" int mg_circle_labels(const int32_t* d_beads, int64_t bead_cap, const 
 namespace {
 int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h, int w,
                  const int32_t* d_beads, const int32_t* d_marker_assay, const int32_t* d_marker_local, int m, int roi_len,
-                 const int32_t* d_labels, const int32_t* d_assay_offsets, int n_assays, int max_per_assay,
-                 const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream) {
+                 const int32_t* d_labels, const int32_t* d_assay_offsets, int64_t bead_stride, int n_assays,
+                 int max_per_assay, const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
+                 double* d_sums, int32_t* d_counts, void* stream) {
   if (!d_image || !d_beads || m < 0 || roi_len <= 0 || n_c <= 0 || n_t <= 0) return MG_EINVAL;
   if (roi_len > h || roi_len > w || roi_lds_bytes(roi_len, d_halfwidths != nullptr) > 60000) return MG_EINVAL;
   if (m == 0) return MG_OK;
@@ -500,27 +509,27 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
     // 4 row loads in flight per wave (2..13 measured: 4-7 are equally fast, 2 is 30 % slower)
     hipLaunchKernelGGL(k_roi_u16_even<4>, grid, dim3(NT), roi_lds_bytes(roi_len, d_halfwidths != nullptr), s,
                        (const uint16_t*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                       roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg, d_sums,
-                       d_counts);
+                       roi_len, d_labels, d_assay_offsets, bead_stride, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg,
+                       d_sums, d_counts);
     MG_CHECK_LAUNCH();
     return MG_OK;
   }
   switch (dtype) {
     case MG_U8:
       return launch_roi<uint8_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
-                                            d_marker_local, grid, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r,
+                                            d_marker_local, grid, roi_len, d_labels, d_assay_offsets, bead_stride, d_halfwidths, max_r,
                                             d_roi, d_fg, d_bg, d_sums, d_counts, s);
     case MG_U16:
       return launch_roi<uint16_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
-                                             d_marker_local, grid, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r,
+                                             d_marker_local, grid, roi_len, d_labels, d_assay_offsets, bead_stride, d_halfwidths, max_r,
                                              d_roi, d_fg, d_bg, d_sums, d_counts, s);
     case MG_F32:
       return launch_roi<float, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                                       grid, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                                       grid, roi_len, d_labels, d_assay_offsets, bead_stride, d_halfwidths, max_r, d_roi, d_fg, d_bg,
                                        d_sums, d_counts, s);
     case MG_F64:
       return launch_roi<double, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                                        grid, roi_len, d_labels, d_assay_offsets, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                                        grid, roi_len, d_labels, d_assay_offsets, bead_stride, d_halfwidths, max_r, d_roi, d_fg, d_bg,
                                         d_sums, d_counts, s);
   }
   return MG_EINVAL;
@@ -533,19 +542,21 @@ extern "C" int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int6
                                             const int32_t* d_labels, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
                                             double* d_sums, int32_t* d_counts, void* stream) {
   return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, m, roi_len,
-                      d_labels, nullptr, 0, 0, nullptr, 0, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
+                      d_labels, nullptr, 0, 0, 0, nullptr, 0, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
 }
 
 extern "C" int mg_roi_segment_reduce(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h,
-                                     int w, const int32_t* d_beads, const int32_t* d_assay_offsets, int n_assays,
-                                     int max_per_assay, int m, int roi_len,
+                                     int w, const int32_t* d_beads, int64_t bead_stride,
+                                     const int32_t* d_assay_offsets, int n_assays, int max_per_assay, int m, int roi_len,
                                      const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
                                      double* d_sums, int32_t* d_counts, void* stream) {
-  if (!d_assay_offsets || !d_halfwidths || n_assays <= 0 || n_assays > 65535 || max_per_assay < 0 || max_r < 0)
+  if (!d_assay_offsets || !d_halfwidths || n_assays <= 0 || n_assays > 65535 || max_per_assay < 0 || max_r < 0 ||
+      bead_stride < 0 || (bead_stride > 0 && bead_stride < max_per_assay))
     return MG_EINVAL;
   if (max_per_assay == 0) return MG_OK;
   return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, nullptr, nullptr, m, roi_len, nullptr,
-                      d_assay_offsets, n_assays, max_per_assay, d_halfwidths, max_r, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
+                      d_assay_offsets, bead_stride, n_assays, max_per_assay, d_halfwidths, max_r, d_roi, d_fg, d_bg, d_sums,
+                      d_counts, stream);
 }
 
 extern "C" int mg_roi_gather_reduce(const void* d_image, int dtype, int n_c, int n_t, int h, int w,

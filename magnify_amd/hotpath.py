@@ -521,19 +521,38 @@ class CircleFinder:
         return out, out_scores, num_out
 
     def find(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw=False, keep_u8=False,
-             passthrough_u8=False):
+             passthrough_u8=False, host_results=True):
         """Returns per-plane lists (circles int32 (M,3) [row, col, r], scores float32 (M,)) on the
-        host plus the device tensors (out, out_scores, num_out)."""
+        host plus the device tensors (out, out_scores, num_out).  ``host_results=False``: only the
+        counts come back -- (counts, (out, out_scores, num_out)); ``fetch_results`` copies the lists
+        later (e.g. after the ROI pass, which reads the tables on the device, has been launched)."""
         n_edges = self.edge_stage(planes, minmax, low_q, high_q, keep_u8=keep_u8, passthrough_u8=passthrough_u8)
         self.circle_stage(seeds, min_roundness, keep_raw=keep_raw)
         out, out_scores, num_out = self.nms_stage(min_dist)
         counts = num_out.cpu().numpy()
+        self.stats["n_edges"] = n_edges
+        if not host_results:
+            self._results_ready = torch.cuda.Event()
+            self._results_ready.record()
+            return counts, (out, out_scores, num_out)
+        return self.fetch_results(counts, out, out_scores), (out, out_scores, num_out)
+
+    def fetch_results(self, counts, out, out_scores, overlap=False):
+        """Host copies of the ordered circle lists.  ``overlap``: on a side stream that only waits for
+        the suppression's outputs, so the copies run beside whatever was launched after ``find``."""
         # only the filled prefix comes back (the full-capacity copies left the GPU idle for ~0.5 ms)
         mx = max(int(counts.max()) if self.P else 0, 1)
-        out_h, sc_h = out[:, :mx].contiguous().cpu().numpy(), out_scores[:, :mx].contiguous().cpu().numpy()
-        res = [(out_h[p, : counts[p]].copy(), sc_h[p, : counts[p]].copy()) for p in range(self.P)]
-        self.stats["n_edges"] = n_edges
-        return res, (out, out_scores, num_out)
+        if overlap:
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+            self._side.wait_event(self._results_ready)
+            with torch.cuda.stream(self._side):
+                out.record_stream(self._side)
+                out_scores.record_stream(self._side)
+                out_h, sc_h = out[:, :mx].contiguous().cpu().numpy(), out_scores[:, :mx].contiguous().cpu().numpy()
+        else:
+            out_h, sc_h = out[:, :mx].contiguous().cpu().numpy(), out_scores[:, :mx].contiguous().cpu().numpy()
+        return [(out_h[p, : counts[p]].copy(), sc_h[p, : counts[p]].copy()) for p in range(self.P)]
 
 
 # --------------------------------------------------------------------------------------
@@ -615,11 +634,16 @@ def release_labels(labels):
 
 
 def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, labels: torch.Tensor | None,
-                      want_roi=True, want_masks=True, want_sums=True, reuse_buffers=False, disks=False):
+                      want_roi=True, want_masks=True, want_sums=True, reuse_buffers=False, disks=False,
+                      device_tables=None):
     """images (A, C, T, h, w); centers_per_assay: list of (M_a, >=2) int arrays [row, col, ...].
 
     Masks: from the ``labels`` map (utils.circle_labels) or, with ``disks=True`` and (M_a, 3) bead
     tables [row, col, r], straight from the bead geometry (same result, no label map at all).
+
+    ``device_tables=(d_beads (A, cap, 3) int32, counts, max_r)`` (with ``disks``): the bead tables
+    are still on the device, one padded row per assay as mg_collect_circles writes them; only the
+    per-assay counts (host) are needed to size the outputs, ``centers_per_assay`` is ignored.
 
     Returns dict: roi (M, C, T, L, L), fg/bg (M, L, L) uint8, sums (M, C, T, 2) float64
     [fg sum, bg sum], counts (M, 2) int32, offsets (A+1,) numpy.  ``reuse_buffers`` returns views of
@@ -628,7 +652,7 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
     a, c, t, h, w = images.shape
     images = images.contiguous()
     dev = images.device
-    sizes = [len(b) for b in centers_per_assay]
+    sizes = [int(n) for n in device_tables[1]] if device_tables is not None else [len(b) for b in centers_per_assay]
     m = int(sum(sizes))
     offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     res = {"offsets": offsets}
@@ -640,6 +664,16 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
     res["sums"] = alloc("sums", m, (c, t, 2), torch.float64, dev) if want_sums else None
     res["counts"] = alloc("counts", m, (2,), torch.int32, dev) if want_sums else None
     if m == 0:
+        return res
+    if device_tables is not None:
+        d_tab, _, max_r = device_tables
+        assert disks and d_tab.dtype == torch.int32 and d_tab.is_contiguous() and d_tab.shape[0] == a
+        max_r = max(int(max_r), 2)
+        tab = _halfwidth_table(max_r, dev)
+        d_off = torch.from_numpy(offsets.astype(np.int32)).to(dev, non_blocking=True)
+        _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
+              d_tab.data_ptr(), d_tab.shape[1], d_off.data_ptr(), a, int(max(sizes)), m, L, tab.data_ptr(), max_r,
+              _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
         return res
     beads = np.zeros((m, 3), dtype=np.int32)
     assay = np.zeros(m, dtype=np.int32)
@@ -657,7 +691,7 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         tab = _halfwidth_table(max_r, dev)
         d_off = torch.from_numpy(offsets.astype(np.int32)).to(dev)
         _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
-              d_beads.data_ptr(), d_off.data_ptr(), a, int(max(sizes)), m, L, tab.data_ptr(), max_r,
+              d_beads.data_ptr(), 0, d_off.data_ptr(), a, int(max(sizes)), m, L, tab.data_ptr(), max_r,
               _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
         return res
     d_assay = torch.from_numpy(assay).to(dev)

@@ -171,9 +171,26 @@ class StackProcessor:
             if not stack.is_cuda:
                 stack = stack.to(self.dev, non_blocking=True)
             self.flatfield(stack, flatfield, darkfield)
+            if self.mode == "P" and len(self.search_channels) == 1 and self.batch >= self.n_assays:
+                return self._detect_reduce_on_device(seed, want_roi)
             beads = self.detect(seed)
         out = self.segment_reduce(beads, want_roi=want_roi)
         out["beads"] = beads
+        return out
+
+    def _detect_reduce_on_device(self, seed, want_roi):
+        """One search channel, the whole stack in one batch: there is no cross-channel de-duplication
+        (find.py:490-500) to do on the host, so the ROI pass reads the suppression's bead tables where
+        they are -- on the device -- and the host fetches its copy of them while that pass runs."""
+        T, C, h, w = self.T, self.C, self.h, self.w
+        ch = self.search_channels[0]
+        seeds = [(seed + 1000003 * a) & 0xFFFFFFFFFFFFFFFF for a in range(self.n_assays)]
+        counts, (d_beads, d_scores, _) = self.finder.find(self.image[:, ch], self.minmax[:, ch].contiguous(), self.low_q,
+                                                           self.high_q, self.min_roundness, self.min_r, seeds,
+                                                           host_results=False)
+        out = hp.roi_gather_reduce(self.image.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi,
+                                   reuse_buffers=True, disks=True, device_tables=(d_beads, counts, self.max_r))
+        out["beads"] = [r[0] for r in self.finder.fetch_results(counts, d_beads, d_scores, overlap=True)]
         return out
 
 
