@@ -409,7 +409,12 @@ class CircleFinder:
                 _call("mg_canny_hysteresis", self.weak_bits.data_ptr(), self.edge_bits.data_ptr(), self.words, P, h, w,
                       self.changed[g].data_ptr(), _ptr(prev), cur.data_ptr(), s)
                 sweeps += 1
-            per_sweep = self.changed[:group].sum(dim=1).cpu().numpy()
+            # the cell counts of the edge grid ride on the same host round trip as the convergence check
+            # (they are recomputed in the rare case that more sweeps are needed)
+            _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, P, h, w, self.grid, self.cell_counts.data_ptr(),
+                  self.cell_starts.data_ptr(), self.num_edges.data_ptr(), 0, 0, s)
+            both = torch.cat([self.changed[:group].sum(dim=1), self.num_edges.to(torch.int64)]).cpu().numpy()
+            per_sweep, n_edges = both[:group], both[group:].astype(np.int32)
             if per_sweep[group - 1] == 0:
                 # sweeps this image needed = up to and including the first one that changed nothing
                 needed = sweeps - group + int(np.argmax(per_sweep == 0)) + 1
@@ -420,9 +425,6 @@ class CircleFinder:
         if self.keep_debug_maps:
             self.edges = torch.empty((P, h, w), dtype=torch.uint8, device=self.dev)
             _call("mg_unpack_bits", self.edge_bits.data_ptr(), self.words, P, h * w, self.edges.data_ptr(), s)
-        _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, P, h, w, self.grid, self.cell_counts.data_ptr(),
-              self.cell_starts.data_ptr(), self.num_edges.data_ptr(), 0, 0, s)
-        n_edges = self.num_edges.cpu().numpy()
         self.coord_cap = max(1, int(n_edges.max()))
         if self.coords is None or self.coords.shape[1] < self.coord_cap:
             self.coords = torch.empty((P, int(self.coord_cap * 1.25) + 1, 2), dtype=torch.int32, device=self.dev)
@@ -477,6 +479,16 @@ class CircleFinder:
         L, P, s = nat.lib(), self.P, _stream()
         n_alive = self.num_alive.cpu().numpy()
         out_cap = max(1, int(n_alive.max()))
+        out = torch.empty((P, out_cap, 3), dtype=torch.int32, device=self.dev)
+        out_scores = torch.empty((P, out_cap), dtype=torch.float32, device=self.dev)
+        scratch = torch.empty((P, out_cap), dtype=torch.int32, device=self.dev)
+        num_out = torch.zeros((P,), dtype=torch.int32, device=self.dev)
+
+        def collect():
+            _call("mg_collect_circles", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
+                  self.num_alive.data_ptr(), self.state.data_ptr(), int(min_dist <= 0), P, out.data_ptr(),
+                  out_scores.data_ptr(), out_cap, num_out.data_ptr(), scratch.data_ptr(), _ptr(self._tie_keys), s)
+
         rounds = 0
         if min_dist > 0 and n_alive.max() > 0:
             pad = 2 * min_dist + 1
@@ -485,39 +497,43 @@ class CircleFinder:
                 self.nms_grid = torch.empty((P, grid_cap), dtype=torch.int64, device=self.dev)
                 self.nms_grid.fill_(-1)  # once: every call restores the cells it touched (mg_nms_cleanup)
                 self.state.zero_()
-            ring = torch.from_numpy(nat.circle_points(min_dist, True)).to(self.dev)
-            # rounds per host check: the previous call's count first (a round with nothing undecided does
-            # no work), then two at a time
+            if getattr(self, "_nms_dist", None) != min_dist:
+                self._nms_ring = torch.from_numpy(nat.circle_points(min_dist, True)).to(self.dev)
+                self._nms_dist = min_dist
+            ring = self._nms_ring
+            # rounds per host check: as many as the previous call needed (a round with nothing undecided
+            # does no work), then two at a time.  The ordered output is gathered before the check and rides
+            # on the same round trip (it is gathered again in the rare case that more rounds are needed).
             group = max(2, min(int(self._nms_hint), 64))
+            if self.undecided.dim() != 2 or self.undecided.shape[0] < group:
+                self.undecided = torch.zeros((group, P), dtype=torch.int32, device=self.dev)
             while True:
-                for _ in range(group):
+                for g in range(group):
                     _call("mg_nms_round", self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
                           self.alive.data_ptr(), self.num_alive.data_ptr(), self.max_rc.data_ptr(), P,
                           min_dist, ring.data_ptr(), ring.shape[0], self.nms_grid.data_ptr(),
-                          self.nms_grid.shape[1], self.state.data_ptr(), self.undecided.data_ptr(),
+                          self.nms_grid.shape[1], self.state.data_ptr(), self.undecided[g].data_ptr(),
                           _ptr(self._tie_keys), out_cap, s)
                     rounds += 1
-                if int(self.undecided.sum().item()) == 0:
+                collect()
+                both = torch.cat([self.undecided[:group].sum(dim=1), num_out.to(torch.int64)]).cpu().numpy()
+                per_round, counts = both[:group], both[group:]
+                if per_round[group - 1] == 0:
+                    self._nms_hint = rounds - group + int(np.argmax(per_round == 0)) + 1
                     break
                 group = 2
                 if rounds > 10000:
                     raise RuntimeError("greedy suppression did not converge")
-            self._nms_hint = rounds
-            self._nms_ring, self._nms_dist = ring, min_dist
+        else:
+            collect()
+            counts = num_out.cpu().numpy()
         self.stats["nms_rounds"] = rounds
-        out = torch.empty((P, out_cap, 3), dtype=torch.int32, device=self.dev)
-        out_scores = torch.empty((P, out_cap), dtype=torch.float32, device=self.dev)
-        scratch = torch.empty((P, out_cap), dtype=torch.int32, device=self.dev)
-        num_out = torch.zeros((P,), dtype=torch.int32, device=self.dev)
-        _call("mg_collect_circles", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
-                                       self.num_alive.data_ptr(), self.state.data_ptr(), int(min_dist <= 0), P,
-                                       out.data_ptr(), out_scores.data_ptr(), out_cap, num_out.data_ptr(),
-                                       scratch.data_ptr(), _ptr(self._tie_keys), s)
         if rounds:
             _call("mg_nms_cleanup", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
                   self.num_alive.data_ptr(), self.max_rc.data_ptr(), P, min_dist, self._nms_ring.data_ptr(),
                   self._nms_ring.shape[0], self.nms_grid.data_ptr(), self.nms_grid.shape[1], self.state.data_ptr(),
                   out_cap, s)
+        self._out_counts = counts.astype(np.int64)
         return out, out_scores, num_out
 
     def find(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw=False, keep_u8=False,
@@ -529,7 +545,7 @@ class CircleFinder:
         n_edges = self.edge_stage(planes, minmax, low_q, high_q, keep_u8=keep_u8, passthrough_u8=passthrough_u8)
         self.circle_stage(seeds, min_roundness, keep_raw=keep_raw)
         out, out_scores, num_out = self.nms_stage(min_dist)
-        counts = num_out.cpu().numpy()
+        counts = self._out_counts  # came back with the suppression's convergence check
         self.stats["n_edges"] = n_edges
         if not host_results:
             self._results_ready = torch.cuda.Event()
