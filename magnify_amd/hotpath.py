@@ -352,30 +352,38 @@ class CircleFinder:
         # fine bins give the order statistic directly
         ccum_d = torch.cumsum(self.hist.to(torch.int64), dim=1)
         ranks_d = torch.tensor(ranks, dtype=torch.int64, device=self.dev).expand(P, -1).contiguous()
-        bins = torch.searchsorted(ccum_d, ranks_d, right=True).cpu().numpy()
+        bins_d = torch.searchsorted(ccum_d, ranks_d, right=True)
+        bins = bins_d.cpu().numpy()
         order_stat = np.where(bins < FINE_BINS, bins, -1).astype(np.int64)
-        todo = [sorted({int(b) - FINE_BINS for b in bins[p] if b >= FINE_BINS}) for p in range(P)] \
-            if (bins >= FINE_BINS).any() else [[] for _ in range(P)]
-        n_pass = max(len(t) for t in todo)
+        n_pass = 0
+        if (bins >= FINE_BINS).any():
+            # Window pass(es): ranks that fell into a coarse bin (strong gradients) are resolved by a fine
+            # histogram of that bin's value window.  Per plane: its distinct coarse bins in ascending
+            # order, one per pass; the look-ups stay on the device (only P x 4 integers come back).
+            big = 1 << 30
+            c = np.where(bins >= FINE_BINS, bins - FINE_BINS, big)
+            c.sort(axis=1)
+            c[:, 1:][c[:, 1:] == c[:, :-1]] = big
+            c.sort(axis=1)
+            cnt = (c < big).sum(axis=1)
+            n_pass = int(cnt.max())
+            order_d = torch.where(bins_d < FINE_BINS, bins_d, torch.full_like(bins_d, -1))
+            rows = np.arange(P)
+            for k in range(n_pass):
+                base_bins = np.where(cnt > 0, c[rows, np.minimum(k, np.maximum(cnt - 1, 0))], 0).astype(np.int64)
+                base_d = torch.from_numpy(base_bins).to(self.dev)
+                self.hist_base.copy_((base_d << COARSE_SHIFT).to(torch.int32))
+                fine = self.hist.view(-1)[: P * FINE_BINS].view(P, FINE_BINS)
+                fine.zero_()
+                _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 1, self.hist_base.data_ptr(), fine.data_ptr(),
+                      self.hist_scratch.data_ptr(), self.hist_scratch.numel(), s)
+                fcum_d = torch.cumsum(fine.to(torch.int64), dim=1)
+                below_d = ccum_d.gather(1, (FINE_BINS + base_d - 1).clamp_(min=0)[:, None])  # values below the bin
+                pos_d = torch.searchsorted(fcum_d, (ranks_d - below_d).contiguous(), right=True)
+                hit = bins_d == (FINE_BINS + base_d)[:, None]
+                order_d = torch.where(hit, (base_d[:, None] << COARSE_SHIFT) + pos_d, order_d)
+            order_stat = order_d.cpu().numpy()
         self.stats["hist_passes"] = 1 + n_pass
-        ccum = ccum_d.cpu().numpy() if n_pass else None
-        for k in range(n_pass):
-            # window pass(es): resolve ranks that fell into a coarse bin (rare: strong gradients)
-            base_bins = np.array([t[min(k, len(t) - 1)] if t else 0 for t in todo], dtype=np.int64)
-            self.hist_base.copy_(torch.from_numpy((base_bins << COARSE_SHIFT).astype(np.int32)))
-            fine = self.hist.view(-1)[: P * FINE_BINS].view(P, FINE_BINS)
-            fine.zero_()
-            _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 1, self.hist_base.data_ptr(), fine.data_ptr(),
-                  self.hist_scratch.data_ptr(), self.hist_scratch.numel(), s)
-            fcum = torch.cumsum(fine.to(torch.int64), dim=1).cpu().numpy()
-            for p in range(P):
-                if not todo[p]:
-                    continue
-                b = base_bins[p]
-                below = ccum[p, FINE_BINS + b - 1]
-                for j, r in enumerate(ranks):
-                    if bins[p, j] == FINE_BINS + b:
-                        order_stat[p, j] = (b << COARSE_SHIFT) + np.searchsorted(fcum[p], r - below, side="right")
         # np.quantile's interpolation and cv::Canny's threshold preparation, vectorised over the planes
         # (same float32 / float64 operations as quantile_indexes / lerp_f32 / canny_int_thresholds)
         vals = []
