@@ -258,13 +258,17 @@ class ButtonFinder:
                     circles, scores = res[c]
                     if len(circles) > 0 and scores[0] > best_score[c]:  # sorted by score: [0] is np.argmax
                         best[c], best_score[c] = circles[0], scores[0]
-        for c in range(m):
-            i, j = divmod(c, n_cols)
-            if tag[i, j] == "" or best[c, 2] < 0:
-                continue
-            top, _, left, _ = utils.bounding_box(int(centers[c, 1]), int(centers[c, 0]), L, w, h)
-            y[i, j], x[i, j] = best[c, 0] + top, best[c, 1] + left
-            radius[i, j] = best[c, 2]
+        # window origins of all chambers at once (utils.bounding_box: shift the L x L window into the image)
+        def origin(c, size):
+            lo = c.astype(np.int64) - L // 2
+            lo = np.where(lo < 0, 0, lo)
+            return np.where(lo + L > size, size - L, lo)
+
+        top, left = origin(centers[:, 0], h), origin(centers[:, 1], w)
+        found = ((tag != "").reshape(-1)) & (best[:, 2] >= 0)
+        ys, xs, rs = y.reshape(-1), x.reshape(-1), radius.reshape(-1)  # views of the (contiguous) copies
+        ys[found], xs[found] = (best[:, 0] + top)[found], (best[:, 1] + left)[found]
+        rs[found] = best[found, 2]
         return x, y, radius
 
     def __call__(self, assay):
