@@ -86,8 +86,9 @@ class BeadFinder:
             b = dedup_against(beads, res[0][0], 2 * self.min_bead_radius)  # find.py:490-500
             beads = np.concatenate([beads, b])
         m, L = len(beads), self.roi_length
-        labels = hotpath.circle_labels([beads], h, w, device=image.device) if m else None
-        out = hotpath.roi_gather_reduce(image[None], [beads], L, labels)
+        # masks straight from the bead table (what utils.circle_labels + the == i / == -1 tests yield,
+        # find.py:561-586) -- no label map is written or read
+        out = hotpath.roi_gather_reduce(image[None], [beads], L, None, disks=True)
         fg = out["fg"].bool()[:, None].expand(m, n_t, L, L)  # geometry replicated over time (find.py:585-586)
         bg = out["bg"].bool()[:, None].expand(m, n_t, L, L)
         assay["roi"] = DataArray(out["roi"], ("mark", "channel", "time", "roi_y", "roi_x"))
