@@ -176,3 +176,44 @@ def test_argument_errors(mg):
                  overlap=0, num_iter=10)
     with pytest.raises(TypeError):
         mg.beads(mg.DataArray(np.zeros((64, 64), np.complex64), ("y", "x")), overlap=0, num_iter=10)
+
+
+def test_full_size_chip_stages_match_c_oracle(mg, monkeypatch):
+    """BASELINE's chip size (C3: 28 x 28 buttons on a 7376 x 7376 stitched image, 5e6 RANSAC iterations):
+    ButtonFinder's grid fit and per-chamber refinement against the oracle's restatement of find_centers /
+    find_rois, with the oracle's C port doing the circle search (the NumPy one takes minutes at this size)."""
+    from magnify_amd.find import ButtonFinder
+    from oracle import cport
+
+    def c_find_circles(img_u8, low_q, high_q, grid, num_iter, min_r, max_r, min_roundness, min_dist, seed=0, **_):
+        return cport.find_circles(img_u8, low_q, high_q, grid, num_iter, min_r, max_r, min_roundness, min_dist, seed=seed)
+
+    monkeypatch.setattr(rp, "find_circles", c_find_circles)
+    n, pitch = 28, 250
+    canvas = draw_chip((n, n), 20, row_dist=pitch, col_dist=pitch)
+    img = np.zeros((7376, 7376), dtype=np.uint16)
+    img[: min(7376, canvas.shape[0]), : min(7376, canvas.shape[1])] = canvas[:7376, :7376]
+    img[img > 0] += 123
+    tag = np.full((n, n), "default", dtype="<U200")
+    tag[3, 4] = tag[20, 11] = ""
+    bf = ButtonFinder(row_dist=pitch, col_dist=pitch, min_button_diameter=8, max_button_diameter=30, chamber_diameter=60,
+                      top_chamber=None, left_chamber=None, low_edge_quantile=0.1, high_edge_quantile=0.9,
+                      num_iter=5_000_000, min_roundness=0.2, cluster_penalty=50, roi_length=None, progress_bar=False,
+                      search_timestep=0, search_channel=None, interactive=False)
+    d_img = torch.from_numpy(img).cuda()
+    gx, gy = bf.find_centers(d_img[None], tag, [4242])
+    ox, oy = rp.find_centers(img[None], tag, pitch, pitch, 4, 15, 30, 0.1, 0.9, 5_000_000, 0.2, 50, seed=4242)
+    np.testing.assert_allclose(gx, ox, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(gy, oy, rtol=0, atol=1e-9)
+    x, y, radius = bf.refine(d_img[None], gx, gy, tag, [0], 777)
+    _, fg_o, _, x_o, y_o = rp.find_rois(img[None], ox, oy, tag, [0], 4, 15, 30, 72, 0.1, 5_000_000, 0.2, seed=777)
+    np.testing.assert_allclose(x, x_o, atol=1e-9)
+    np.testing.assert_allclose(y, y_o, atol=1e-9)
+    found = tag != ""
+    # the oracle's fg mask is cv.circle's disk of the refined radius: same radii <=> same pixel counts
+    from oracle import ref_opencv as rcv
+
+    area = {r: int(rcv.filled_circle_mask((72, 72), (36, 36), r).sum()) for r in range(4, 16)}
+    np.testing.assert_array_equal(fg_o.sum(axis=(-1, -2)), np.vectorize(area.get)(radius))
+    assert (np.abs(x[found] - pitch * (np.arange(n)[None, :] + 1).repeat(n, 0)[found]) <= 2).all()
+    assert radius[3, 4] == 15 and (radius[found] >= 8).all() and (radius[found] <= 12).all()
