@@ -217,3 +217,26 @@ def test_full_size_chip_stages_match_c_oracle(mg, monkeypatch):
     np.testing.assert_array_equal(fg_o.sum(axis=(-1, -2)), np.vectorize(area.get)(radius))
     assert (np.abs(x[found] - pitch * (np.arange(n)[None, :] + 1).repeat(n, 0)[found]) <= 2).all()
     assert radius[3, 4] == 15 and (radius[found] >= 8).all() and (radius[found] <= 12).all()
+
+
+def test_public_api_c2_matches_c_oracle(mg):
+    """BASELINE's C2 (4 ch x 4096^2, reference-default 5e6 iterations) through the drop-in call mg.beads:
+    bead positions, ROI pixels and fg / bg masks equal the oracle's C restatement."""
+    from magnify_amd.stack import synthetic_stack
+    from oracle import cport
+
+    stack, _ = synthetic_stack(1, 4, 4096, 4096, seed=2000)
+    planes = stack[0]
+    mg.seed(2100)
+    xp = mg.beads(data=mg.DataArray(planes, ("channel", "y", "x")), overlap=0, num_iter=5_000_000, search_channel=0)
+    host = planes.cpu().numpy()
+    img = cport.flatfield_correct(host[:, None, None, None], 1.0, 0.0)[:, 0, 0, 0]
+    first = (2100 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF  # the first seed magnify_amd.utils.next_seed hands out
+    want = cport.bead_assay(img, 5, 25, 100, num_iter=5_000_000, seed=first)
+    m = xp.roi.sizes["mark"]
+    assert m == len(want["beads"]) > 1500
+    np.testing.assert_array_equal(np.asarray(xp.y.values).reshape(m, -1)[:, 0], want["beads"][:, 0])
+    np.testing.assert_array_equal(np.asarray(xp.x.values).reshape(m, -1)[:, 0], want["beads"][:, 1])
+    np.testing.assert_array_equal(np.asarray(xp.roi.values).reshape(want["roi"].shape), want["roi"])
+    np.testing.assert_array_equal(np.asarray(xp.fg.values).reshape(want["fg"].shape), want["fg"])
+    np.testing.assert_array_equal(np.asarray(xp.bg.values).reshape(want["bg"].shape), want["bg"])
