@@ -273,21 +273,33 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
   // canonical order compares the keys themselves, never list positions.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_li = ntx * nr;
-  for (int li = wave; li < n_li; li += NT / 64) {
-    const uint2 v = reinterpret_cast<const uint2*>(lbits + li * LAYER_WORDS)[lane];
-    const int c = mg_wave_sum_i32(__popc(v.x) + __popc(v.y));
-    if (lane == 0) s_cnt[li] = c;
+  // one pass over the wave's layers (li = wave, wave + 4, ...): the rows stay in registers together with
+  // their inclusive lane prefix, whose last lane is the layer's count
+  constexpr int LPW = TX * 32 / (NT / 64);  // layers per wave at most (nr <= 32)
+  uint2 rows[LPW];
+  int incl[LPW];
+#pragma unroll
+  for (int u = 0; u < LPW; ++u) {
+    const int li = wave + u * (NT / 64);
+    rows[u] = make_uint2(0u, 0u);
+    incl[u] = 0;
+    if (li < n_li) {  // wave-uniform
+      rows[u] = reinterpret_cast<const uint2*>(lbits + li * LAYER_WORDS)[lane];
+      incl[u] = mg_wave_scan_incl_i32(__popc(rows[u].x) + __popc(rows[u].y));
+      const int total = __builtin_amdgcn_readlane(incl[u], 63);
+      if (lane == 0) s_cnt[li] = total;
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int li = 0; li < n_li; ++li) {
-      const int c = s_cnt[li];
-      s_cnt[li] = run;
-      run += c;
+  if (wave == 0) {  // exclusive prefix of the n_li <= 64 layer counts by one wave scan
+    const int c = lane < n_li ? s_cnt[lane] : 0;
+    const int inc = mg_wave_scan_incl_i32(c);
+    const int run = __builtin_amdgcn_readlane(inc, 63);
+    if (lane < n_li) s_cnt[lane] = inc - c;
+    if (lane == 0) {
+      s_cnt[n_li] = run;
+      s_base = run ? atomicAdd(&d_num_circles[plane], run) : 0;
     }
-    s_cnt[n_li] = run;
-    s_base = run ? atomicAdd(&d_num_circles[plane], run) : 0;
   }
   __syncthreads();
   const int64_t base = s_base;
@@ -297,11 +309,12 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
     tr2[1] = s_cnt[(threadIdx.x + 1) * nr] - s_cnt[threadIdx.x * nr];
   }
   uint32_t* out = d_ukeys + (int64_t)plane * circle_cap;
-  for (int li = wave; li < n_li; li += NT / 64) {
-    const uint2 v = reinterpret_cast<const uint2*>(lbits + li * LAYER_WORDS)[lane];
-    uint64_t bits = ((uint64_t)v.y << 32) | v.x;
-    const int cnt = __popc(v.x) + __popc(v.y);
-    int64_t pos = base + s_cnt[li] + mg_wave_scan_incl_i32(cnt) - cnt;
+#pragma unroll
+  for (int u = 0; u < LPW; ++u) {
+    const int li = wave + u * (NT / 64);
+    uint64_t bits = ((uint64_t)rows[u].y << 32) | rows[u].x;
+    if (li >= n_li || !bits) continue;
+    int64_t pos = base + s_cnt[li] + incl[u] - (__popc(rows[u].x) + __popc(rows[u].y));
     const int t = li / nr, ri = li - t * nr;
     const uint32_t hi = ((uint32_t)(tile0 + t) << 17) | ((uint32_t)ri << 12) | ((uint32_t)lane << 6);
     while (bits) {
