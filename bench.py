@@ -298,7 +298,7 @@ def main():
         for part in (roofline, streaming):
             if part and result["hbm_copy_ceiling"]:
                 gbs = part.get("achieved", part.get("achieved_GBs"))
-                part["frac_of_measured_copy"] = gbs / result["hbm_copy_ceiling"]["GBs"]
+                part["frac_of_measured_copy"] = gbs / result["hbm_copy_ceiling"]["GBs"] if gbs else None
         if not args.no_cpu and world == 1:
             last = args.warmup + args.steps - 1  # seed of the step whose results are in `out`
             seeds = [(last + 1000003 * a) & 0xFFFFFFFFFFFFFFFF for a in range(T)]
