@@ -323,9 +323,13 @@ int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int64_t assay_s
  * r < 2 or r > max_r cover nothing, as there).  bead_stride = 0: d_beads is that compact list;
  * bead_stride > 0: d_beads holds one padded row of bead_stride triples per assay (the layout
  * mg_collect_circles writes: the ROI pass can start from the device-resident tables while the host
- * is still fetching them); the outputs are compact either way.  Outputs as mg_roi_gather_reduce. */
+ * is still fetching them); the outputs are compact either way.  time_major != 0: every assay's image
+ * block is stored (n_t, n_c, h, w) instead of (n_c, n_t, h, w) -- a time-sharded single assay is gathered
+ * where the flat-field pass left it, without a transposing copy; the outputs stay (channel, time)-ordered.
+ * Outputs as mg_roi_gather_reduce. */
 int mg_roi_segment_reduce(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h, int w,
-                          const int32_t* d_beads, int64_t bead_stride, const int32_t* d_assay_offsets, int n_assays,
+                          int time_major, const int32_t* d_beads, int64_t bead_stride, const int32_t* d_assay_offsets,
+                          int n_assays,
                           int max_per_assay, int m, int roi_len, const int32_t* d_halfwidths, int max_r, void* d_roi,
                           uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream);
 

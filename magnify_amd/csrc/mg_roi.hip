@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64
                                             const int32_t* __restrict__ d_marker_assay,
                                             const int32_t* __restrict__ d_marker_local, int len,
                                             const int32_t* __restrict__ d_labels,
-                                            const int32_t* __restrict__ d_assay_offsets, int64_t bead_stride,
+                                            const int32_t* __restrict__ d_assay_offsets, int64_t bead_stride, int time_major,
                                             const int32_t* __restrict__ d_halfwidths, int max_r, T* __restrict__ d_roi,
                                             uint8_t* __restrict__ d_fg, uint8_t* __restrict__ d_bg,
                                             double* __restrict__ d_sums, int32_t* __restrict__ d_counts) {
@@ -233,7 +233,8 @@ __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64
   // gather every (channel, time) window (find.py:589-602) and reduce under the masks
   const T* img = d_image + (int64_t)assay * assay_stride;
   for (int ct = 0; ct < n_c * n_t; ++ct) {
-    const T* plane = img + (int64_t)ct * h * w;
+    // outputs are (channel, time)-ordered; the image block may be stored time-major (t, c, h, w)
+    const T* plane = img + (int64_t)(time_major ? (ct % n_t) * n_c + ct / n_t : ct) * h * w;
     T* out = d_roi ? d_roi + ((int64_t)g * n_c * n_t + ct) * n : nullptr;
     ACC sf = 0, sb = 0;
     for (int p = threadIdx.x; p < n; p += NT) {
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
                                                      const int32_t* __restrict__ d_marker_assay,
                                                      const int32_t* __restrict__ d_marker_local, int len,
                                                      const int32_t* __restrict__ d_labels,
-                                                     const int32_t* __restrict__ d_assay_offsets, int64_t bead_stride,
+                                                     const int32_t* __restrict__ d_assay_offsets, int64_t bead_stride, int time_major,
                                                      const int32_t* __restrict__ d_halfwidths, int max_r,
                                                      uint16_t* __restrict__ d_roi, uint8_t* __restrict__ d_fg,
                                                      uint8_t* __restrict__ d_bg, double* __restrict__ d_sums,
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
   }
   const uint16_t* img = d_image + (int64_t)assay * assay_stride;
   for (int ct = 0; ct < n_c * n_t; ++ct) {
-    const uint16_t* plane = img + (int64_t)ct * h * w;
+    const uint16_t* plane = img + (int64_t)(time_major ? (ct % n_t) * n_c + ct / n_t : ct) * h * w;
     uint16_t* out = d_roi ? d_roi + ((int64_t)g * n_c * n_t + ct) * n : nullptr;
     long long sf = 0, sb = 0;
     // rows are handled U at a time per wave: all U row loads are in flight before the first is
@@ -468,11 +469,12 @@ __global__ __launch_bounds__(NT) void k_masked_median_u16(const uint16_t* __rest
 template <typename T, typename ACC>
 int launch_roi(const void* d_image, int64_t assay_stride, int n_c, int n_t, int h, int w, const int32_t* d_beads,
                const int32_t* d_marker_assay, const int32_t* d_marker_local, dim3 grid, int len,
-               const int32_t* d_labels, const int32_t* d_assay_offsets, int64_t bead_stride, const int32_t* d_halfwidths,
+               const int32_t* d_labels, const int32_t* d_assay_offsets, int64_t bead_stride, int time_major,
+               const int32_t* d_halfwidths,
                int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, hipStream_t s) {
   hipLaunchKernelGGL((k_roi<T, ACC>), grid, dim3(NT), roi_lds_bytes(len, d_halfwidths != nullptr), s,
                      (const T*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, len,
-                     d_labels, d_assay_offsets, bead_stride, d_halfwidths, max_r, (T*)d_roi, d_fg, d_bg, d_sums, d_counts);
+                     d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r, (T*)d_roi, d_fg, d_bg, d_sums, d_counts);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -495,7 +497,7 @@ extern "C" int mg_circle_labels(const int32_t* d_beads, int64_t bead_cap, const 
 namespace {
 int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h, int w,
                  const int32_t* d_beads, const int32_t* d_marker_assay, const int32_t* d_marker_local, int m, int roi_len,
-                 const int32_t* d_labels, const int32_t* d_assay_offsets, int64_t bead_stride, int n_assays,
+                 const int32_t* d_labels, const int32_t* d_assay_offsets, int64_t bead_stride, int time_major, int n_assays,
                  int max_per_assay, const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
                  double* d_sums, int32_t* d_counts, void* stream) {
   if (!d_image || !d_beads || m < 0 || roi_len <= 0 || n_c <= 0 || n_t <= 0) return MG_EINVAL;
@@ -509,7 +511,7 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
     // 4 row loads in flight per wave (2..13 measured: 4-7 are equally fast, 2 is 30 % slower)
     hipLaunchKernelGGL(k_roi_u16_even<4>, grid, dim3(NT), roi_lds_bytes(roi_len, d_halfwidths != nullptr), s,
                        (const uint16_t*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                       roi_len, d_labels, d_assay_offsets, bead_stride, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg,
+                       roi_len, d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg,
                        d_sums, d_counts);
     MG_CHECK_LAUNCH();
     return MG_OK;
@@ -517,19 +519,19 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
   switch (dtype) {
     case MG_U8:
       return launch_roi<uint8_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
-                                            d_marker_local, grid, roi_len, d_labels, d_assay_offsets, bead_stride, d_halfwidths, max_r,
+                                            d_marker_local, grid, roi_len, d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r,
                                             d_roi, d_fg, d_bg, d_sums, d_counts, s);
     case MG_U16:
       return launch_roi<uint16_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
-                                             d_marker_local, grid, roi_len, d_labels, d_assay_offsets, bead_stride, d_halfwidths, max_r,
+                                             d_marker_local, grid, roi_len, d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r,
                                              d_roi, d_fg, d_bg, d_sums, d_counts, s);
     case MG_F32:
       return launch_roi<float, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                                       grid, roi_len, d_labels, d_assay_offsets, bead_stride, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                                       grid, roi_len, d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r, d_roi, d_fg, d_bg,
                                        d_sums, d_counts, s);
     case MG_F64:
       return launch_roi<double, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                                        grid, roi_len, d_labels, d_assay_offsets, bead_stride, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                                        grid, roi_len, d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r, d_roi, d_fg, d_bg,
                                         d_sums, d_counts, s);
   }
   return MG_EINVAL;
@@ -542,11 +544,11 @@ extern "C" int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int6
                                             const int32_t* d_labels, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
                                             double* d_sums, int32_t* d_counts, void* stream) {
   return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, m, roi_len,
-                      d_labels, nullptr, 0, 0, 0, nullptr, 0, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
+                      d_labels, nullptr, 0, 0, 0, 0, nullptr, 0, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
 }
 
 extern "C" int mg_roi_segment_reduce(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h,
-                                     int w, const int32_t* d_beads, int64_t bead_stride,
+                                     int w, int time_major, const int32_t* d_beads, int64_t bead_stride,
                                      const int32_t* d_assay_offsets, int n_assays, int max_per_assay, int m, int roi_len,
                                      const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
                                      double* d_sums, int32_t* d_counts, void* stream) {
@@ -555,8 +557,8 @@ extern "C" int mg_roi_segment_reduce(const void* d_image, int dtype, int64_t ass
     return MG_EINVAL;
   if (max_per_assay == 0) return MG_OK;
   return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, nullptr, nullptr, m, roi_len, nullptr,
-                      d_assay_offsets, bead_stride, n_assays, max_per_assay, d_halfwidths, max_r, d_roi, d_fg, d_bg, d_sums,
-                      d_counts, stream);
+                      d_assay_offsets, bead_stride, time_major, n_assays, max_per_assay, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                      d_sums, d_counts, stream);
 }
 
 extern "C" int mg_roi_gather_reduce(const void* d_image, int dtype, int n_c, int n_t, int h, int w,

@@ -659,8 +659,9 @@ def release_labels(labels):
 
 def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, labels: torch.Tensor | None,
                       want_roi=True, want_masks=True, want_sums=True, reuse_buffers=False, disks=False,
-                      device_tables=None):
-    """images (A, C, T, h, w); centers_per_assay: list of (M_a, >=2) int arrays [row, col, ...].
+                      device_tables=None, time_major=False):
+    """images (A, C, T, h, w) -- or, with ``time_major`` (and ``disks``), (A, T, C, h, w): the outputs
+    are (channel, time)-ordered either way; centers_per_assay: list of (M_a, >=2) int arrays [row, col, ...].
 
     Masks: from the ``labels`` map (utils.circle_labels) or, with ``disks=True`` and (M_a, 3) bead
     tables [row, col, r], straight from the bead geometry (same result, no label map at all).
@@ -673,7 +674,12 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
     [fg sum, bg sum], counts (M, 2) int32, offsets (A+1,) numpy.  ``reuse_buffers`` returns views of
     pooled buffers that the next call overwrites (steady-state streaming use)."""
     require_gpu()
-    a, c, t, h, w = images.shape
+    if time_major:
+        if not disks:
+            raise ValueError("time_major needs the bead-table masks (disks=True)")
+        a, t, c, h, w = images.shape
+    else:
+        a, c, t, h, w = images.shape
     images = images.contiguous()
     dev = images.device
     sizes = [int(n) for n in device_tables[1]] if device_tables is not None else [len(b) for b in centers_per_assay]
@@ -696,7 +702,7 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         tab = _halfwidth_table(max_r, dev)
         d_off = torch.from_numpy(offsets.astype(np.int32)).to(dev, non_blocking=True)
         _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
-              d_tab.data_ptr(), d_tab.shape[1], d_off.data_ptr(), a, int(max(sizes)), m, L, tab.data_ptr(), max_r,
+              int(time_major), d_tab.data_ptr(), d_tab.shape[1], d_off.data_ptr(), a, int(max(sizes)), m, L, tab.data_ptr(), max_r,
               _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
         return res
     beads = np.zeros((m, 3), dtype=np.int32)
@@ -715,7 +721,7 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         tab = _halfwidth_table(max_r, dev)
         d_off = torch.from_numpy(offsets.astype(np.int32)).to(dev)
         _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
-              d_beads.data_ptr(), 0, d_off.data_ptr(), a, int(max(sizes)), m, L, tab.data_ptr(), max_r,
+              int(time_major), d_beads.data_ptr(), 0, d_off.data_ptr(), a, int(max(sizes)), m, L, tab.data_ptr(), max_r,
               _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
         return res
     d_assay = torch.from_numpy(assay).to(dev)

@@ -156,12 +156,13 @@ class StackProcessor:
     def segment_reduce(self, beads, want_roi=True):
         """fg/bg masks, ROI gather and masked sums for every marker (find.py:561-602)."""
         T, C, h, w = self.T, self.C, self.h, self.w
-        if self.mode == "P":
-            images = self.image.view(T, C, 1, h, w)
-        else:
-            images = self.image.permute(1, 0, 2, 3).contiguous().view(1, C, T, h, w)
         # masks straight from the bead tables (mg_roi_segment_reduce): no label map is written or read
-        return hp.roi_gather_reduce(images, beads, self.L, None, want_roi=want_roi, reuse_buffers=True, disks=True)
+        if self.mode == "P":
+            return hp.roi_gather_reduce(self.image.view(T, C, 1, h, w), beads, self.L, None, want_roi=want_roi,
+                                        reuse_buffers=True, disks=True)
+        # mode R: one assay whose image block is stored (T, C, h, w); gathered in place (time_major)
+        return hp.roi_gather_reduce(self.image.view(1, T, C, h, w), beads, self.L, None, want_roi=want_roi,
+                                    reuse_buffers=True, disks=True, time_major=True)
 
     def __call__(self, stack, flatfield=1.0, darkfield=0.0, seed=0, want_roi=True):
         if self.n_streams > 1 and self.mode == "P":
