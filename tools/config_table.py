@@ -100,12 +100,34 @@ def chip_config(args):
     want_y = pitch * (np.arange(n)[:, None] + 1) - clip
     err = float(max(np.abs(x - want_x).max(), np.abs(y - want_y).max()))
     px = 64 * ty * ty
-    return {"config": "C3", "shape": [8, 8, ty, ty], "stitched": [side, side], "num_iter": args.num_iter, "markers": n * n,
-            "max_centre_error_px": err, "gpu_ms_device_resident": 1e3 * t_dev, "gpu_MPs": px / t_dev / 1e6,
-            "gpu_markers_per_s": n * n / t_dev, "gpu_ms_from_host_arrays": 1e3 * t_host,
-            "gpu_MPs_from_host_arrays": px / t_host / 1e6,
-            "cpu": "not timed: the chip path exists in the oracle only as the NumPy restatement, compared at test scale "
-                   "(tests/test_gpu_chip_api.py)"}
+    rec = {"config": "C3", "shape": [8, 8, ty, ty], "stitched": [side, side], "num_iter": args.num_iter, "markers": n * n,
+           "max_centre_error_px": err, "gpu_ms_device_resident": 1e3 * t_dev, "gpu_MPs": px / t_dev / 1e6,
+           "gpu_markers_per_s": n * n / t_dev, "gpu_ms_from_host_arrays": 1e3 * t_host,
+           "gpu_MPs_from_host_arrays": px / t_host / 1e6}
+    if not args.no_cpu:
+        # the oracle's restatement of the chip path (stitch, flat-field, find_centers, find_rois) with its C port
+        # as the circle search; same RNG streams as the GPU call (magnify_amd.utils.next_seed: 1st and 2nd draw)
+        from oracle import cport
+        from oracle import ref_pipeline as rp
+
+        def c_find_circles(img_u8, low_q, high_q, grid, num_iter, min_r, max_r, min_roundness, min_dist, seed=0, **_):
+            return cport.find_circles(img_u8, low_q, high_q, grid, num_iter, min_r, max_r, min_roundness, min_dist, seed=seed)
+
+        rp.find_circles = c_find_circles
+        k = 0x632BE59BD9B4E019
+        s1, s2 = (3000 + k) & 0xFFFFFFFFFFFFFFFF, (3000 + 2 * k) & 0xFFFFFFFFFFFFFFFF
+        tag = np.full((n, n), "default", dtype="<U200")
+        t0 = time.perf_counter()
+        img = rp.stitch(rp.flatfield_correct(tiles[None, None], 1.0, 0.0), overlap)[0, 0]
+        min_r, max_r, chamber_r, L = rp.button_params(8, 30, 60)
+        ox, oy = rp.find_centers(img[None], tag, pitch, pitch, min_r, max_r, chamber_r, 0.1, 0.9, args.num_iter, 0.2, 50, seed=s1)
+        _, _, _, x_o, y_o = rp.find_rois(img[None], ox, oy, tag, [0], min_r, max_r, chamber_r, L, 0.1, args.num_iter, 0.2, seed=s2)
+        t_cpu = time.perf_counter() - t0
+        rec.update({"cpu_ms": 1e3 * t_cpu, "cpu_MPs": px / t_cpu / 1e6, "cpu_markers_per_s": n * n / t_cpu, "cpu_threads": 1,
+                    "cpu_kind": "NumPy restatement of stitch / flat-field / grid fit / refinement with the C port "
+                                "(oracle/c/ref_port.c) as its circle search",
+                    "same_xy_as_gpu": bool(np.allclose(x, x_o, rtol=0, atol=1e-9) and np.allclose(y, y_o, rtol=0, atol=1e-9))})
+    return rec
 
 
 def main():
