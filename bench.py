@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--cpu-assays-per-core", type=int, default=2)
     ap.add_argument("--from-host", action="store_true",
                     help="the stack starts every step in pinned HOST memory (PCIe-inclusive rate; not the headline)")
+    ap.add_argument("--noiseless", action="store_true",
+                    help="the reference tests' kind of image: zero background, beads of value 1000 (not the headline)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-stream pass")
     args = ap.parse_args()
@@ -178,7 +180,7 @@ def main():
     dev = torch.device("cuda", local)
     T, C, S = args.timepoints, args.channels, args.size
 
-    stack, truth = synthetic_stack(T, C, S, S, seed=4000 + 100 * rank, device=dev)
+    stack, truth = synthetic_stack(T, C, S, S, seed=4000 + 100 * rank, device=dev, noiseless=args.noiseless)
     flat_np = vignette((S, S))
     flat = torch.from_numpy(flat_np).to(dev)
     proc = StackProcessor(T, C, S, S, num_iter=args.num_iter, min_bead_diameter=10, max_bead_diameter=50,
@@ -278,7 +280,8 @@ def main():
             "metric": "megapixels/sec through flatfield+segment+ROI-reduce; markers/sec",
             "value": mp_total / (dt / args.steps), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u16", "data": "synthetic" + (" (host-resident, PCIe-inclusive)" if args.from_host else ""),
+            "vs_baseline": None, "dtype": "u16",
+            "data": "synthetic" + (" noiseless" if args.noiseless else "") + (" (host-resident, PCIe-inclusive)" if args.from_host else ""),
             "config": {"workload": f"C4: {T} timepoints x {C} ch x {S}x{S} uint16 per GPU, mode P (per-timepoint "
                                    f"detection), search channel 0, num_iter={args.num_iter}, vignette flat-field, "
                                    f"dark=100, roi_length={proc.L}",

@@ -209,10 +209,13 @@ def dedup_against(seen: np.ndarray, new: np.ndarray, radius: float) -> np.ndarra
 # --------------------------------------------------------------------------------------
 
 
-def synthetic_stack(n_t, n_c, h, w, beads_per_mpx=120.0, seed=4000, r_lo=8, r_hi=20, jitter=2, device="cuda"):
+def synthetic_stack(n_t, n_c, h, w, beads_per_mpx=120.0, seed=4000, r_lo=8, r_hi=20, jitter=2, device="cuda",
+                    noiseless=False):
     """uint16 stack (T, C, H, W): background 100 + Poisson(20) + N(0, 3) read noise, filled-disk
     beads (the reference's filled_circle_points pixel sets) of radius U{8..20}, per-channel value
     U{500..4000}, non-overlapping, jittered by +-``jitter`` px per timepoint.
+    ``noiseless``: zero background and bead value 1000, as in the reference's own tests (both Canny
+    quantiles degenerate to 0 there).
     Returns (stack, truth) with truth (n_beads, 3) [row, col, r] of timepoint 0."""
     from . import _native as nat
 
@@ -248,8 +251,12 @@ def synthetic_stack(n_t, n_c, h, w, beads_per_mpx=120.0, seed=4000, r_lo=8, r_hi
         d_idx = torch.from_numpy(flat_idx).to(device)
         for c in range(n_c):
             values = rng.integers(500, 4001, n_beads).astype(np.float32)
-            plane = 100.0 + torch.poisson(torch.full((h * w,), 20.0, device=device), generator=gen)
-            plane += torch.randn((h * w,), device=device, generator=gen) * 3.0
+            if noiseless:
+                values[:] = 1000.0
+                plane = torch.zeros((h * w,), device=device)
+            else:
+                plane = 100.0 + torch.poisson(torch.full((h * w,), 20.0, device=device), generator=gen)
+                plane += torch.randn((h * w,), device=device, generator=gen) * 3.0
             if n_beads:
                 plane.index_add_(0, d_idx, torch.from_numpy(values[owner]).to(device))
             plane = torch.clamp(torch.round(plane), 0, 32767).to(torch.int16)
