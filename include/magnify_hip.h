@@ -243,13 +243,17 @@ int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, int n_planes,
  * Input, one of: (a) d_unique_keys + d_tile_ranges from mg_keys_to_circles (d_layer_offsets unused):
  * the circles are decoded from the keys and d_circles[n_planes][circle_cap][3] is an OUTPUT, written
  * only at the positions of the circles that pass the threshold (all that suppression and the ordered
- * output read); (b) d_unique_keys == NULL: d_circles + d_layer_offsets from mg_bitmap_to_circles. */
+ * output read); (b) d_unique_keys == NULL: d_circles + d_layer_offsets from mg_bitmap_to_circles.
+ * dedup_centres != 0 (only when greedy suppression with min_dist > 0 follows): of the passing circles that
+ * share a centre, only the first in suppression order (score desc, radius asc) is appended to d_alive --
+ * the others have the same suppression ring and are rejected whatever happens to the first one
+ * (utils.py:254-292), so the kept set is unchanged; best effort per tile (64 parked circles). */
 int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, const uint32_t* d_class_bits,
                      int64_t words_per_plane, int n_planes, int h, int w, int32_t* d_circles, int64_t circle_cap,
                      const int32_t* d_layer_offsets, const uint32_t* d_unique_keys, const int32_t* d_tile_ranges,
                      int min_r, int max_r, const int32_t* d_per_rc, const double* d_per_expected,
                      const int32_t* d_per_starts, int per_total, float min_roundness, int write_skipped,
-                     float* d_scores, int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc,
+                     int dedup_centres, float* d_scores, int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc,
                      int32_t* d_num_scored, void* stream);
 
 /* One round of the parallel-but-equivalent greedy suppression of filter_neighbors

@@ -48,7 +48,7 @@ PROTOTYPES = {
     "mg_bitmap_to_circles": [_p, _l, _i, _i, _i, _i, _i, _p, _p, _l, _p, _p],
     "mg_edge_angles": [_p, _i, _i, _i, _p, _l, _p, _p, _p],
     "mg_dedup_layout": [_i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
-    "mg_score_circles": [_p, _p, _p, _l, _i, _i, _i, _p, _l, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _i, _p, _p, _p, _p, _p, _p],
+    "mg_score_circles": [_p, _p, _p, _l, _i, _i, _i, _p, _l, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _i, _i, _p, _p, _p, _p, _p, _p],
     "mg_nms_round": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _p, _l, _p],
     "mg_collect_circles": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p],
     "mg_circle_labels": [_p, _l, _p, _i, _i, _i, _p, _i, _p, _i, _p],

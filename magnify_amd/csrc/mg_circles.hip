@@ -430,11 +430,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(96))) void k_sco
                                                     const int32_t* __restrict__ d_per_rc, int per_total,
                                                     const double* __restrict__ d_per_expected,
                                                     const int32_t* __restrict__ d_per_starts, float min_roundness,
-                                                    int write_skipped, float* __restrict__ d_scores,
+                                                    int write_skipped, int dedup_centres,
+                                                    float* __restrict__ d_scores,
                                                     int32_t* __restrict__ d_alive, int32_t* __restrict__ d_num_alive,
                                                     int32_t* __restrict__ d_max_rc, int32_t* __restrict__ d_num_scored) {
   extern __shared__ uint32_t lds[];
-  __shared__ int n_surv;
+  __shared__ int n_surv, n_pass;
   const int plane = blockIdx.y, tile = blockIdx.x;
   int64_t first, last;
   if (KEYED) {
@@ -508,6 +509,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(96))) void k_sco
   } else {                                                                  \
     row = circles[3 * (i)], col = circles[3 * (i) + 1], rad = circles[3 * (i) + 2]; \
   }
+#define MG_PASS(i, row, col, rad)                                                        \
+  {                                                                                      \
+    const int k_ = atomicAdd(&d_num_alive[plane], 1);                                    \
+    d_alive[(int64_t)plane * circle_cap + k_] = (int32_t)(i);                            \
+    if (KEYED) circles[3 * (i)] = (row), circles[3 * (i) + 1] = (col), circles[3 * (i) + 2] = (rad); \
+    atomicMax(&d_max_rc[2 * plane], (row));                                              \
+    atomicMax(&d_max_rc[2 * plane + 1], (col));                                          \
+  }
   const float* ang = d_angle + (int64_t)plane * h * w;
   float* scores = d_scores + (int64_t)plane * circle_cap;
   const double PI = 3.141592653589793, INV_PI = 1.0 / 3.141592653589793;
@@ -515,6 +524,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(96))) void k_sco
   // done), then the exact pass over the list -- with few survivors per batch the exact pass would
   // otherwise run on mostly idle waves.
   constexpr int BATCH = 2 * NT;
+  // dedup_centres: circles that pass are parked in the top PASS_CAP x 3 words of `list` until the tile is
+  // done; of those that share a centre only the first in suppression order goes on (see the end)
+  constexpr int PASS_CAP = 64, SURV_ROOM = CHUNK - 3 * PASS_CAP;
+  if (threadIdx.x == 0) n_pass = 0;
   for (int64_t chunk = first; chunk < last;) {
     if (threadIdx.x == 0) n_surv = 0;
     __syncthreads();
@@ -560,7 +573,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(96))) void k_sco
       pos += BATCH;
       __syncthreads();
       const int so_far = n_surv;
-      if (pos >= last || so_far > CHUNK - BATCH || pos - chunk > (1 << SURV_IDX_BITS) - BATCH) break;
+      if (pos >= last || so_far > SURV_ROOM - BATCH || pos - chunk > (1 << SURV_IDX_BITS) - BATCH) break;
       __syncthreads();  // everyone has read the count before the next batch adds to it
     }
     const int ns = n_surv;
@@ -634,15 +647,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(96))) void k_sco
       const float score = (float)acc / (float)(p1 - p0);
       scores[i] = score;
       if (score >= min_roundness) {
-        const int k = atomicAdd(&d_num_alive[plane], 1);
-        d_alive[(int64_t)plane * circle_cap + k] = (int32_t)i;
-        if (KEYED) circles[3 * i] = row, circles[3 * i + 1] = col, circles[3 * i + 2] = rad;
-        atomicMax(&d_max_rc[2 * plane], row);
-        atomicMax(&d_max_rc[2 * plane + 1], col);
+        const int slot = dedup_centres ? atomicAdd(&n_pass, 1) : PASS_CAP;
+        if (slot < PASS_CAP) {
+          list[CHUNK - 1 - 3 * slot] = (int32_t)(i - first);
+          list[CHUNK - 2 - 3 * slot] = __float_as_int(score);
+          list[CHUNK - 3 - 3 * slot] = (rad << 12) | ((row - trow0) << 6) | (col - tcol0);
+        } else {  // no room (or no de-duplication wanted): straight to the plane's list
+          MG_PASS(i, row, col, rad)
+        }
       }
     }
     __syncthreads();
     chunk = pos;
+  }
+  // Circles with one centre have one suppression ring (it only depends on the centre and min_dist), so
+  // whatever the first of them in (score desc, radius asc) order does -- claim the ring, or fail on a cell
+  // that is already claimed -- leaves every later one rejected: they can be dropped here, and on clean
+  // images (many radii pass per bead) most of the suppression's bids go with them.
+  const int np = min(n_pass, PASS_CAP);
+  for (int a = threadIdx.x; a < np; a += NT) {
+    const int code = list[CHUNK - 3 - 3 * a];
+    const float score = __int_as_float(list[CHUNK - 2 - 3 * a]);
+    bool first_at_centre = true;
+    for (int b = 0; b < np; ++b) {
+      const int code_b = list[CHUNK - 3 - 3 * b];
+      const float score_b = __int_as_float(list[CHUNK - 2 - 3 * b]);
+      if (((code ^ code_b) & 0xFFF) == 0 && (score_b > score || (score_b == score && code_b < code))) first_at_centre = false;
+    }
+    if (first_at_centre) {
+      const int64_t i = first + list[CHUNK - 1 - 3 * a];
+      MG_PASS(i, trow0 + ((code >> 6) & 63), tcol0 + (code & 63), code >> 12)
+    }
   }
 }
 
@@ -650,6 +685,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(96))) void k_sco
 #undef MG_TAB_DC
 #undef MG_TAB_Q
 #undef MG_CIRCLE
+#undef MG_PASS
 
 // ---- K10: greedy suppression in parallel rounds ------------------------------------------------------
 // Priority key: smaller = earlier in the reference's score-descending order; ties broken by the
@@ -945,8 +981,9 @@ extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bit
                                 int64_t circle_cap, const int32_t* d_layer_offsets, const uint32_t* d_unique_keys,
                                 const int32_t* d_tile_ranges, int min_r, int max_r, const int32_t* d_per_rc,
                                 const double* d_per_expected, const int32_t* d_per_starts, int per_total,
-                                float min_roundness, int write_skipped, float* d_scores, int32_t* d_alive,
-                                int32_t* d_num_alive, int32_t* d_max_rc, int32_t* d_num_scored, void* stream) {
+                                float min_roundness, int write_skipped, int dedup_centres, float* d_scores,
+                                int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc, int32_t* d_num_scored,
+                                void* stream) {
   if (!d_angle || !d_edge_bits || !d_circles || !d_per_rc || !d_per_expected || !d_per_starts || !d_scores ||
       !d_alive || !d_num_alive || !d_max_rc)
     return MG_EINVAL;
@@ -978,7 +1015,8 @@ extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bit
   hipLaunchKernelGGL(kernel, dim3(ntr * ntc, n_planes), dim3(NT), lds_bytes, mg_stream(stream), d_angle, d_edge_bits,
                      d_class_bits, words_per_plane, h, w, d_circles, circle_cap, d_layer_offsets, d_unique_keys,
                      d_tile_ranges, ntr * ntc, (int)n_layers, max_r - min_r + 1, ntc, min_r, max_r, d_per_rc, per_total,
-                     d_per_expected, d_per_starts, min_roundness, write_skipped, d_scores, d_alive, d_num_alive,
+                     d_per_expected, d_per_starts, min_roundness, write_skipped, dedup_centres, d_scores, d_alive,
+                     d_num_alive,
                      d_max_rc, d_num_scored);
   MG_CHECK_LAUNCH();
   return MG_OK;

@@ -445,7 +445,7 @@ class CircleFinder:
         return n_edges
 
     # -- stage 2: candidates -> unique integer circles -> scores ------------------------------
-    def circle_stage(self, seeds, min_roundness: float, keep_raw=False):
+    def circle_stage(self, seeds, min_roundness: float, keep_raw=False, dedup_centres=False):
         L, P, h, w, s = nat.lib(), self.P, self.h, self.w, _stream()
         seeds = np.asarray(seeds, dtype=np.uint64).reshape(P)
         self.seeds.copy_(torch.from_numpy(seeds.view(np.int64)))
@@ -479,7 +479,8 @@ class CircleFinder:
               self.circles.data_ptr(), self.cap, _ptr(self.layer_offsets), _ptr(self._tie_keys),
               _ptr(self.tile_ranges if self._tie_keys is not None else None), self.min_r, self.max_r,
               self.per_rc.data_ptr(), self.per_exp.data_ptr(), self.per_starts.data_ptr(), int(self.per_rc.shape[0]),
-              float(min_roundness), int(self.keep_debug_maps), self.scores.data_ptr(), self.alive.data_ptr(),
+              float(min_roundness), int(self.keep_debug_maps), int(dedup_centres), self.scores.data_ptr(),
+              self.alive.data_ptr(),
               self.num_alive.data_ptr(), self.max_rc.data_ptr(), self.num_scored.data_ptr(), s)
 
     # -- stage 3: greedy suppression + ordered output -------------------------------------------
@@ -551,7 +552,8 @@ class CircleFinder:
         counts come back -- (counts, (out, out_scores, num_out)); ``fetch_results`` copies the lists
         later (e.g. after the ROI pass, which reads the tables on the device, has been launched)."""
         n_edges = self.edge_stage(planes, minmax, low_q, high_q, keep_u8=keep_u8, passthrough_u8=passthrough_u8)
-        self.circle_stage(seeds, min_roundness, keep_raw=keep_raw)
+        # with suppression to follow, passing circles that share a centre are reduced to their first
+        self.circle_stage(seeds, min_roundness, keep_raw=keep_raw, dedup_centres=min_dist > 0)
         out, out_scores, num_out = self.nms_stage(min_dist)
         counts = self._out_counts  # came back with the suppression's convergence check
         self.stats["n_edges"] = n_edges
