@@ -172,3 +172,45 @@ class Reader:
     @registry.readers.register("read")
     def make():
         return Reader()
+
+
+def iter_time_chunks(pattern, chunk: int, pinned: bool = False):
+    """Streamed ingest of a time series too large to hold: the files behind
+    ``pattern`` -- one 2-D page per (channel, time), groups ``(channel)`` and ``(time|format)`` as in
+    ``extract_paths`` -- are read ``chunk`` timepoints at a time, in time order, never all at once.
+    Yields ``(time_values, channels, block)`` with ``block`` a (T_chunk, C, H, W) array of the files'
+    dtype: a NumPy array, or with ``pinned`` a page-locked torch tensor ready for an asynchronous upload.
+    Tiled files (``(row)`` / ``(col)`` groups) and several assays per pattern are not streamed: use
+    ``Reader``."""
+    path_dict, _ = extract_paths(os.fspath(pattern), assay="str", channel="str", time="time", row="int", col="int")
+    if len(path_dict) == 0:
+        raise FileNotFoundError(f"The pattern {pattern} did not lead to any files.")
+    if any(k[0] is not None or k[3] is not None or k[4] is not None for k in path_dict):
+        raise ValueError("iter_time_chunks streams single-tile, single-assay series only")
+    if any(k[2] is None for k in path_dict):
+        raise ValueError("the pattern needs a (time) group")
+    channels = sorted({k[1] for k in path_dict}, key=lambda c: (c is None, c))
+    times = sorted({k[2] for k in path_dict})
+    first, _, _ = _open_tiff(path_dict[(None, channels[0], times[0], None, None)])
+    h, w = first[0].shape[:2]
+    dtype = first[0].dtype
+    for lo in range(0, len(times), int(chunk)):
+        part = times[lo: lo + int(chunk)]
+        if pinned:
+            import torch
+
+            block_t = torch.empty((len(part), len(channels), h, w), dtype=torch.from_numpy(np.empty(0, dtype)).dtype).pin_memory()
+            block = block_t.numpy()
+        else:
+            block = np.empty((len(part), len(channels), h, w), dtype=dtype)
+        for i, t in enumerate(part):
+            for j, c in enumerate(channels):
+                key = (None, c, t, None, None)
+                if key not in path_dict:
+                    raise FileNotFoundError(f"no file for channel {c!r} at time {t}")
+                pages, in_file, _ = _open_tiff(path_dict[key])
+                if in_file or pages[0].shape[:2] != (h, w):
+                    raise ValueError(f"{path_dict[key]}: expected one {h} x {w} page")
+                block[i, j] = pages[0]
+        stamps = [int(t.timestamp()) if isinstance(t, datetime.datetime) else t for t in part]
+        yield stamps, [c for c in channels], (block_t if pinned else block)

@@ -195,6 +195,55 @@ class StackProcessor:
         return out
 
 
+def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False, prefetch=2, **processor_kwargs):
+    """Mode-P processing of a time series that arrives chunk by chunk (config C5: ``reader.iter_time_chunks``
+    or any iterator of (T_chunk, C, H, W) blocks, optionally wrapped as (time_values, channels, block)).
+    A reader thread keeps ``prefetch`` chunks ahead, so decoding files overlaps the GPU's work on the chunk
+    before; inside a chunk the upload overlaps compute when ``n_streams > 1`` is passed on.  Every
+    timepoint is its own assay, and its RNG stream only depends on its global index: the results equal
+    those of the whole stack in one ``StackProcessor`` call, whatever the chunk size.
+    Yields one result dict per chunk (as ``StackProcessor.__call__``, plus ``first_timepoint``); ROI pixel
+    stacks / masks (``want_roi``) are views of pooled buffers that the next chunk overwrites."""
+    import queue
+    import threading
+
+    q = queue.Queue(maxsize=max(1, int(prefetch)))
+    stop = object()
+
+    def produce():
+        try:
+            for item in chunks:
+                q.put(item)
+            q.put(stop)
+        except BaseException as exc:  # surfaces in the consumer
+            q.put(exc)
+
+    threading.Thread(target=produce, daemon=True).start()
+    procs, done = {}, 0
+    while True:
+        item = q.get()
+        if item is stop:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        block = item[-1] if isinstance(item, tuple) else item
+        if not isinstance(block, torch.Tensor):
+            block = torch.from_numpy(np.ascontiguousarray(block))
+        t, c, h, w = block.shape
+        key = (t, c, h, w, block.dtype)
+        if key not in procs:  # a shorter last chunk gets its own workspaces
+            procs[key] = StackProcessor(t, c, h, w, dtype=block.dtype, mode="P", **processor_kwargs)
+        out = procs[key](block, flatfield, darkfield, seed=(seed + 1000003 * done) & 0xFFFFFFFFFFFFFFFF, want_roi=want_roi)
+        out["first_timepoint"] = done
+        for k in ("sums", "counts"):  # small; the pooled buffers behind them are reused by the next chunk
+            if out.get(k) is not None:
+                out[k] = out[k].clone()
+        if isinstance(item, tuple) and len(item) == 3:
+            out["time"], out["channel"] = item[0], item[1]
+        done += t
+        yield out
+
+
 def dedup_against(seen: np.ndarray, new: np.ndarray, radius: float) -> np.ndarray:
     """Cross-channel de-duplication (find.py:490-500): drop new beads that have an earlier bead
     within ``radius`` (Euclidean, inclusive, as KDTree.query_ball_point)."""

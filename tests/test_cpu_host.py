@@ -373,3 +373,32 @@ def test_perimeter_table_structure_for_orientation_windows():
             x, y = int(body[-4][0]), int(body[-4][1])
             assert abs(x) == abs(y)
             assert sorted([(x, y), (-x, -y), (-x, y), (x, -y)]) == sorted(tuple(int(v) for v in p) for p in body[-4:])
+
+
+def test_reader_streams_time_chunks(tmp_path):
+    """reader.iter_time_chunks (config C5 / SURVEY 8f N2): a (channel, time) series comes back chunk by
+    chunk in time order, without the whole stack ever being held."""
+    from magnify_amd import reader
+
+    rng = np.random.default_rng(5)
+    days = ["20240101", "20240103", "20240102", "20240110", "20240107"]
+    truth = {}
+    for day in days:
+        for ch in ("b", "a"):
+            truth[ch, day] = rng.integers(0, 60000, (6, 9)).astype(np.uint16)
+            _write_tiff(tmp_path / f"s_{ch}_{day}.tif", truth[ch, day])
+    pattern = str(tmp_path / "s_(channel)_(time|%Y%m%d).tif")
+    chunks = list(reader.iter_time_chunks(pattern, 2))
+    assert [c[2].shape for c in chunks] == [(2, 2, 6, 9), (2, 2, 6, 9), (1, 2, 6, 9)]
+    assert all(c[1] == ["a", "b"] and c[2].dtype == np.uint16 for c in chunks)
+    order = sorted(days)
+    stamps = [t for c in chunks for t in c[0]]
+    assert stamps == sorted(stamps) and len(stamps) == 5
+    for k, day in enumerate(order):
+        block = chunks[k // 2][2][k % 2]
+        np.testing.assert_array_equal(block[0], truth["a", day])
+        np.testing.assert_array_equal(block[1], truth["b", day])
+    with pytest.raises(FileNotFoundError):
+        next(reader.iter_time_chunks(str(tmp_path / "none_(channel)_(time|%Y%m%d).tif"), 2))
+    with pytest.raises(ValueError):  # no time group
+        next(reader.iter_time_chunks(str(tmp_path / "s_(channel)_20240101.tif"), 2))

@@ -240,3 +240,36 @@ def test_public_api_c2_matches_c_oracle(mg):
     np.testing.assert_array_equal(np.asarray(xp.roi.values).reshape(want["roi"].shape), want["roi"])
     np.testing.assert_array_equal(np.asarray(xp.fg.values).reshape(want["fg"].shape), want["fg"])
     np.testing.assert_array_equal(np.asarray(xp.bg.values).reshape(want["bg"].shape), want["bg"])
+
+
+def test_streamed_series_equals_whole_stack(mg, tmp_path):
+    """Config C5's path at small scale: TIFF files -> reader.iter_time_chunks -> stack.process_stream
+    (reader thread ahead of the GPU) gives, chunk by chunk, exactly what one StackProcessor call gives on
+    the whole stack -- whatever the chunk size."""
+    from PIL import Image
+
+    from magnify_amd import reader
+    from magnify_amd.stack import StackProcessor, process_stream, synthetic_stack
+
+    T, C, S = 7, 2, 320
+    stack, _ = synthetic_stack(T, C, S, S, seed=515)
+    host = stack.cpu().numpy()
+    for t in range(T):
+        for c in range(C):
+            Image.fromarray(host[t, c]).save(tmp_path / f"x_ch{c}_202401{t + 10}.tif")
+    kw = dict(num_iter=60000, search_channels=(0,))
+    whole = StackProcessor(T, C, S, S, mode="P", **kw)(stack, 0.9, 90.0, seed=21)
+    whole_sums = whole["sums"].cpu().numpy()  # a view of a pooled buffer: the next processor call reuses it
+    pattern = str(tmp_path / "x_(channel)_(time|%Y%m%d).tif")
+    for chunk in (3, 7, 2):
+        got_beads, got_sums, firsts = [], [], []
+        for out in process_stream(reader.iter_time_chunks(pattern, chunk, pinned=True), 0.9, 90.0, seed=21, **kw):
+            assert out["channel"] == ["ch0", "ch1"]
+            got_beads += out["beads"]
+            got_sums.append(out["sums"].cpu().numpy())
+            firsts.append(out["first_timepoint"])
+        assert firsts == list(range(0, T, chunk)) and len(got_beads) == T
+        for a, b in zip(got_beads, whole["beads"]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(np.concatenate(got_sums), whole_sums)
+    assert sum(len(b) for b in whole["beads"]) > 30
