@@ -2,9 +2,10 @@
 GPU, with the oracle's C restatement timed beside it on the host for the bead configs (SURVEY 8d:
 "report MP/s and markers/s for C1-C3 in full").  C4 is bench.py's workload.
 
-    python tools/config_table.py [--out gpurun_out/configs.json] [--num-iter 5000000] [--no-cpu]
+    python tests/config_table.py [--out gpurun_out/configs.json] [--num-iter 5000000] [--no-cpu]
 
-Prints one JSON object per config; writes the list to --out.  Test infrastructure (imports oracle/).
+Prints one JSON object per config; writes the list to --out.  Test infrastructure: it lives under tests/
+because it times and checks against oracle/ (which only tests/, smoke() and bench.py's cpu_baseline may use).
 """
 import argparse
 import json
@@ -17,7 +18,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # synth.py
 
 import magnify_amd as mg  # noqa: E402
 from magnify_amd import utils as mg_utils  # noqa: E402
