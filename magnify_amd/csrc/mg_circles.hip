@@ -748,9 +748,26 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
       }
       state[idx] = 0;
     } else if (PHASE == 0) {  // claim: every undecided circle bids for its ring pixels
-      for (int j = 0; j < ring_len; ++j) {
-        const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
-        atomicMin(reinterpret_cast<unsigned long long*>(&grid[(int64_t)rr * n_cols + cc]), (unsigned long long)key);
+      // a cell that already holds a smaller key cannot be won (cells only ever decrease during the bids):
+      // look first, eight cells at a time, and spare the memory-side atomic for those
+      constexpr int RB = 8;
+      for (int j0 = 0; j0 < ring_len; j0 += RB) {
+        uint64_t* cell[RB];
+        uint64_t cur[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          cell[u] = nullptr;
+          cur[u] = 0;
+          if (j0 + u < ring_len) {
+            const int rr = wrap(d_ring_rc[2 * (j0 + u)] + row + pad, n_rows);
+            const int cc = wrap(d_ring_rc[2 * (j0 + u) + 1] + col + pad, n_cols);
+            cell[u] = &grid[(int64_t)rr * n_cols + cc];
+            cur[u] = __builtin_nontemporal_load(cell[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+          if (cell[u] && cur[u] > key) atomicMin(reinterpret_cast<unsigned long long*>(cell[u]), (unsigned long long)key);
       }
     } else {  // decide
       bool all_mine = true, hit_kept = false;
