@@ -402,3 +402,35 @@ def test_reader_streams_time_chunks(tmp_path):
         next(reader.iter_time_chunks(str(tmp_path / "none_(channel)_(time|%Y%m%d).tif"), 2))
     with pytest.raises(ValueError):  # no time group
         next(reader.iter_time_chunks(str(tmp_path / "s_(channel)_20240101.tif"), 2))
+
+
+def test_mrbles_code_assignment_matches_loop_restatement():
+    """identify.py:88-234 (code assignment of identify_mrbles): the vectorised lattice fit + EM of
+    magnify_amd.identify.assign_codes against the oracle's statement-by-statement loops, on synthetic
+    lanthanide ratios -- 3 x 3 codes in two ratio dimensions, unequal code populations, a few outliers."""
+    from magnify_amd.identify import _fit_levels, assign_codes
+    from oracle import ref_identify as ri
+
+    rng = np.random.default_rng(11)
+    levels = [np.array([0.1, 0.35, 0.8]), np.array([0.05, 0.3, 0.55])]
+    codes = np.array([[a, b] for a in levels[0] for b in levels[1]])
+    pops = rng.integers(12, 40, len(codes))
+    truth = np.repeat(np.arange(len(codes)), pops)
+    scale, shift = np.array([1.7, 0.9]), np.array([0.04, 0.02])
+    X = codes[truth] * scale + shift + rng.normal(0, 0.012, (len(truth), 2))
+    X = np.concatenate([X, rng.uniform(0, 1.6, (6, 2))])  # strays
+    ratios = np.column_stack([np.ones(len(X)), X])
+    # 1-D fit alone
+    for d in range(2):
+        lv, cnt = np.unique(codes[:, d], return_counts=True)
+        pts = np.sort(X[:, d])
+        a1, p1 = _fit_levels(pts, lv, cnt, 40)
+        a2, p2 = ri.fit_1d(pts, lv, cnt, 40)
+        assert (a1, p1) == pytest.approx((a2, p2), rel=0, abs=1e-12)
+    tags, A, p = assign_codes(ratios, codes, n_grid=40)
+    tags_o, A_o, p_o = ri.assign_codes(ratios, codes, n_grid=40)
+    np.testing.assert_allclose(A, A_o, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(p, p_o, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(tags, tags_o)
+    # and it decodes: nearly every clustered bead gets its code, most strays the outlier component
+    assert (tags[: len(truth)] == truth).mean() > 0.97

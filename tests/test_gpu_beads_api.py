@@ -208,6 +208,7 @@ def test_mrbles_front_half(mg, tmp_path):
     pipe.remove_pipe("restore_format")
     xp = pipe(arr(mg, data, ("channel", "y", "x"), channel=chans))
     assert list(xp.ln.values) == ["eu", "dy", "sm"]
+    assert xp.tag.dims == ("mark",) and set(xp.tag.values.tolist()) <= {"code0", "code1", "outlier"}  # identify.py:224-231
     m = xp.roi.sizes["mark"]
     assert m == len(pos) and xp.ln_vol.shape == (m, 3) and xp.ln_ratio.shape == (m, 3)
     # oracle: the same expression on the returned arrays
