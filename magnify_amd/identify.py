@@ -12,28 +12,24 @@ from . import registry
 
 @registry.component("identify_buttons")
 def identify_buttons(assay, shape=None, pinlist=None, blank=None):
-    if blank is None:
-        blank = ["", "blank", "BLANK"]
+    """identify.py:13-47: the (mark_row, mark_col) table of tags -- read from a pin list (columns
+    ``Indices`` = "(col, row)", 1-based, and ``MutantID``; names in ``blank`` become "") or, without one,
+    "default" everywhere on a chip of ``shape`` -- plus an all-true ``valid`` over (mark_row, mark_col, time)."""
+    blanks = ["", "blank", "BLANK"] if blank is None else blank
     if pinlist is not None:
         import pandas as pd
 
-        df = pd.read_csv(pinlist)
-        df["Indices"] = df["Indices"].apply(lambda s: [int(x) for x in re.sub(r"[\(\)]", "", s).split(",")])
-        df["MutantID"] = df["MutantID"].replace(blank, "")
-        cols, rows = np.array(df["Indices"].to_list()).T - 1
-        names = df["MutantID"].to_numpy(dtype=str, na_value="")
-        names_array = np.empty((max(rows) + 1, max(cols) + 1), dtype=names.dtype)
-        names_array[rows, cols] = names
+        table = pd.read_csv(pinlist)
+        where = np.array([[int(v) for v in re.findall(r"-?\d+", str(text))] for text in table["Indices"]]) - 1
+        labels = table["MutantID"].replace(blanks, "").to_numpy(dtype=str, na_value="")
+        tags = np.empty((where[:, 1].max() + 1, where[:, 0].max() + 1), dtype=labels.dtype)
+        tags[where[:, 1], where[:, 0]] = labels
     elif shape is not None:
-        names_array = np.empty((shape[0], shape[1]), dtype="<U200")
-        names_array.fill("default")
+        tags = np.full((shape[0], shape[1]), "default", dtype="<U200")
     else:
         raise ValueError("Either pinlist or shape must be provided.")
-    n_t = assay.sizes["time"]
-    return assay.assign_coords(
-        tag=(("mark_row", "mark_col"), names_array),
-        valid=(("mark_row", "mark_col", "time"), np.ones(names_array.shape + (n_t,), dtype=bool)),
-    )
+    alive = np.ones(tags.shape + (assay.sizes["time"],), dtype=bool)
+    return assay.assign_coords(tag=(("mark_row", "mark_col"), tags), valid=(("mark_row", "mark_col", "time"), alive))
 
 
 @registry.component("identify_mrbles")

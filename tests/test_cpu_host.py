@@ -434,3 +434,16 @@ def test_mrbles_code_assignment_matches_loop_restatement():
     np.testing.assert_array_equal(tags, tags_o)
     # and it decodes: nearly every clustered bead gets its code, most strays the outlier component
     assert (tags[: len(truth)] == truth).mean() > 0.97
+
+
+def test_identify_buttons_pinlist(tmp_path):
+    """identify.py:19-29: pin list rows "(col, row)" (1-based) -> tag[row, col]; blank names become ""."""
+    csv = tmp_path / "pins.csv"
+    csv.write_text('Indices,MutantID\n"(1,1)",wt\n"(2,1)",BLANK\n"(3,1)",m7\n"(1,2)",m2\n"(2,2)",blank\n"(3,2)",m9\n')
+    xp = mg.preprocess.standardize_format(mg.DataArray(np.zeros((2, 8, 8), np.uint16), ("time", "y", "x")))
+    xp = mg.identify.identify_buttons(xp, pinlist=str(csv))
+    assert xp.tag.shape == (2, 3)
+    assert xp.tag.values.tolist() == [["wt", "", "m7"], ["m2", "", "m9"]]
+    assert xp.valid.shape == (2, 3, 2) and xp.valid.values.all()
+    xp2 = mg.identify.identify_buttons(xp, pinlist=str(csv), blank=["wt"])
+    assert xp2.tag.values[0, 0] == "" and xp2.tag.values[0, 1] == "BLANK"
