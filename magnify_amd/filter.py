@@ -3,8 +3,8 @@
 ``filter_expression`` (filter.py:11-37) and ``filter_leaky`` (filter.py:65-94) only need the masked
 medians of the first timestep, which ``mg_roi_masked_median_u16`` computes on the gathered ROIs; the
 thresholding is the reference's own NumPy expression, evaluated on the (mark,) vectors on the host.
-``filter_nonround`` (filter.py:40-62) measures contours with cv.findContours / cv.arcLength and is
-not part of this build.
+``filter_nonround`` (filter.py:40-62) measures contours with cv.findContours / cv.arcLength: restated here
+as Moore border tracing of every connected component of the small fg masks, on the host.
 """
 from __future__ import annotations
 
@@ -79,7 +79,63 @@ def filter_leaky_buttons(assay, search_channel=None):
     return assay.assign_coords(valid=(var.dims, flat.reshape(valid.shape)))
 
 
+# 8-neighbourhood in clockwise order starting east (row, col steps) and the step lengths along it
+_RING = np.array([(0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1)])
+_STEP = np.array([1.0, np.sqrt(2.0)] * 4)
+
+
+def outer_border_length(blob: np.ndarray) -> float:
+    """Length of the closed outer border of ONE 8-connected component (``blob`` bool, component only),
+    followed through its border pixels' centres: what cv.findContours(RETR_EXTERNAL) + cv.arcLength(closed)
+    measure (collapsing straight runs, CHAIN_APPROX_SIMPLE, does not change the length).  Moore-neighbour
+    tracing from the component's first pixel in raster order, stopping when the start pixel is entered again
+    in the start direction.  A single pixel has length 0; a one-pixel-wide line is walked there and back."""
+    h, w = blob.shape
+    pad = np.zeros((h + 2, w + 2), dtype=bool)
+    pad[1:-1, 1:-1] = blob
+    ys, xs = np.nonzero(pad)
+    start = (int(ys[0]), int(xs[0]))  # raster-first pixel: its west and north neighbours are background
+    cur, came = start, 4              # pretend we arrived from the west
+    first_move = None
+    length = 0.0
+    for _ in range(4 * pad.size + 8):
+        for turn in range(1, 9):      # clockwise from the neighbour after the one we came from
+            d = (came + turn) % 8
+            nxt = (cur[0] + _RING[d][0], cur[1] + _RING[d][1])
+            if pad[nxt]:
+                break
+        else:
+            return 0.0                # isolated pixel
+        if cur == start and first_move is not None and d == first_move:
+            return length
+        if first_move is None:
+            first_move = d
+        length += _STEP[d]
+        cur, came = nxt, (d + 4) % 8
+    raise RuntimeError("border following did not close")
+
+
 @registry.component("filter_nonround")
 def filter_nonround(assay, min_roundness=0.75, search_channel=None):
-    raise NotImplementedError("filter_nonround needs OpenCV's contour tracing (cv.findContours / cv.arcLength); "
-                              "it is outside this build")
+    """filter.py:40-62: a marker stays valid only if its foreground mask (time 0) is round enough,
+    4 pi area / perimeter^2 > min_roundness, perimeter = total length of the outer borders of its connected
+    components; a mask without any border length (empty or single pixels) is invalid.  The masks are a few
+    thousand small images per assay: traced on the host.  PARITY UNPINNED (OpenCV is not available to check
+    the border lengths against; nested components, which RETR_EXTERNAL would skip, are counted)."""
+    import scipy.ndimage
+
+    _channel_indexes(assay, search_channel)  # validates the names like the other filters
+    fg = assay.coords["fg"] if "fg" in assay.coords else assay.data_vars["fg"]
+    masks = fg.transpose("mark", "time", "roi_y", "roi_x").data
+    masks = (masks[:, 0].cpu().numpy() if hasattr(masks, "cpu") else np.asarray(masks)[:, 0]).astype(bool)
+    var, valid = _valid_array(assay)
+    flat = valid.reshape(len(masks), -1)
+    eight = np.ones((3, 3), dtype=bool)
+    for i, mask in enumerate(masks):
+        labels, n = scipy.ndimage.label(mask, structure=eight)
+        perimeter = sum(outer_border_length(labels == k) for k in range(1, n + 1))
+        if perimeter == 0:
+            flat[i] = False
+            continue
+        flat[i] &= 4 * np.pi * float(mask.sum()) / perimeter**2 > min_roundness
+    return assay.assign_coords(valid=(var.dims, flat.reshape(valid.shape)))

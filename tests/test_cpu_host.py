@@ -447,3 +447,33 @@ def test_identify_buttons_pinlist(tmp_path):
     assert xp.valid.shape == (2, 3, 2) and xp.valid.values.all()
     xp2 = mg.identify.identify_buttons(xp, pinlist=str(csv), blank=["wt"])
     assert xp2.tag.values[0, 0] == "" and xp2.tag.values[0, 1] == "BLANK"
+
+
+def test_filter_nonround_border_lengths_and_component():
+    """filter.py:40-62: outer-border length of simple shapes (values cv.arcLength of cv.findContours' external
+    contours has for them: a filled s x s square 4 (s - 1), a one-pixel line there and back, a diagonal in
+    sqrt(2) steps) and the component on a small Dataset: round disks stay, a sliver and an empty mask go."""
+    from magnify_amd.filter import outer_border_length
+
+    assert outer_border_length(np.ones((5, 5), bool)) == 16.0
+    line = np.zeros((3, 7), bool)
+    line[1, 1:6] = True
+    assert outer_border_length(line) == 8.0
+    assert outer_border_length(np.eye(6, dtype=bool)) == pytest.approx(10 * np.sqrt(2))
+    one = np.zeros((3, 3), bool)
+    one[1, 1] = True
+    assert outer_border_length(one) == 0.0
+    yy, xx = np.mgrid[-15:16, -15:16]
+    disk = (yy * yy + xx * xx) <= 100
+    sliver = np.zeros_like(disk)
+    sliver[15, 4:27] = True
+    two = disk.copy()
+    two[:, 15] = False  # split into two half disks: two components, both counted
+    fg = np.stack([disk, sliver, np.zeros_like(disk), two])[:, None]  # (mark, time, y, x)
+    xp = mg.Dataset({"roi": mg.DataArray(np.zeros((4, 1, 1, 31, 31), np.uint16), ("mark", "channel", "time", "roi_y", "roi_x"))},
+                    coords={"fg": (("mark", "time", "roi_y", "roi_x"), fg), "valid": (("mark", "time"), np.ones((4, 1), bool))})
+    out = mg.components.get("filter_nonround")()(xp)
+    assert out.valid.values[:, 0].tolist() == [True, False, False, False]
+    roundness = 4 * np.pi * disk.sum() / outer_border_length(disk) ** 2
+    assert 0.85 < roundness < 1.0
+    assert mg.components.get("filter_nonround")(min_roundness=0.95)(xp).valid.values[0, 0] == False  # noqa: E712
