@@ -263,6 +263,8 @@ def test_marker_filters(mg):
             want[i] &= empty[i + 1]
     np.testing.assert_array_equal(out.valid.values[:, 0], want)
     assert not want[12] and not want[14] and want[6] and want[8]
-    with pytest.raises(NotImplementedError):
-        mg.filter.filter_nonround(ds)
+    # filter_nonround (filter.py:40-62): the chip's fg masks are cv.circle disks -- all round enough
+    rnd = mg.filter.filter_nonround(ds)
+    assert rnd.valid.values.all()
+    assert not mg.filter.filter_nonround(ds, min_roundness=2.0).valid.values.any()  # pixel-area over centre-line perimeter stays below 2
     assert {"filter_expression", "filter_leaky", "filter_nonround"} <= set(mg.components.get_all())
