@@ -5,9 +5,14 @@ One "step" = one pass of flat-field + stitch -> bead detection -> fg/bg segmenta
 reduction over one synthetic (T x C x H x W) uint16 stack that is already resident in HBM.
 Workload at N=1: BASELINE.json's 64 x 4 x 4096 x 4096 stack (C4), per-timepoint detection (mode P),
 search channel 0, the reference's default 5 000 000 RANSAC iterations per searched plane.
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own block of
-timepoints of the same size (weak scaling), runs the chain locally and all-gathers the final marker
-table over RCCL.  Prints ONE JSON line on rank 0.
+N > 1, one rank per GPU -- started by torch.distributed.run, or by this script itself: a parent
+that never touches the GPU spawns the N ranks (magnify_amd/launch.py) and relays rank 0's line.
+  --scaling weak (default): every rank owns its own 64-timepoint block, runs the chain locally and
+      all-gathers the final marker table over RCCL; for N > 1 the line also carries a `strong` object,
+      measured right after the timed region.
+  --scaling strong: north_star's C4 -- ONE 64-timepoint stack, contiguous shards of 64/N timepoints
+      per rank (distributed.shard_range), same all-gather.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -173,7 +178,17 @@ def main():
                     help="the reference tests' kind of image: zero background, beads of value 1000 (not the headline)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-stream pass")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --timepoints per GPU; strong: --timepoints in total, sharded over the GPUs")
+    ap.add_argument("--no-strong-extra", action="store_true",
+                    help="weak scaling with N > 1: skip the extra strong-scaling measurement")
     args = ap.parse_args()
+
+    from magnify_amd import launch
+
+    if args.gpus > 1 and not launch.launched_by_torchrun():
+        # this process has not touched the GPU (and never will): it starts one child per rank
+        raise SystemExit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
     import numpy as np
     import torch
@@ -185,52 +200,86 @@ def main():
 
     rank, world, local = mgd.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     hp.require_gpu()
     dev = torch.device("cuda", local)
-    T, C, S = args.timepoints, args.channels, args.size
+    C, S = args.channels, args.size
+    strong = args.scaling == "strong"
+    if strong:   # one stack of --timepoints, this rank owns [lo, hi)
+        lo, hi = mgd.shard_range(args.timepoints, rank, world)
+    else:        # every rank owns its own block of --timepoints
+        lo, hi = rank * args.timepoints, (rank + 1) * args.timepoints
+    T = hi - lo
+    if T == 0:
+        raise SystemExit(f"rank {rank} owns no timepoint: --timepoints {args.timepoints} < --gpus {world}")
 
-    stack, truth = synthetic_stack(T, C, S, S, seed=4000 + 100 * rank, device=dev, noiseless=args.noiseless)
+    # the stack is the concatenation of the ranks' blocks; a block's content only depends on where it starts
+    # (N = 1: seed 4000, the whole stack, in both modes)
+    stack, truth = synthetic_stack(T, C, S, S, seed=4000 + (lo if strong else 100 * rank), device=dev,
+                                   noiseless=args.noiseless)
     flat_np = vignette((S, S))
     flat = torch.from_numpy(flat_np).to(dev)
-    proc = StackProcessor(T, C, S, S, num_iter=args.num_iter, min_bead_diameter=10, max_bead_diameter=50,
-                          search_channels=(0,), mode="P", plane_batch=args.plane_batch or None, device=dev,
-                          n_streams=args.streams, sub_batches=args.sub_batches or None)
 
-    src = stack.cpu().pin_memory() if args.from_host else stack
-
-    def step(seed):
-        out = proc(src, flat, 100.0, seed=seed)
-        table = mgd.marker_table(out, rank * T, C, dev)
-        table = mgd.gather_marker_table(table)
-        return out, table
+    def make_proc(n_t):
+        return StackProcessor(n_t, C, S, S, num_iter=args.num_iter, min_bead_diameter=10, max_bead_diameter=50,
+                              search_channels=(0,), mode="P", plane_batch=args.plane_batch or None, device=dev,
+                              n_streams=args.streams, sub_batches=args.sub_batches or None)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        out, table = step(i)
-    timer = hp.StageTimer()
-    barrier()
-    hp.set_timer(timer)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out, table = step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    hp.set_timer(None)
-    stages = timer.summary()
-    if world > 1:
-        gloo = torch.distributed.get_backend() == "gloo"
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    def max_over_ranks(dt):
+        if world > 1:
+            gloo = torch.distributed.get_backend() == "gloo"
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def run_steps(proc, src, first_assay, with_timer):
+        """W untimed + K timed steps; a step = the chain on this rank's block + the marker-table all-gather.
+        The detection RNG stream of an assay depends on its GLOBAL index only (seed + 1000003 * index)."""
+        def step(seed):
+            out = proc(src, flat, 100.0, seed=(seed + 1000003 * first_assay) & 0xFFFFFFFFFFFFFFFF)
+            table = mgd.gather_marker_table(mgd.marker_table(out, first_assay, C, dev))
+            return out, table
+
+        for i in range(args.warmup):
+            out, table = step(i)
+        timer = hp.StageTimer() if with_timer else None
+        barrier()
+        hp.set_timer(timer)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out, table = step(args.warmup + i)
+        barrier()
+        dt = time.perf_counter() - t0
+        hp.set_timer(None)
+        return out, table, max_over_ranks(dt), (timer.summary() if with_timer else None)
+
+    proc = make_proc(T)
+    src = stack.cpu().pin_memory() if args.from_host else stack
+    out, table, dt, stages = run_steps(proc, src, lo, True)
+    n_total = args.timepoints if strong else world * args.timepoints  # timepoints all ranks processed per step
+
+    strong_extra = None
+    if world > 1 and not strong and not args.no_strong_extra and args.timepoints >= world:
+        # the same ranks once more on north_star's C4 proper: ONE --timepoints stack, 1/N of it per rank
+        # (the first timepoints of this rank's block stand in for its shard)
+        slo, shi = mgd.shard_range(args.timepoints, rank, world)
+        proc_s = make_proc(shi - slo)
+        _, table_s, dt_s, _ = run_steps(proc_s, src[: shi - slo], slo, False)
+        strong_extra = {"value": args.timepoints * C * S * S / 1e6 / (dt_s / args.steps), "unit": "MP/s",
+                        "ms_per_step": dt_s / args.steps * 1e3, "timepoints_total": args.timepoints,
+                        "timepoints_per_gpu": shi - slo, "markers": int(table_s.shape[0]),
+                        "what": "strong scaling: one stack of --timepoints sharded over the ranks (same steps / warmup)"}
+        del proc_s
 
     markers_local = int(sum(len(b) for b in out["beads"]))
     markers_total = int(table.shape[0])
-    mp_total = world * T * C * S * S / 1e6
+    mp_total = n_total * C * S * S / 1e6
     ms_per_step = dt / args.steps * 1e3
 
     if rank == 0:
@@ -289,13 +338,20 @@ def main():
         result = {
             "metric": "megapixels/sec through flatfield+segment+ROI-reduce; markers/sec",
             "value": mp_total / (dt / args.steps), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u16",
             "data": "synthetic" + (" noiseless" if args.noiseless else "") + (" (host-resident, PCIe-inclusive)" if args.from_host else ""),
-            "config": {"workload": f"C4: {T} timepoints x {C} ch x {S}x{S} uint16 per GPU, mode P (per-timepoint "
-                                   f"detection), search channel 0, num_iter={args.num_iter}, vignette flat-field, "
-                                   f"dark=100, roi_length={proc.L}",
-                       "timepoints_per_gpu": T, "parallelism": f"time-shard x{world}"},
+            "config": {"workload": (f"C4: {args.timepoints} timepoints x {C} ch x {S}x{S} uint16 "
+                                    + ("in total" if strong else "per GPU") + ", mode P (per-timepoint "
+                                    f"detection), search channel 0, num_iter={args.num_iter}, vignette flat-field, "
+                                    f"dark=100, roi_length={proc.L}"),
+                       "timepoints_per_gpu": T, "timepoints_total": n_total, "parallelism": f"time-shard x{world}"},
+            "ranks": {"world_size": torch.distributed.get_world_size() if world > 1 else 1,
+                      "backend": (("rccl" if torch.distributed.get_backend() == "nccl" else torch.distributed.get_backend())
+                                  if world > 1 else None),
+                      "shared_gpu": os.environ.get("MG_SHARE_GPU") == "1",
+                      "launcher": "self" if os.environ.get("MG_LAUNCHED") == "1" else ("torchrun" if world > 1 else None)},
+            "strong": strong_extra,
             "markers_per_s": markers_total / (dt / args.steps), "markers": markers_total,
             "roofline": roofline,
             "streaming_part": streaming,

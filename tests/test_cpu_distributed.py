@@ -67,3 +67,25 @@ def test_shard_range_covers_everything():
             spans = [shard_range(n, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_self_launcher(capsys):
+    """bench.py's way of starting N ranks from a parent that never touches the GPU
+    (magnify_amd/launch.py): env as torchrun sets it, rank 0's stdout relayed, failures propagated."""
+    import io
+    import json
+
+    from magnify_amd import launch
+
+    child = os.path.join(ROOT, "tests", "_launch_child.py")
+    buf = io.StringIO()
+    assert launch.spawn_ranks([child, "7"], 2, share_gpu=False, timeout=120, out=buf) == 0
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "rank 1 done" not in buf.getvalue()
+    rec = json.loads(lines[0])
+    assert rec == {"world": 2, "rows": [float(i) for i in range(7)], "owners": [0.0] * 4 + [1.0] * 3, "launched": "1"}
+    # a rank that exits non-zero fails the launch (the other rank is terminated, not left behind)
+    assert launch.spawn_ranks([child, "7", "1"], 2, share_gpu=False, timeout=120, out=io.StringIO()) == 7
+    env = launch.rank_env(1, 4, 1234, share_gpu=True, base={})
+    assert env["RANK"] == "1" and env["WORLD_SIZE"] == "4" and env["MG_SHARE_GPU"] == "1" and env["MG_DIST_BACKEND"] == "gloo"
+    assert launch.launched_by_torchrun({"RANK": "0", "WORLD_SIZE": "2"}) and not launch.launched_by_torchrun({})

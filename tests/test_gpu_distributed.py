@@ -68,3 +68,37 @@ def test_mode_r_time_sharded_matches_single_process():
         np.testing.assert_array_equal(image, proc.image[lo:hi].cpu().numpy())  # global maxima on every shard
         np.testing.assert_array_equal(roi, want["roi"][:, :, lo:hi].cpu().numpy())
         np.testing.assert_array_equal(sums, want["sums"][:, :, lo:hi].cpu().numpy())
+
+
+def _bench(*flags):
+    import json
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--size", "512", "--num-iter", "40000",
+           "--no-cpu", *flags]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, done.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as typed (no torchrun): the parent spawns the ranks; on this one-GPU box
+    they share cuda:0 over gloo.  Weak scaling carries the strong-scaling object; `--scaling strong`
+    processes ONE stack, and its shards find exactly the markers of the single-rank run (an assay's
+    RNG stream and synthetic content depend on its global index only for shard starts that coincide)."""
+    weak = _bench("--gpus", "2", "--timepoints", "4")
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["ranks"]["world_size"] == 2
+    assert weak["ranks"]["launcher"] == "self" and weak["ranks"]["shared_gpu"] is True
+    assert weak["config"]["timepoints_per_gpu"] == 4 and weak["config"]["timepoints_total"] == 8
+    assert weak["strong"]["timepoints_per_gpu"] == 2 and weak["strong"]["value"] > 0
+    assert abs(weak["value"] - 8 * 4 * 512 * 512 / 1e6 / (weak["ms_per_step"] / 1e3)) < 1e-6 * weak["value"]
+    strong = _bench("--gpus", "2", "--timepoints", "4", "--scaling", "strong")
+    assert strong["scaling"] == "strong" and strong["config"]["timepoints_per_gpu"] == 2
+    assert strong["config"]["timepoints_total"] == 4
+    assert abs(strong["value"] - 4 * 4 * 512 * 512 / 1e6 / (strong["ms_per_step"] / 1e3)) < 1e-6 * strong["value"]
+    one = _bench("--gpus", "1", "--timepoints", "2")
+    assert one["n_gpus"] == 1 and one["strong"] is None and one["ranks"]["world_size"] == 1
+    assert one["roofline"]["frac"] is not None and "cpu_baseline" in one
