@@ -325,6 +325,13 @@ def test_candidates_scores_nms(hp, keyed):
                                   grad_angles=ang)
         np.testing.assert_array_equal(res[k][0], oc)
         assert ulp_diff_f32(res[k][1], osc).max() <= 1
+        # end to end with the oracle's OWN angles (np.arctan2 on float32, utils.py:170 -- NumPy's SIMD
+        # loop, up to 2 ulp from the GPU's correctly rounded angles): same circles in the same order;
+        # a score may move by a few ulp, which could only reorder / flip circles whose scores are that
+        # close to each other or to min_roundness -- none here (bound stated in DESIGN.md section 2)
+        oc2, osc2 = rp.find_circles(u8, 0.1, 0.9, 20, num_iter, min_r, max_r, 0.3, min_dist, seed=seeds[k])
+        np.testing.assert_array_equal(res[k][0], oc2)
+        assert ulp_diff_f32(res[k][1], osc2).max() <= 4
 
 
 def test_nms_golden_and_wrap(hp, golden):
