@@ -127,10 +127,12 @@ int64_t mg_scharr_hist_scratch_words(int n_planes, int h, int w, int mode);
 /* cv.Canny(dx, dy, L2gradient=True) non-maximum suppression + double threshold with the
  * already prepared integer thresholds d_thresh[n_planes][2] = {low, high}.  Output: two bitmaps,
  * d_weak (local maxima with m > low: OpenCV map values 0 and 2) and d_strong (m > high: value 2).
- * d_class (optional, [n_planes][2][words_per_plane]): bit planes c0, c1 of every pixel's gradient
- * orientation class floor((atan2(dy, dx) mod pi) / (pi / 4)), decided exactly on the integer Scharr
- * gradient (same sign: |dy| < |dx| -> 0 else 1; opposite sign: |dy| > |dx| -> 2 else 3); consumed by
- * mg_score_circles' prefilter. */
+ * d_class (optional, [n_planes][3][words_per_plane]): bit planes c0, c1, c2 of every pixel's gradient
+ * orientation bin floor((atan2(dy, dx) mod pi) / (pi / 8)) = 4 c1 + 2 c0 + c2, decided exactly on the integer
+ * Scharr gradient: the quarter 2 c1 + c0 (same sign: |dy| < |dx| -> 0 else 1; opposite sign: |dy| > |dx| -> 2
+ * else 3) and its upper half c2 (tan(pi/8) = sqrt(2) - 1 and tan(3 pi/8) = sqrt(2) + 1 as integer
+ * inequalities (|dx| + |dy|)^2 > 2 dx^2, (|dy| - |dx|)^2 > 2 dx^2); consumed by the scoring prefilters
+ * (mg_score_circles: quarters; mg_score_circles_keyed: eighths). */
 int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_thresh, uint32_t* d_weak,
                  uint32_t* d_strong, uint32_t* d_class, int64_t words_per_plane, void* stream);
 
@@ -209,11 +211,13 @@ int mg_candidate_keys(const int32_t* d_coords, int64_t coord_cap, const int32_t*
  *   of every tile (n_tiles = tile rows x tile cols of mg_dedup_layout), d_num_circles[n_planes].
  * The slices of different workgroups land in arrival order: list positions are not canonical, the
  * keys are (mg_nms_round / mg_collect_circles take them as tie-breakers).  d_cell_* / d_num_edges /
- * grid / num_iter must be those the keys were generated with. */
+ * grid / num_iter must be those the keys were generated with.
+ * d_layer_starts (optional, [n_planes][n_tiles][nr + 1], nr = max_r - min_r + 1): list index of the first key
+ * of every radius of every tile, entry nr = the tile's end (mg_score_circles_keyed deals its work by radius). */
 int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, const int32_t* d_cell_starts,
                        const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w, int grid,
                        int min_r, int max_r, uint32_t* d_unique_keys, int64_t circle_cap, int32_t* d_tile_ranges,
-                       int32_t* d_num_circles, void* stream);
+                       int32_t* d_num_circles, int32_t* d_layer_starts, void* stream);
 
 /* Ordered compaction of the bitmap into the unique circle list in the build's canonical order
  * (tile_row, tile_col, r, row, col): d_circles[n_planes][circle_cap][3] int32 (row, col, r),
@@ -255,6 +259,37 @@ int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, const ui
                      const int32_t* d_per_starts, int per_total, float min_roundness, int write_skipped,
                      int dedup_centres, float* d_scores, int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc,
                      int32_t* d_num_scored, void* stream);
+
+/* The keyed path's scoring (same scores and same passing set as mg_score_circles input (a), which remains for
+ * radii outside mg_score_keyed_supported): two kernels.
+ * Prefilter: a workgroup per super-tile of 2 x 2 centre tiles with the edge window in LDS as one byte per
+ * pixel (the gradient-orientation bin of mg_canny_nms' class planes, 0x0C = no edge); a lane per circle, all
+ * circles of a wave of one radius, the perimeter walked as straight-line code per radius.  For every pair of
+ * opposite perimeter points the two window bytes select, in one byte permute, UPPER BOUNDS of the two pixels'
+ * terms 4 |d - pi/2| / pi - 1 (utils.py:244-249) from the pair's table (mg_score_pair_table: the distance
+ * between the points' radial direction and the pixel's orientation bin bounds the term); the bounds are summed
+ * in 1/64 (rounded up) and a circle whose bound is below min_roundness * P - 1e-3 is dropped -- exact: every
+ * term <= its bound.  Survivors are appended to d_surv_list[n_planes][surv_cap] (scratch; surv_cap >=
+ * circle_cap can never overflow), d_num_surv[n_planes] (scratch, zeroed here).
+ * Exact pass: the reference's float64 sum in perimeter order, one lane per survivor; the gradient angle of a
+ * hit is d_angle's entry or, with d_angle == NULL, computed on demand from d_blur exactly as mg_edge_angles
+ * does (so neither the angle map nor its pass is needed).  Outputs as mg_score_circles (no same-centre
+ * reduction: the suppression treats same-centre circles correctly by itself); d_num_scored = survivors.
+ * d_class_bits is required. */
+int mg_score_keyed_supported(int min_r, int max_r); /* 1: 2 <= min_r, max_r <= 26 */
+/* out_entries[27][80]: for radius r and pair k of opposite perimeter points, 8 signed bytes = bound (1/64) per
+ * orientation bin.  Returns the number of entries (2160); fills them when cap >= that. */
+int mg_score_pair_table(uint64_t* out_entries, int cap);
+/* first point (dr, dc) of every pair of radius r, in table order; returns the number of pairs */
+int mg_score_pairs(int r, int32_t* out_rc, int cap);
+int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angle, const uint32_t* d_edge_bits,
+                           const uint32_t* d_class_bits, int64_t words_per_plane, int n_planes, int h, int w,
+                           int32_t* d_circles, int64_t circle_cap, const uint32_t* d_unique_keys,
+                           const int32_t* d_layer_starts, int min_r, int max_r, const int32_t* d_per_rc,
+                           const double* d_per_expected, const int32_t* d_per_starts, int per_total,
+                           const uint64_t* d_pair_table, float min_roundness, int write_skipped, float* d_scores,
+                           int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc, int32_t* d_num_scored,
+                           int32_t* d_surv_list, int64_t surv_cap, int32_t* d_num_surv, void* stream);
 
 /* One round of the parallel-but-equivalent greedy suppression of filter_neighbors
  * (utils.py:254-292).  Priority = (score desc, tie key asc) -- the build's canonical tie order

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libmagnify_hip.so")
+LIB_PATH = os.environ.get("MG_LIB") or os.path.join(_HERE, "_lib", "libmagnify_hip.so")
 
 MG_U8, MG_U16, MG_F32, MG_F64 = 0, 1, 2, 3
 MG_NO_EDGE = 100.0
@@ -44,11 +44,16 @@ PROTOTYPES = {
     "mg_edge_grid": [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p],
     "mg_candidate_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _p, _p],
     "mg_candidate_keys": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _i, _p, _p, _p],
-    "mg_keys_to_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _l, _p, _p, _p],
+    "mg_keys_to_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _l, _p, _p, _p, _p],
     "mg_bitmap_to_circles": [_p, _l, _i, _i, _i, _i, _i, _p, _p, _l, _p, _p],
     "mg_edge_angles": [_p, _i, _i, _i, _p, _l, _p, _p, _p],
     "mg_dedup_layout": [_i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "mg_score_circles": [_p, _p, _p, _l, _i, _i, _i, _p, _l, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _i, _i, _p, _p, _p, _p, _p, _p],
+    "mg_score_keyed_supported": [_i, _i],
+    "mg_score_pair_table": [_p, _i],
+    "mg_score_pairs": [_i, _p, _i],
+    "mg_score_circles_keyed": [_p, _p, _p, _p, _l, _i, _i, _i, _p, _l, _p, _p, _i, _i, _p, _p, _p, _i, _p, _f, _i,
+                               _p, _p, _p, _p, _p, _p, _l, _p, _p],
     "mg_nms_round": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _p, _l, _p],
     "mg_collect_circles": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p],
     "mg_circle_labels": [_p, _l, _p, _i, _i, _i, _p, _i, _p, _i, _p],
@@ -141,6 +146,22 @@ def perimeter_table(min_r: int, max_r: int):
     expected = np.empty(total, dtype=np.float64)
     lib().mg_perimeter_table(int(min_r), int(max_r), rc.ctypes.data, expected.ctypes.data, starts.ctypes.data, total)
     return rc, expected, starts
+
+
+def score_pair_table():
+    """Bound tables of mg_score_circles_keyed: uint64 (27, 80), 8 signed bytes per pair of opposite points."""
+    total = lib().mg_score_pair_table(None, 0)
+    entries = np.zeros(total, dtype=np.uint64)
+    check(min(lib().mg_score_pair_table(entries.ctypes.data, total), 0), "mg_score_pair_table")
+    return entries.reshape(27, 80)
+
+
+def score_pairs(r: int):
+    """First points (dr, dc) of the pairs of opposite perimeter points of radius r, in table order."""
+    n = lib().mg_score_pairs(int(r), None, 0)
+    out = np.empty((n, 2), dtype=np.int32)
+    lib().mg_score_pairs(int(r), out.ctypes.data, n)
+    return out
 
 
 def dedup_layout(h: int, w: int, min_r: int, max_r: int):

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
                                                    int gr, int gc, int ntc, int nr, int max_r,
                                                    uint32_t* __restrict__ d_ukeys, int64_t circle_cap,
                                                    int32_t* __restrict__ d_tile_ranges, int n_tiles,
-                                                   int32_t* __restrict__ d_num_circles) {
+                                                   int32_t* __restrict__ d_num_circles,
+                                                   int32_t* __restrict__ d_layer_starts) {
   extern __shared__ uint32_t lbits[];  // [TX][nr][LAYER_WORDS]
   __shared__ long long s_lo[MAX_RANGES];
   __shared__ int s_pre[MAX_RANGES + 1];
@@ -307,6 +308,13 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
     int32_t* tr2 = d_tile_ranges + ((int64_t)plane * n_tiles + tile0 + threadIdx.x) * 2;
     tr2[0] = (int32_t)min(base + s_cnt[threadIdx.x * nr], circle_cap);
     tr2[1] = s_cnt[(threadIdx.x + 1) * nr] - s_cnt[threadIdx.x * nr];
+  }
+  if (d_layer_starts) {  // first key of every radius of every tile (+ the tile's end): the scoring kernel's chunks
+    for (int i = threadIdx.x; i < ntx * (nr + 1); i += NT) {
+      const int t = i / (nr + 1), ri = i - t * (nr + 1);
+      d_layer_starts[((int64_t)plane * n_tiles + tile0 + t) * (nr + 1) + ri] =
+          (int32_t)min(base + s_cnt[t * nr + ri], circle_cap);
+    }
   }
   uint32_t* out = d_ukeys + (int64_t)plane * circle_cap;
 #pragma unroll
@@ -458,8 +466,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(96))) void k_sco
   int32_t* list = tab + per_total;                        // [CHUNK]
   const int wy0 = (tile / ntc) * TS - 2 * max_r, wx0 = (tile % ntc) * TS - 2 * max_r;
   const uint32_t* bits = d_bits + plane * words_per_plane;
-  const uint32_t* cls0 = d_class ? d_class + (2 * plane) * words_per_plane : nullptr;
-  const uint32_t* cls1 = d_class ? d_class + (2 * plane + 1) * words_per_plane : nullptr;
+  // planes c0, c1 of mg_canny_nms' three (the quarter of the orientation; c2, its half, is not used here)
+  const uint32_t* cls0 = d_class ? d_class + (3 * plane) * words_per_plane : nullptr;
+  const uint32_t* cls1 = d_class ? d_class + (3 * plane + 1) * words_per_plane : nullptr;
   for (int i = threadIdx.x; i < side * wpr; i += NT) {
     const int j = i >> wsh, k = i & (wpr - 1);
     const int y = wy0 + j, xs = wx0 + 32 * k;
@@ -967,7 +976,8 @@ extern "C" int mg_bitmap_to_circles(uint32_t* d_bitmap, int64_t bitmap_words, in
 extern "C" int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, const int32_t* d_cell_starts,
                                   const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w,
                                   int grid, int min_r, int max_r, uint32_t* d_unique_keys, int64_t circle_cap,
-                                  int32_t* d_tile_ranges, int32_t* d_num_circles, void* stream) {
+                                  int32_t* d_tile_ranges, int32_t* d_num_circles, int32_t* d_layer_starts,
+                                  void* stream) {
   if (!d_keys || !d_cell_starts || !d_cell_counts || !d_num_edges || !d_unique_keys || !d_tile_ranges ||
       !d_num_circles || n_planes < 0 || n_planes > 65535 || circle_cap < 0 || num_iter < 0 || grid <= 0)
     return MG_EINVAL;
@@ -986,7 +996,7 @@ extern "C" int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, cons
   hipLaunchKernelGGL(k_tile_dedup<DEDUP_TX>,
                      dim3((ntc + tx - 1) / tx, ntr, n_planes), dim3(NT), (size_t)tx * nr * LAYER_WORDS * 4, s, d_keys,
                      num_iter, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gr, gc, ntc, nr, max_r,
-                     d_unique_keys, circle_cap, d_tile_ranges, ntr * ntc, d_num_circles);
+                     d_unique_keys, circle_cap, d_tile_ranges, ntr * ntc, d_num_circles, d_layer_starts);
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_clamp_counts, dim3((n_planes + 255) / 256), dim3(256), 0, s, d_num_circles, n_planes, circle_cap);
   MG_CHECK_LAUNCH();

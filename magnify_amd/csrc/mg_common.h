@@ -9,6 +9,14 @@
 
 #define MG_WAVE 64
 
+// Keyed scoring prefilter (mg_score.hip): super-tiles of 2 x 2 centre tiles (128 x 128 positions) with their
+// edge window as bytes in LDS, row stride 180 B = 45 dwords (odd: rows rotate through the banks); radii up to
+// MG_SCORE_MAX_R (window side 128 + 2 * 26 = 180), perimeters up to 2 * MG_SCORE_MAX_PAIRS points.
+#define MG_SCORE_TILE 64
+#define MG_SCORE_MAX_R 26
+#define MG_SCORE_MAX_PAIRS 80
+#define MG_SCORE_WSTRIDE 180
+
 #define MG_CHECK_LAUNCH()                          \
   do {                                             \
     hipError_t e_ = hipGetLastError();             \

@@ -477,11 +477,13 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
   const int c0 = 4 * lane, gx = tx0 + c0;
   uint32_t* weak = d_weak + plane * words_per_plane;
   uint32_t* strong = d_strong + plane * words_per_plane;
-  // Orientation class of the gradient, phi = atan2(dy, dx) mod pi in quarters of pi (exact, from the
-  // integer gradient): bit planes c0, c1 of the class index; the scoring prefilter drops the edge
-  // pixels whose class is perpendicular to a perimeter point's radial direction (their term is <= 0).
-  uint32_t* cls0 = d_class ? d_class + (2 * plane) * words_per_plane : nullptr;
-  uint32_t* cls1 = d_class ? d_class + (2 * plane + 1) * words_per_plane : nullptr;
+  // Orientation bin of the gradient, phi = atan2(dy, dx) mod pi in eighths of pi (exact, from the
+  // integer gradient): bit planes c0, c1 (quarter index 2 c1 + c0) and c2 (upper half of the quarter),
+  // bin = 4 c1 + 2 c0 + c2.  The scoring prefilter bounds every perimeter term by the distance between
+  // the point's radial direction and the pixel's bin.
+  uint32_t* cls0 = d_class ? d_class + (3 * plane) * words_per_plane : nullptr;
+  uint32_t* cls1 = d_class ? d_class + (3 * plane + 1) * words_per_plane : nullptr;
+  uint32_t* cls2 = d_class ? d_class + (3 * plane + 2) * words_per_plane : nullptr;
   constexpr int TG22 = 13573;
   const uint32_t in_row = gx + 4 <= w ? 0xFu : ((1u << max(w - gx, 0)) - 1u);  // the lane's pixels left of the row end
   // mag rows: 6 magnitudes (cols c0-1 .. c0+4) of image rows y-1, y, y+1; zero outside the image
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
     if (jr < 4) continue;
     // NMS of image row yo = ym - 1 (mag rows 0, 1, 2 = yo - 1, yo, yo + 1; gradients in cd*[0])
     const int yo = ym - 1;
-    uint32_t wb = 0, sb = 0, cb0 = 0, cb1 = 0;
+    uint32_t wb = 0, sb = 0, cb0 = 0, cb1 = 0, cb2 = 0;
     if (yo < h) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -542,6 +544,13 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
         const int ay = abs(ys);
         cb0 |= ((neg ? ay <= x : ay >= x) ? 1u : 0u) << q;
         cb1 |= (neg ? 1u : 0u) << q;
+        // halves of a quarter: psi = atan(|dy| / |dx|) against pi/8 (psi < pi/4: tan = sqrt(2) - 1, i.e.
+        // (|dx| + |dy|)^2 > 2 dx^2) or 3 pi/8 (tan = sqrt(2) + 1, i.e. (|dy| - |dx|)^2 > 2 dx^2); phi = psi or
+        // pi - psi (signs differ), which mirrors the halves.  Irrational tangents: never an equality.
+        const bool lowq = neg ? ay <= x : ay < x;
+        const int sq = lowq ? x + ay : ay - x;
+        const bool upper = sq * sq > 2 * x * x;
+        cb2 |= ((neg != upper) ? 1u : 0u) << q;
       }
     }
     // 8 lanes x 4 bits -> one 32-bit word
@@ -550,6 +559,7 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
     if (d_class) {
       cb0 = or_reduce8((cb0 & in_row) << (4 * (lane & 7)));
       cb1 = or_reduce8((cb1 & in_row) << (4 * (lane & 7)));
+      cb2 = or_reduce8((cb2 & in_row) << (4 * (lane & 7)));
     }
     if ((lane & 7) == 0 && yo < h && gx < w) {
       const int64_t bit0 = (int64_t)yo * w + gx;
@@ -559,6 +569,7 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
         if (d_class) {
           cls0[bit0 >> 5] = cb0;
           cls1[bit0 >> 5] = cb1;
+          cls2[bit0 >> 5] = cb2;
         }
       } else {
         bits_or(weak, bit0, wb);
@@ -566,6 +577,7 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
         if (d_class) {
           bits_or(cls0, bit0, cb0);
           bits_or(cls1, bit0, cb1);
+          bits_or(cls2, bit0, cb2);
         }
       }
     }
@@ -898,7 +910,7 @@ extern "C" int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, c
   const size_t bytes = (size_t)n_planes * words_per_plane * 4;
   if (hipMemsetAsync(d_weak, 0, bytes, s) != hipSuccess || hipMemsetAsync(d_strong, 0, bytes, s) != hipSuccess)
     return MG_ELAUNCH;
-  if (d_class && (w & 31) && hipMemsetAsync(d_class, 0, 2 * bytes, s) != hipSuccess) return MG_ELAUNCH;
+  if (d_class && (w & 31) && hipMemsetAsync(d_class, 0, 3 * bytes, s) != hipSuccess) return MG_ELAUNCH;
   hipLaunchKernelGGL(k_canny_nms, g, dim3(NT), 0, s, d_blur, h, w, d_thresh, words_per_plane, d_weak, d_strong,
                      d_class);
   MG_CHECK_LAUNCH();

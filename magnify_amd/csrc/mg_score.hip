@@ -1,0 +1,491 @@
+// A9-A10 on the keyed path: mean_grad / len(perimeter) (utils.py:183-192, 225-251) for the unique circles of
+// mg_keys_to_circles, as two kernels.
+//
+//   k_prefilter  exact rejection of the circles that cannot reach min_roundness -- 99.6 % of them on noisy images.
+//                A workgroup owns a super-tile of 2 x 2 centre tiles; its window of the edge map lives in LDS as
+//                ONE BYTE per pixel: the pixel's gradient-orientation bin (eighths of pi, decided exactly on the
+//                integer gradient by mg_canny_nms) or 0x0C for "no edge".  A lane owns a circle; all 64 circles of
+//                a wave have the SAME radius (the keys of a tile are sorted by radius: the block cuts the four key
+//                lists at the radius boundaries and deals 64-circle chunks of one radius to its waves), so the
+//                perimeter walk is straight-line code per radius (template <R>, the midpoint circle evaluated at
+//                compile time): the offset of a perimeter point is the immediate of its ds_read_u8 and the bound
+//                table of the point sits in scalar registers.  Opposite points (p, -p) have the same radial
+//                direction mod pi and share a table: their two bytes form the selector of ONE v_perm_b32, which
+//                looks both up in the 8 signed bytes of the table (0x0C selects the constant 0), and one
+//                v_dot4_i32_i8 adds both to the lane's sum.  A table byte is an upper bound, in 1/64, of the term
+//                a pixel of that bin can contribute to the reference's sum; a circle whose bounds add up to less
+//                than min_roundness * P cannot pass (every term <= its bound) and is dropped.  Survivors are
+//                appended to a per-plane list.  Bounding roofline: LDS (one byte read per perimeter point).
+//   k_exact      the survivors' reference sum, one lane per survivor: float64, sequential in perimeter order,
+//                gradient angles computed on demand from the blurred image exactly as mg_edge_angles does (the
+//                dense angle map and its pass are not needed), score stored float32; circles that pass go to d_alive.
+#include <math.h>
+
+#include <algorithm>
+
+#include "mg_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int NP = 512;  // prefilter block: 8 waves share a window (4 blocks per CU by LDS: 32 waves per CU)
+constexpr int TS = MG_SCORE_TILE;
+constexpr int ST = 2 * TS;
+constexpr int WSTR = MG_SCORE_WSTRIDE;
+constexpr int MAXR = MG_SCORE_MAX_R;
+constexpr int MAXP = MG_SCORE_MAX_PAIRS;
+constexpr int BIAS = MAXR * WSTR + MAXR;  // immediates BIAS +- (dr * WSTR + dc) are >= 0
+constexpr int WBASE = 8192;               // LDS byte offset of the window (>= BIAS: lane addresses stay >= 0)
+constexpr int SEGW = 33;                  // radii + 1 per sub-tile in the segment table
+static_assert(WBASE >= BIAS && WBASE % 16 == 0, "window base");
+static_assert(ST + 2 * MAXR <= WSTR && (WSTR % 4) == 0 && ((WSTR / 4) & 1) == 1, "window stride");
+
+__device__ __forceinline__ uint32_t bits_at(const uint32_t* __restrict__ bits, int64_t bit0, int n) {
+  const int64_t wi = bit0 >> 5;
+  const int sh = (int)(bit0 & 31);
+  uint64_t two = bits[wi];
+  if (sh + n > 32) two |= (uint64_t)bits[wi + 1] << 32;
+  const uint32_t v = (uint32_t)(two >> sh);
+  return n >= 32 ? v : (v & ((1u << n) - 1u));
+}
+
+// First point (dr, dc) of every pair of opposite perimeter points of radius R, in the order of
+// mg_score_pair_table (mg_tables.hip: score_pairs) -- the reference's midpoint walk, utils.py:433-465.
+template <int R>
+struct Pairs {
+  int n;
+  int dr[MAXP], dc[MAXP];
+  constexpr Pairs() : n(0), dr{}, dc{} {
+    put(0, -R);
+    put(-R, 0);
+    int x = 1, y = -R;
+    while (x < -y) {
+      put(x, y);
+      put(y, x);
+      put(-x, y);
+      put(-y, x);
+      if (x * x + y * y - R * R <= 0) {
+        ++x;
+      } else {
+        ++y;
+        ++x;
+      }
+    }
+    if (y == -x) {
+      put(x, y);
+      put(-x, y);
+    }
+  }
+  constexpr void put(int a, int b) {
+    dr[n] = a;
+    dc[n] = b;
+    ++n;
+  }
+};
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+// Sum of the bounds over the perimeter of the circle whose centre byte sits at lds[vaddr + BIAS].
+template <int R>
+__device__ __forceinline__ int score_r(const uint8_t* lds, int vaddr, const uint2* __restrict__ tabs) {
+  constexpr Pairs<R> P{};
+  static_assert(P.n <= MAXP, "perimeter too long");
+  int sum = 0;
+#pragma unroll
+  for (int k = 0; k < P.n; ++k) {
+#ifdef MG_DBG_CONST_TAB
+    const uint2 t = make_uint2(0x40302010u + k, 0x10203040u);
+#else
+    const uint2 t = tabs[R * MAXP + k];  // uniform address: scalar loads
+#endif
+    const int off = P.dr[k] * WSTR + P.dc[k];
+    us2 s;
+    s.x = lds[vaddr + (BIAS + off)];
+    s.y = lds[vaddr + (BIAS - off)];
+    const uint32_t q = __builtin_amdgcn_perm(t.y, t.x, __builtin_bit_cast(uint32_t, s));  // bytes 0 and 2: the two bounds
+    sum = __builtin_amdgcn_sdot4((int)q, 0x00010001, sum, false);
+  }
+  return sum;
+}
+
+// ---- prefilter ----------------------------------------------------------------------------------------
+// LDS: [0, WBASE) small tables, [WBASE, +side * WSTR) the window, then SCAP sorted circle entries.
+constexpr int NBK = 32 * 32;   // (radius, bank class) buckets
+constexpr int SCAP = 6144;     // circles sorted per round (a super-tile holds ~3000 on noisy images)
+constexpr int KPT = SCAP / NP; // keys per thread and round
+static_assert(NBK * 4 + 512 <= WBASE, "small tables");
+
+__global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d_bits, const uint32_t* __restrict__ d_class,
+                                                  int64_t words_per_plane, int h, int w,
+                                                  const uint32_t* __restrict__ d_ukeys, int64_t circle_cap,
+                                                  const int32_t* __restrict__ d_layer_starts, int n_tiles, int ntr, int ntc,
+                                                  int nsc, int n_st, int64_t total_st, int min_r, int max_r, int nr,
+                                                  const uint2* __restrict__ d_tabs,
+                                                  const int32_t* __restrict__ d_per_starts, float min_roundness,
+                                                  int write_skipped, float* __restrict__ d_scores,
+                                                  int32_t* __restrict__ d_surv, int64_t surv_cap,
+                                                  int32_t* __restrict__ d_num_surv) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  int32_t* cursor = reinterpret_cast<int32_t*>(lds);  // [NBK]: count, then start, then end of every bucket
+  int32_t* chunk0 = cursor + NBK;                     // [nr + 1]: first chunk (wave) of radius rho
+  int32_t* need = chunk0 + SEGW;                      // [nr]: threshold on the sum of bounds (1/64)
+  int32_t* lfirst = need + 32;                        // [4] + [4]: first key / number of keys of the four sub-tiles
+  int32_t* next = lfirst + 8;                         // the block's chunk counter
+  uint8_t* win = lds + WBASE;
+  const int side = ST + 2 * max_r;
+  uint32_t* skeys = reinterpret_cast<uint32_t*>(lds + WBASE + ((side * WSTR + 15) & ~15));  // [SCAP]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < nr; i += NP) {
+    const int len = d_per_starts[i + 1] - d_per_starts[i];
+    // a circle can only pass with sum(terms) >= min_roundness * len - 1e-3 (margin far above any rounding of the
+    // real sum), and sum(terms) <= sum(bounds) / 64
+    need[i] = (int)ceil(64.0 * ((double)min_roundness * len - 1e-3));
+  }
+  const int wgroups = (side + 31) >> 5;  // 32-pixel groups per window row
+  for (int64_t st = blockIdx.x; st < total_st; st += gridDim.x) {
+    const int plane = (int)(st / n_st), sidx = (int)(st - (int64_t)plane * n_st);
+    const int sr = sidx / nsc, sc = sidx - sr * nsc;
+    __syncthreads();  // the previous super-tile's window and tables are no longer read
+    if (threadIdx.x < 4) {  // the four sub-tiles' key lists (mg_keys_to_circles: sorted by radius, row, column)
+      const int tr = 2 * sr + (threadIdx.x >> 1), tc = 2 * sc + (threadIdx.x & 1);
+      int a = 0, b = 0;
+      if (tr < ntr && tc < ntc) {
+        const int32_t* ls = d_layer_starts + ((int64_t)plane * n_tiles + tr * ntc + tc) * (nr + 1);
+        a = ls[0];
+        b = ls[nr];
+      }
+      lfirst[threadIdx.x] = a;
+      lfirst[4 + threadIdx.x] = max(b - a, 0);
+    }
+    // ---- the window: orientation bin of every edge pixel, 0x0C elsewhere.  All loads of a thread's (at most
+    // WI) 32-pixel groups are issued before the first is used: the block would otherwise wait for two to four
+    // global round trips per group, one after the other ----
+    const int wy0 = sr * ST - 2 * max_r, wx0 = sc * ST - 2 * max_r;
+    {
+      const uint32_t* pl[4] = {d_bits + plane * words_per_plane, d_class + (3 * plane) * words_per_plane,
+                               d_class + (3 * plane + 1) * words_per_plane, d_class + (3 * plane + 2) * words_per_plane};
+      constexpr int WI = 3;  // side * wgroups <= 180 * 6 <= WI * NP
+      uint32_t lo[WI][4], hi[WI][4];
+#pragma unroll
+      for (int it = 0; it < WI; ++it) {
+        const int i = threadIdx.x + it * NP;
+        const int j = i / wgroups, k = i - j * wgroups;
+        const int y = wy0 + j, xs = wx0 + 32 * k;
+        const int x_lo = max(xs, 0), x_hi = min(min(xs + 32, wx0 + side), w);
+        const bool live = i < side * wgroups && y >= 0 && y < h && x_lo < x_hi;
+        const int64_t wi = live ? ((int64_t)y * w + x_lo) >> 5 : 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          lo[it][c] = pl[c][wi];
+          hi[it][c] = pl[c][wi + 1];  // (the bitmaps carry one spare word)
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < WI; ++it) {
+        const int i = threadIdx.x + it * NP;
+        if (i >= side * wgroups) break;
+        const int j = i / wgroups, k = i - j * wgroups;
+        const int y = wy0 + j, xs = wx0 + 32 * k;
+        const int x_lo = max(xs, 0), x_hi = min(min(xs + 32, wx0 + side), w);
+        uint32_t pv[4] = {0u, 0u, 0u, 0u};  // edge bit, c0, c1, c2 of the group's 32 pixels
+        if (y >= 0 && y < h && x_lo < x_hi) {
+          const int sh = (int)(((int64_t)y * w + x_lo) & 31), n = x_hi - x_lo;
+          const uint32_t keep = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            pv[c] = ((uint32_t)(((((uint64_t)hi[it][c]) << 32) | lo[it][c]) >> sh) & keep) << (x_lo - xs);
+        }
+        uint32_t* rowp = reinterpret_cast<uint32_t*>(win + j * WSTR) + 8 * k;
+        const int nd = min(8, (WSTR >> 2) - 8 * k);  // dwords of this group inside the row
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (q >= nd) break;
+          uint32_t out = 0x0C0C0C0Cu;
+          if ((pv[0] >> (4 * q)) & 0xFu) {
+            out = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const int bit = 4 * q + b;
+              const uint32_t bin = (((pv[2] >> bit) & 1u) << 2) | (((pv[1] >> bit) & 1u) << 1) | ((pv[3] >> bit) & 1u);
+              out |= (((pv[0] >> bit) & 1u) ? bin : 0x0Cu) << (8 * b);
+            }
+          }
+          rowp[q] = out;
+        }
+      }
+    }
+    const uint32_t* ukeys = d_ukeys + (int64_t)plane * circle_cap;
+    __syncthreads();
+    const int n0 = lfirst[4], n1 = lfirst[5], n2 = lfirst[6], n3 = lfirst[7];
+    const int f0 = lfirst[0], f1 = lfirst[1], f2 = lfirst[2], f3 = lfirst[3];
+    const int n_all = n0 + n1 + n2 + n3;
+    // Rounds of at most SCAP circles (one round on noisy images).  A round sorts its circles by (radius, bank
+    // class of the centre's window dword) in LDS and deals every radius to half-waves so that the 32 lanes of a
+    // half-wave sit on different LDS banks: a perimeter read then takes one or two LDS cycles per half-wave
+    // instead of the ~4 of 32 random dwords, and the walk is bound by exactly those cycles.
+    for (int base = 0; base < n_all; base += SCAP) {
+      const int n_round = min(SCAP, n_all - base);
+      for (int i = threadIdx.x; i < NBK; i += NP) cursor[i] = 0;
+      if (threadIdx.x == 0) *next = 0;
+      __syncthreads();
+      // -- keys of the round: bucket = radius * 32 + bank class; rank within the bucket from the LDS counter --
+      uint32_t ent[KPT];
+      int bkt[KPT], rnk[KPT];
+#pragma unroll
+      for (int u = 0; u < KPT; ++u) {
+        const int m = base + threadIdx.x + u * NP;  // position in the concatenation of the four lists
+        const bool live = m < base + n_round;
+        const int sub = live ? (m >= n0) + (m >= n0 + n1) + (m >= n0 + n1 + n2) : 0;
+        const int off = m - (sub == 0 ? 0 : sub == 1 ? n0 : sub == 2 ? n0 + n1 : n0 + n1 + n2);
+        const int fs = sub == 0 ? f0 : sub == 1 ? f1 : sub == 2 ? f2 : f3;
+        const uint32_t key = ukeys[live ? (int64_t)fs + off : 0];
+        // entry: off << 14 | sub << 12 | row << 6 | col (off < 2^18: a tile holds at most 64 * 64 * 32 circles)
+        ent[u] = ((uint32_t)off << 14) | ((uint32_t)sub << 12) | (key & 0xFFFu);
+        const int wrow = (sub >> 1) * TS + (int)((key >> 6) & 63u) + max_r, wcol = (sub & 1) * TS + (int)(key & 63u) + max_r;
+        bkt[u] = live ? (int)((key >> 12) & 31u) * 32 + ((13 * wrow + (wcol >> 2)) & 31) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < KPT; ++u) rnk[u] = bkt[u] >= 0 ? atomicAdd(&cursor[bkt[u]], 1) : 0;
+      __syncthreads();
+      {  // exclusive prefix over the buckets (two per thread)
+        const int a = cursor[2 * threadIdx.x], b = cursor[2 * threadIdx.x + 1];
+        int total;
+        const int ex = mg_block_exscan(a + b, &total);
+        cursor[2 * threadIdx.x] = ex;
+        cursor[2 * threadIdx.x + 1] = ex + a;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < KPT; ++u)
+        if (bkt[u] >= 0) skeys[cursor[bkt[u]] + rnk[u]] = ent[u];
+      __syncthreads();
+      // -- waves per radius: radius rho owns sorted positions [rs, re); H = ceil(n / 32) half-waves --
+      if (wave == 0) {
+        int waves = 0;
+        if (lane < nr) {
+          const int rs = cursor[32 * lane], re = lane + 1 < 32 ? cursor[32 * lane + 32] : n_round;
+          waves = (((re - rs) + 31) / 32 + 1) / 2;
+        }
+        const int incl = mg_wave_scan_incl_i32(waves);
+        if (lane < nr) chunk0[lane] = incl - waves;
+        if (lane == nr - 1) chunk0[nr] = incl;
+      }
+      __syncthreads();
+      const int total_chunks = chunk0[nr];
+      for (;;) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(next, 1);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= total_chunks) break;
+        // the chunk's radius: the last rho with chunk0[rho] <= c (radii without circles share their successor's start)
+        const int rho = __builtin_popcountll(__ballot(lane < nr && chunk0[lane] <= c)) - 1;
+        const int j = c - chunk0[rho];
+        const int rs = cursor[32 * rho], re = rho + 1 < 32 ? cursor[32 * rho + 32] : n_round;
+        const int n_r = re - rs, hw_n = (n_r + 31) >> 5;
+        // half-wave hw takes the sorted positions hw, hw + H, hw + 2 H, ...: one circle per bank class (two where
+        // a class holds more than H circles)
+        const int hw = 2 * j + (lane >> 5), p = hw + hw_n * (lane & 31);
+        const bool valid = hw < hw_n && p < n_r;
+        const uint32_t e = skeys[valid ? rs + p : 0];
+        const int sub = (int)((e >> 12) & 3u);
+        const int wrow = (sub >> 1) * TS + (int)((e >> 6) & 63u) + max_r, wcol = (sub & 1) * TS + (int)(e & 63u) + max_r;
+        const int vaddr = WBASE + wrow * WSTR + wcol - BIAS;
+        int sum = 0;
+        if (!(write_skipped & 2))
+#ifdef MG_DBG_ONE_RADIUS
+        switch (14) {
+#else
+        switch (rho + min_r) {
+#endif
+#define MG_CASE(R) case R: sum = score_r<R>(lds, vaddr, d_tabs); break;
+          MG_CASE(2) MG_CASE(3) MG_CASE(4) MG_CASE(5) MG_CASE(6) MG_CASE(7) MG_CASE(8) MG_CASE(9) MG_CASE(10)
+          MG_CASE(11) MG_CASE(12) MG_CASE(13) MG_CASE(14) MG_CASE(15) MG_CASE(16) MG_CASE(17) MG_CASE(18)
+          MG_CASE(19) MG_CASE(20) MG_CASE(21) MG_CASE(22) MG_CASE(23) MG_CASE(24) MG_CASE(25) MG_CASE(26)
+#undef MG_CASE
+          default: break;
+        }
+        const bool pass = valid && sum >= need[rho];
+        const int64_t i = (int64_t)lfirst[sub] + (int)(e >> 14);  // the circle's index in the plane's key list
+        if ((write_skipped & 1) && valid && !pass) d_scores[(int64_t)plane * circle_cap + i] = MG_SCORE_SKIPPED;
+        const uint64_t pm = __ballot(pass);
+        if (pm) {  // rare: append the survivors to the plane's list
+          int sbase = 0;
+          if (lane == 0) sbase = atomicAdd(&d_num_surv[plane], __builtin_popcountll(pm));
+          sbase = __builtin_amdgcn_readfirstlane(sbase);
+          const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+          if (pass && (int64_t)sbase + rank < surv_cap) d_surv[(int64_t)plane * surv_cap + sbase + rank] = (int32_t)i;
+        }
+      }
+      __syncthreads();  // the round's tables are reused by the next round
+    }
+  }
+}
+
+// ---- exact sums of the survivors --------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_exact(const uint8_t* __restrict__ d_blur, const float* __restrict__ d_angle,
+                                              const uint32_t* __restrict__ d_bits, int64_t words_per_plane, int h, int w,
+                                              int32_t* __restrict__ d_circles, int64_t circle_cap,
+                                              const uint32_t* __restrict__ d_ukeys, int ntc, int min_r, int max_r,
+                                              const int32_t* __restrict__ d_per_rc, int per_total,
+                                              const double* __restrict__ d_per_expected,
+                                              const int32_t* __restrict__ d_per_starts, float min_roundness,
+                                              int write_skipped, float* __restrict__ d_scores,
+                                              int32_t* __restrict__ d_alive, int32_t* __restrict__ d_num_alive,
+                                              int32_t* __restrict__ d_max_rc, int32_t* __restrict__ d_num_scored,
+                                              const int32_t* __restrict__ d_surv, int64_t surv_cap,
+                                              const int32_t* __restrict__ d_num_surv) {
+  extern __shared__ __attribute__((aligned(16))) int32_t tab[];  // (dr << 16) | (dc & 0xFFFF) per perimeter point
+  const int plane = blockIdx.y;
+  const int64_t n = min((int64_t)d_num_surv[plane], surv_cap);
+  if ((int64_t)blockIdx.x * NT >= n) return;  // block-uniform
+  for (int i = threadIdx.x; i < per_total; i += NT) tab[i] = (d_per_rc[2 * i] << 16) | (d_per_rc[2 * i + 1] & 0xFFFF);
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0 && d_num_scored) d_num_scored[plane] = (int32_t)n;
+  int32_t* circles = d_circles + (int64_t)plane * circle_cap * 3;
+  const uint32_t* ukeys = d_ukeys + (int64_t)plane * circle_cap;
+  const uint32_t* bits = d_bits + plane * words_per_plane;
+  const uint8_t* blur = d_blur + (int64_t)plane * h * w;
+  const float* ang = d_angle ? d_angle + (int64_t)plane * h * w : nullptr;
+  float* scores = d_scores + (int64_t)plane * circle_cap;
+  const double PI = 3.141592653589793, INV_PI = 1.0 / 3.141592653589793;
+  for (int64_t k = (int64_t)blockIdx.x * NT + threadIdx.x; k < n; k += (int64_t)gridDim.x * NT) {
+    const int64_t i = d_surv[(int64_t)plane * surv_cap + k];
+    const uint32_t key = ukeys[i];
+    const int tile = (int)(key >> 17);
+    const int row = (tile / ntc) * TS - max_r + (int)((key >> 6) & 63u), col = (tile % ntc) * TS - max_r + (int)(key & 63u);
+    const int rad = min_r + (int)((key >> 12) & 31u);
+    const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
+    const double floor_sum = (double)min_roundness * (double)(p1 - p0) - 1e-3;
+    // the edge pixels on the perimeter, 32 points per mask word (perimeters <= 160 points), loads batched
+    uint32_t masks[5];
+    int left = 0;  // edge pixels not yet summed: each adds at most 1 (+1.2e-7, inside the margin)
+#pragma unroll
+    for (int wd = 0; wd < 5; ++wd) {
+      uint32_t mask = 0;
+      const int base = p0 + 32 * wd;
+      if (base < p1) {
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) {
+          const int v = tab[min(base + j, p1 - 1)];
+          const int y = row + (v >> 16), x = col + (int)(int16_t)(v & 0xFFFF);
+          const bool inb = base + j < p1 && y >= 0 && y < h && x >= 0 && x < w;
+          const int bi = inb ? y * w + x : 0;
+          const uint32_t wv = bits[bi >> 5];
+          mask |= (inb ? (wv >> (bi & 31)) & 1u : 0u) << j;
+        }
+      }
+      masks[wd] = mask;
+      left += __builtin_popcount(mask);
+    }
+    double acc = 0.0;
+    bool dead = (double)left < floor_sum;
+#pragma unroll
+    for (int wd = 0; wd < 5; ++wd) {
+      uint32_t mask = masks[wd];
+      const int base = p0 + 32 * wd;
+      constexpr int PF = 8;  // angle evaluations in flight
+      while (mask && !dead) {
+        int jj[PF];
+        float an[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          jj[u] = __ffs(mask) - 1;  // -1 once the word's hits are used up
+          mask &= mask - 1;
+          an[u] = 0.0f;
+          if (jj[u] >= 0) {
+            const int v = tab[base + jj[u]];
+            const int y = row + (v >> 16), x = col + (int)(int16_t)(v & 0xFFFF);
+            an[u] = ang ? ang[(int64_t)y * w + x] : mg_edge_angle(blur, h, w, y, x);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          if (jj[u] < 0 || dead) continue;
+          const int p = base + jj[u];
+          double d = fabs((double)an[u] - d_per_expected[p]);
+          if (d > PI) d = d - PI;
+          // x / pi, correctly rounded without the division (Markstein: y = RN(1/pi), q0 = RN(x y),
+          // r = x - q0 pi exactly by FMA, q = RN(q0 + r y) == RN(x / pi); verified against x / pi on 1e9
+          // operands of exactly this form)
+          const double x4 = 4.0 * fabs(d - PI / 2.0);
+          const double q0 = x4 * INV_PI;
+          const double q = fma(fma(-q0, PI, x4), INV_PI, q0);
+          acc += q - 1.0;
+          --left;
+          if (acc + (double)left < floor_sum) dead = true;  // exact: the remaining hits add <= 1 each
+        }
+      }
+    }
+    if (dead) {
+      if (write_skipped) scores[i] = MG_SCORE_SKIPPED;
+      continue;
+    }
+    const float score = (float)acc / (float)(p1 - p0);
+    scores[i] = score;
+    if (score >= min_roundness) {
+      const int k_ = atomicAdd(&d_num_alive[plane], 1);
+      d_alive[(int64_t)plane * circle_cap + k_] = (int32_t)i;
+      circles[3 * i] = row, circles[3 * i + 1] = col, circles[3 * i + 2] = rad;
+      atomicMax(&d_max_rc[2 * plane], row);
+      atomicMax(&d_max_rc[2 * plane + 1], col);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mg_score_keyed_supported(int min_r, int max_r) {
+  return (min_r >= 2 && max_r >= min_r && max_r <= MG_SCORE_MAX_R && max_r - min_r + 1 <= 32) ? 1 : 0;
+}
+
+extern "C" int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angle, const uint32_t* d_edge_bits,
+                                      const uint32_t* d_class_bits, int64_t words_per_plane, int n_planes, int h, int w,
+                                      int32_t* d_circles, int64_t circle_cap, const uint32_t* d_unique_keys,
+                                      const int32_t* d_layer_starts, int min_r, int max_r, const int32_t* d_per_rc,
+                                      const double* d_per_expected, const int32_t* d_per_starts, int per_total,
+                                      const uint64_t* d_pair_table, float min_roundness, int write_skipped,
+                                      float* d_scores, int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc,
+                                      int32_t* d_num_scored, int32_t* d_surv_list, int64_t surv_cap, int32_t* d_num_surv,
+                                      void* stream) {
+  if ((!d_blur && !d_angle) || !d_edge_bits || !d_class_bits || !d_circles || !d_unique_keys || !d_layer_starts ||
+      !d_per_rc || !d_per_expected || !d_per_starts || !d_pair_table || !d_scores || !d_alive || !d_num_alive ||
+      !d_max_rc || !d_surv_list || !d_num_surv)
+    return MG_EINVAL;
+  if (n_planes < 0 || n_planes > 65535 || per_total <= 0 || surv_cap < 0) return MG_EINVAL;
+  if (mg_score_keyed_supported(min_r, max_r) != 1) return MG_EINVAL;
+  if (h <= 0 || w <= 0 || h >= (1 << 24) || w >= (1 << 24) || (int64_t)h * w >= (1LL << 31)) return MG_EINVAL;
+  const int nr = max_r - min_r + 1;
+  int ntr, ntc;
+  int64_t n_layers, words;
+  if (mg_dedup_layout(h, w, min_r, max_r, &ntr, &ntc, &n_layers, &words) != MG_OK) return MG_EINVAL;
+  if ((int64_t)ntr * ntc >= 32768) return MG_EINVAL;  // the 32-bit key
+  if ((size_t)per_total * 4 > 48 * 1024 || 4 * (nr + 1) > NP) return MG_EINVAL;
+  hipStream_t s = mg_stream(stream);
+  if (hipMemsetAsync(d_num_surv, 0, (size_t)std::max(n_planes, 1) * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
+  if (n_planes == 0 || circle_cap == 0) return MG_OK;
+  const int side = ST + 2 * max_r;
+  const size_t lds_bytes = (size_t)WBASE + (((size_t)side * WSTR + 15) & ~(size_t)15) + (size_t)SCAP * 4;
+  const int nsr = (ntr + 1) / 2, nsc = (ntc + 1) / 2, n_st = nsr * nsc;
+  const int64_t total_st = (int64_t)n_st * n_planes;
+  // persistent blocks, super-tiles dealt round-robin (neighbouring super-tiles run at the same time)
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_prefilter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(WBASE + WSTR * WSTR + 16 + SCAP * 4)) != hipSuccess)
+      return MG_ELAUNCH;
+    attr_set = true;
+  }
+  const int blocks = (int)std::min<int64_t>(total_st, 256 * 2 * 8);
+  hipLaunchKernelGGL(k_prefilter, dim3(blocks), dim3(NP), lds_bytes, s, d_edge_bits, d_class_bits, words_per_plane, h, w,
+                     d_unique_keys, circle_cap, d_layer_starts, ntr * ntc, ntr, ntc, nsc, n_st, total_st, min_r, max_r, nr,
+                     reinterpret_cast<const uint2*>(d_pair_table), d_per_starts, min_roundness, write_skipped, d_scores,
+                     d_surv_list, surv_cap, d_num_surv);
+  MG_CHECK_LAUNCH();
+  if (!(write_skipped & 8))
+  hipLaunchKernelGGL(k_exact, dim3(64, n_planes), dim3(NT), (size_t)per_total * 4, s, d_blur, d_angle, d_edge_bits,
+                     words_per_plane, h, w, d_circles, circle_cap, d_unique_keys, ntc, min_r, max_r, d_per_rc, per_total,
+                     d_per_expected, d_per_starts, min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc,
+                     d_num_scored, d_surv_list, surv_cap, d_num_surv);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}

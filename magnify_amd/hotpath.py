@@ -270,7 +270,7 @@ class CircleFinder:
         i32, u8 = torch.int32, torch.uint8
         self.blur = torch.empty((P, h, w), dtype=u8, device=dev)
         self.edges = None  # {0,1} byte map, only with keep_debug_maps
-        self.angle = torch.empty((P, h, w), dtype=torch.float32, device=dev)  # valid at edge pixels
+        self.angle = None  # float32 (P, h, w), valid at edge pixels: only when something reads it (see need_angle_map)
         self.hist = torch.zeros((P, COMBINED_BINS), dtype=i32, device=dev)
         self.hist_base = torch.zeros((P,), dtype=i32, device=dev)
         self._hyst_hint, self._nms_hint = 4, 2  # sweeps / rounds the previous call needed
@@ -284,10 +284,8 @@ class CircleFinder:
         self.words = 2 * ((h * w + 63) // 64) + 2  # bitmap words per plane (even, one spare)
         self.edge_bits = torch.zeros((P, self.words), dtype=i32, device=dev)  # strong bits = edges
         self.weak_bits = torch.zeros((P, self.words), dtype=i32, device=dev)
-        # gradient orientation classes (two bit planes per image plane) for the scoring prefilter;
-        # MG_NO_CLASS_BITS=1 switches the orientation test off (A/B measurements)
-        self.class_bits = (None if os.environ.get("MG_NO_CLASS_BITS") else
-                           torch.zeros((P, 2, self.words), dtype=i32, device=dev))
+        # gradient orientation bins (three bit planes per image plane) for the scoring prefilter
+        self.class_bits = torch.zeros((P, 3, self.words), dtype=i32, device=dev)
         self.keep_debug_maps = False  # True: also produce the {0,1} byte map and the angle map (tests)
         self.cell_counts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
         self.cell_starts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
@@ -319,6 +317,17 @@ class CircleFinder:
         self.per_rc = torch.from_numpy(per_rc).to(dev)
         self.per_exp = torch.from_numpy(per_exp).to(dev)
         self.per_starts = torch.from_numpy(per_starts).to(dev)
+        # keyed scoring (mg_score_circles_keyed: group-per-circle prefilter with orientation bounds, angles on
+        # demand) whenever the radii fit it; else mg_score_circles, which reads the angle map.
+        # MG_OLD_SCORE=1 forces the latter (A/B measurements, parity of the two paths)
+        self.layer_starts = None
+        self.keyed_score = bool(self.keyed and nat.lib().mg_score_keyed_supported(self.min_r, self.max_r) == 1
+                                and not os.environ.get("MG_OLD_SCORE"))
+        if self.keyed_score:
+            self.pair_table = torch.from_numpy(nat.score_pair_table().view(np.int64)).to(dev)
+            self.layer_starts = torch.zeros((P, self.n_tiles, self.max_r - self.min_r + 2), dtype=i32, device=dev)
+            self.surv_list = torch.empty((P, self.cap), dtype=i32, device=dev)
+            self.num_surv = torch.zeros((P,), dtype=i32, device=dev)
         self.nms_grid = None
         self.seeds = torch.zeros((P,), dtype=torch.int64, device=dev)
         self.raw = None
@@ -439,10 +448,18 @@ class CircleFinder:
         self.coord_cap = self.coords.shape[1]
         _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, P, h, w, self.grid, self.cell_counts.data_ptr(),
               self.cell_starts.data_ptr(), self.num_edges.data_ptr(), self.coords.data_ptr(), self.coord_cap, s)
-        _call("mg_edge_angles", self.blur.data_ptr(), P, h, w, self.coords.data_ptr(), self.coord_cap,
-              self.num_edges.data_ptr(), self.angle.data_ptr(), s)
+        if self.need_angle_map():
+            if self.angle is None:
+                self.angle = torch.empty((P, h, w), dtype=torch.float32, device=self.dev)
+            _call("mg_edge_angles", self.blur.data_ptr(), P, h, w, self.coords.data_ptr(), self.coord_cap,
+                  self.num_edges.data_ptr(), self.angle.data_ptr(), s)
         self.n_edges_host = n_edges
         return n_edges
+
+    def need_angle_map(self):
+        """The dense angle map (mg_edge_angles) is only written for the scoring path that reads it or for the
+        tests (keep_debug_maps); the keyed scoring computes the angles of its few exact sums on demand."""
+        return self.keep_debug_maps or not self.keyed_score
 
     # -- stage 2: candidates -> unique integer circles -> scores ------------------------------
     def circle_stage(self, seeds, min_roundness: float, keep_raw=False, dedup_centres=False):
@@ -457,8 +474,8 @@ class CircleFinder:
                   stage="mg_candidate_circles")
             _call("mg_keys_to_circles", self.keys.data_ptr(), self.num_iter, self.cell_starts.data_ptr(),
                   self.cell_counts.data_ptr(), self.num_edges.data_ptr(), P, h, w, self.grid, self.min_r, self.max_r,
-                  self.unique_keys.data_ptr(), self.cap, self.tile_ranges.data_ptr(), self.num_circles.data_ptr(), s,
-                  stage="mg_bitmap_to_circles")
+                  self.unique_keys.data_ptr(), self.cap, self.tile_ranges.data_ptr(), self.num_circles.data_ptr(),
+                  _ptr(self.layer_starts), s, stage="mg_bitmap_to_circles")
             self._tie_keys = self.unique_keys
         else:
             if self.bitmap is None:
@@ -475,6 +492,19 @@ class CircleFinder:
         self.num_alive.zero_()
         self.num_scored.zero_()
         self.max_rc.fill_(-(2**31))
+        if self.keyed_score and self._tie_keys is not None:
+            _call("mg_score_circles_keyed", self.blur.data_ptr(), 0, self.edge_bits.data_ptr(), self.class_bits.data_ptr(),
+                  self.words, P, h, w, self.circles.data_ptr(), self.cap, self.unique_keys.data_ptr(),
+                  self.layer_starts.data_ptr(), self.min_r, self.max_r, self.per_rc.data_ptr(), self.per_exp.data_ptr(),
+                  self.per_starts.data_ptr(), int(self.per_rc.shape[0]), self.pair_table.data_ptr(), float(min_roundness),
+                  int(self.keep_debug_maps) | int(os.environ.get("MG_SCORE_DEBUG", "0")), self.scores.data_ptr(), self.alive.data_ptr(), self.num_alive.data_ptr(),
+                  self.max_rc.data_ptr(), self.num_scored.data_ptr(), self.surv_list.data_ptr(), self.cap,
+                  self.num_surv.data_ptr(), s, stage="mg_score_circles")
+            return
+        if self.angle is None:  # a path switch after the edge stage (tests flip `keyed`): the map is needed after all
+            self.angle = torch.empty((P, h, w), dtype=torch.float32, device=self.dev)
+            _call("mg_edge_angles", self.blur.data_ptr(), P, h, w, self.coords.data_ptr(), self.coord_cap,
+                  self.num_edges.data_ptr(), self.angle.data_ptr(), s)
         _call("mg_score_circles", self.angle.data_ptr(), self.edge_bits.data_ptr(), _ptr(self.class_bits), self.words, P, h, w,
               self.circles.data_ptr(), self.cap, _ptr(self.layer_offsets), _ptr(self._tie_keys),
               _ptr(self.tile_ranges if self._tie_keys is not None else None), self.min_r, self.max_r,

@@ -477,3 +477,38 @@ def test_filter_nonround_border_lengths_and_component():
     roundness = 4 * np.pi * disk.sum() / outer_border_length(disk) ** 2
     assert 0.85 < roundness < 1.0
     assert mg.components.get("filter_nonround")(min_roundness=0.95)(xp).valid.values[0, 0] == False  # noqa: E712
+
+
+def test_score_pair_table_bounds_every_term():
+    """mg_score_pair_table (host side of the keyed scoring prefilter): the perimeter of every radius as pairs of
+    opposite points -- together exactly the reference's circle_points set -- and, for every pair and every
+    orientation bin, a signed byte that is an upper bound (1/64) of mean_grad's term 4 |d - pi/2| / pi - 1
+    (utils.py:244-249) for ANY gradient angle whose orientation lies in the bin, at either point of the pair."""
+    from magnify_amd import _native as nat
+
+    table = nat.score_pair_table()
+    assert table.shape == (27, 80)
+    rng = np.random.default_rng(0)
+    for r in range(2, 27):
+        firsts = nat.score_pairs(r)
+        n = len(firsts)
+        rc, expected, _ = nat.perimeter_table(r, r)
+        assert 2 * n == len(rc) <= 160
+        both = np.concatenate([firsts, -firsts])
+        assert {tuple(p) for p in both} == {tuple(p) for p in rc} and len({tuple(p) for p in both}) == 2 * n
+        q = table[r, :n].view(np.int8).reshape(n, 8).astype(np.int64)
+        assert (table[r, n:] == 0).all() and q.min() >= -48 and q.max() <= 64
+        for sign in (1, -1):
+            exp = np.arctan2(sign * firsts[:, 0].astype(np.float64), sign * firsts[:, 1].astype(np.float64))
+            for b in range(8):
+                # angles (either sign of the gradient) whose orientation falls into bin b, boundaries included
+                phi = np.concatenate([np.linspace(b, b + 1, 41) * np.pi / 8, rng.uniform(b, b + 1, 200) * np.pi / 8])
+                for ang in (phi, phi - np.pi):
+                    d = np.abs(ang[None, :].astype(np.float32).astype(np.float64) - exp[:, None])
+                    d = np.where(d > np.pi, d - np.pi, d)
+                    term = 4 * np.abs(d - np.pi / 2) / np.pi - 1
+                    ub = q[:, b, None] / 64.0
+                    # (+2e-7: float32 angles at +-pi give terms of 1 + 1.1e-7 in the reference's own formula; the
+                    # prefilter's threshold carries a 1e-3 margin for exactly this kind of rounding)
+                    assert (term <= ub + 2e-7).all()
+                    assert (ub - term.max(axis=1, keepdims=True) <= 1 / 64 + 1e-5).all()  # and not uselessly loose

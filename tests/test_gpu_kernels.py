@@ -204,6 +204,14 @@ def test_edge_stage(hp, quantiles):
         on_b = ~interior & ((idx != 0) | (idy != 0))
         near = np.round(phi / (np.pi / 4)).astype(np.int64) % 4  # the boundary index k: classes k-1 and k
         assert np.all((got[on_b] == near[on_b]) | (got[on_b] == (near[on_b] - 1) % 4))
+        # third plane: the half of the quarter -> bins of pi/8 (never ambiguous off the quarter boundaries:
+        # tan(pi/8), tan(3 pi/8) are irrational), bin = 2 * quarter + c2
+        c2 = np.unpackbits(cb[2].view(np.uint8), bitorder="little")[: h * w].reshape(h, w)
+        want_bin = np.floor(phi / (np.pi / 8)).astype(np.int64)
+        np.testing.assert_array_equal((4 * c1 + 2 * c0 + c2)[interior], want_bin[interior])
+        got_bin = (4 * c1 + 2 * c0 + c2).astype(np.int64)
+        near8 = np.round(phi / (np.pi / 8)).astype(np.int64) % 8
+        assert np.all((got_bin[on_b] == near8[on_b]) | (got_bin[on_b] == (near8[on_b] - 1) % 8))
         # angle map: sentinel off-edge; on edges the correctly rounded float32 arctan2, which is
         # within 2 ulp of NumPy's SIMD float32 arctan2 (itself not correctly rounded: e.g.
         # arctan2(-1, 1) comes out 1 ulp above float32(-pi/4) on AVX-512 hosts)
@@ -235,16 +243,21 @@ def test_edge_stage_empty_and_tiny(hp):
 # ---------------------------------------------------------------------------------------------
 
 
-@pytest.mark.parametrize("keyed", [True, False])
-def test_candidates_scores_nms(hp, keyed):
-    """keyed: de-duplication by 32-bit keys and per-tile LDS bitmaps (no global atomics);
-    not keyed: atomicOr into the global bitmap.  Same unique circle list either way."""
+@pytest.mark.parametrize("path", ["keyed", "keyed_tile_score", "atomic"])
+def test_candidates_scores_nms(hp, path):
+    """keyed: de-duplication by 32-bit keys and per-tile LDS bitmaps (no global atomics), scoring by
+    mg_score_circles_keyed (group-per-circle prefilter with orientation bounds, angles on demand);
+    keyed_tile_score: same keys, scored by mg_score_circles (lane-per-circle prefilter, angle map);
+    atomic: atomicOr into the global bitmap + mg_score_circles.  Same unique circle list, same scores for
+    every circle that can pass, same suppression result on all three."""
+    keyed = path != "atomic"
     planes = _edge_images()
     p, h, w = planes.shape
     min_r, max_r, num_iter, min_dist = 5, 14, 20000, 5
     cf = hp.CircleFinder(p, h, w, min_r, max_r, num_iter)
-    assert cf.keyed
+    assert cf.keyed and cf.keyed_score
     cf.keyed = keyed
+    cf.keyed_score = path == "keyed"
     cf.keep_debug_maps = True
     seeds = [11, 12, 13]
     res, _ = cf.find(dev(planes), None, 0.1, 0.9, 0.3, min_dist, seeds, keep_raw=True)
