@@ -9,13 +9,15 @@
 
 #define MG_WAVE 64
 
-// Keyed scoring prefilter (mg_score.hip): super-tiles of 2 x 2 centre tiles (128 x 128 positions) with their
-// edge window as bytes in LDS, row stride 180 B = 45 dwords (odd: rows rotate through the banks); radii up to
-// MG_SCORE_MAX_R (window side 128 + 2 * 26 = 180), perimeters up to 2 * MG_SCORE_MAX_PAIRS points.
+// Keyed scoring prefilter (mg_score.hip): super-tiles of MG_SCORE_SUBY x MG_SCORE_SUBX centre tiles (128 x 256
+// positions) with their edge window as bytes in LDS, row stride 308 B = 77 dwords (odd: rows rotate through the
+// banks); radii up to MG_SCORE_MAX_R (window 180 x 308), perimeters up to 2 * MG_SCORE_MAX_PAIRS points.
 #define MG_SCORE_TILE 64
+#define MG_SCORE_SUBY 2
+#define MG_SCORE_SUBX 4
 #define MG_SCORE_MAX_R 26
 #define MG_SCORE_MAX_PAIRS 80
-#define MG_SCORE_WSTRIDE 180
+#define MG_SCORE_WSTRIDE (MG_SCORE_TILE * MG_SCORE_SUBX + 2 * MG_SCORE_MAX_R)
 
 #define MG_CHECK_LAUNCH()                          \
   do {                                             \

@@ -30,7 +30,8 @@ namespace {
 constexpr int NT = 256;
 constexpr int NP = 512;  // prefilter block: 8 waves share a window (4 blocks per CU by LDS: 32 waves per CU)
 constexpr int TS = MG_SCORE_TILE;
-constexpr int ST = 2 * TS;
+constexpr int SUBY = MG_SCORE_SUBY, SUBX = MG_SCORE_SUBX, NSUB = SUBY * SUBX;  // centre tiles per super-tile
+constexpr int STY = SUBY * TS, STX = SUBX * TS;
 constexpr int WSTR = MG_SCORE_WSTRIDE;
 constexpr int MAXR = MG_SCORE_MAX_R;
 constexpr int MAXP = MG_SCORE_MAX_PAIRS;
@@ -38,7 +39,8 @@ constexpr int BIAS = MAXR * WSTR + MAXR;  // immediates BIAS +- (dr * WSTR + dc)
 constexpr int WBASE = 8192;               // LDS byte offset of the window (>= BIAS: lane addresses stay >= 0)
 constexpr int SEGW = 33;                  // radii + 1 per sub-tile in the segment table
 static_assert(WBASE >= BIAS && WBASE % 16 == 0, "window base");
-static_assert(ST + 2 * MAXR <= WSTR && (WSTR % 4) == 0 && ((WSTR / 4) & 1) == 1, "window stride");
+static_assert(STX + 2 * MAXR <= WSTR && (WSTR % 4) == 0 && ((WSTR / 4) & 1) == 1, "window stride");
+static_assert(2 * BIAS < 65536, "DS immediates are 16 bits");
 
 __device__ __forceinline__ uint32_t bits_at(const uint32_t* __restrict__ bits, int64_t bit0, int n) {
   const int64_t wi = bit0 >> 5;
@@ -109,11 +111,11 @@ __device__ __forceinline__ int score_r(const uint8_t* lds, int vaddr, const uint
 }
 
 // ---- prefilter ----------------------------------------------------------------------------------------
-// LDS: [0, WBASE) small tables, [WBASE, +side * WSTR) the window, then SCAP sorted circle entries.
-constexpr int NBK = 32 * 32;   // (radius, bank class) buckets
-constexpr int SCAP = 6144;     // circles sorted per round (a super-tile holds ~3000 on noisy images)
-constexpr int KPT = SCAP / NP; // keys per thread and round
-static_assert(NBK * 4 + 512 <= WBASE, "small tables");
+// LDS: [0, WBASE) small tables, [WBASE, +side_y * WSTR) the window.
+static_assert((NSUB * SEGW + SEGW + 32 + 8) * 4 <= WBASE, "small tables");
+
+// bits 0..3 of x -> bit 0 of bytes 0..3
+__device__ __forceinline__ uint32_t spread4(uint32_t x) { return ((x & 0xFu) * 0x00204081u) & 0x01010101u; }
 
 __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d_bits, const uint32_t* __restrict__ d_class,
                                                   int64_t words_per_plane, int h, int w,
@@ -126,14 +128,12 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
                                                   int32_t* __restrict__ d_surv, int64_t surv_cap,
                                                   int32_t* __restrict__ d_num_surv) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  int32_t* cursor = reinterpret_cast<int32_t*>(lds);  // [NBK]: count, then start, then end of every bucket
-  int32_t* chunk0 = cursor + NBK;                     // [nr + 1]: first chunk (wave) of radius rho
-  int32_t* need = chunk0 + SEGW;                      // [nr]: threshold on the sum of bounds (1/64)
-  int32_t* lfirst = need + 32;                        // [4] + [4]: first key / number of keys of the four sub-tiles
-  int32_t* next = lfirst + 8;                         // the block's chunk counter
+  int32_t* seg = reinterpret_cast<int32_t*>(lds);  // [NSUB][SEGW]: index of the first key of radius rho in sub-tile s
+  int32_t* chunk0 = seg + NSUB * SEGW;             // [nr + 1]: first chunk of radius rho
+  int32_t* need = chunk0 + SEGW;                   // [nr]: threshold on the sum of bounds (1/64)
+  int32_t* next = need + 32;                       // the block's chunk counter
   uint8_t* win = lds + WBASE;
-  const int side = ST + 2 * max_r;
-  uint32_t* skeys = reinterpret_cast<uint32_t*>(lds + WBASE + ((side * WSTR + 15) & ~15));  // [SCAP]
+  const int side_y = STY + 2 * max_r, side_x = STX + 2 * max_r;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < nr; i += NP) {
     const int len = d_per_starts[i + 1] - d_per_starts[i];
@@ -141,38 +141,36 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
     // real sum), and sum(terms) <= sum(bounds) / 64
     need[i] = (int)ceil(64.0 * ((double)min_roundness * len - 1e-3));
   }
-  const int wgroups = (side + 31) >> 5;  // 32-pixel groups per window row
+  const int wgroups = (side_x + 31) >> 5;  // 32-pixel groups per window row
   for (int64_t st = blockIdx.x; st < total_st; st += gridDim.x) {
     const int plane = (int)(st / n_st), sidx = (int)(st - (int64_t)plane * n_st);
     const int sr = sidx / nsc, sc = sidx - sr * nsc;
     __syncthreads();  // the previous super-tile's window and tables are no longer read
-    if (threadIdx.x < 4) {  // the four sub-tiles' key lists (mg_keys_to_circles: sorted by radius, row, column)
-      const int tr = 2 * sr + (threadIdx.x >> 1), tc = 2 * sc + (threadIdx.x & 1);
-      int a = 0, b = 0;
-      if (tr < ntr && tc < ntc) {
-        const int32_t* ls = d_layer_starts + ((int64_t)plane * n_tiles + tr * ntc + tc) * (nr + 1);
-        a = ls[0];
-        b = ls[nr];
-      }
-      lfirst[threadIdx.x] = a;
-      lfirst[4 + threadIdx.x] = max(b - a, 0);
+    // ---- segment table: first key of every radius in the sub-tiles' sorted lists (mg_keys_to_circles) ----
+    if ((int)threadIdx.x < NSUB * (nr + 1)) {
+      const int s = threadIdx.x / (nr + 1), q = threadIdx.x - s * (nr + 1);
+      const int tr = SUBY * sr + s / SUBX, tc = SUBX * sc + s % SUBX;
+      int v = 0;
+      if (tr < ntr && tc < ntc) v = d_layer_starts[((int64_t)plane * n_tiles + tr * ntc + tc) * (nr + 1) + q];
+      seg[s * SEGW + q] = v;  // a sub-tile beyond the grid: all zero = empty
     }
+    if (threadIdx.x == 0) *next = 0;
     // ---- the window: orientation bin of every edge pixel, 0x0C elsewhere.  All loads of a thread's (at most
     // WI) 32-pixel groups are issued before the first is used: the block would otherwise wait for two to four
     // global round trips per group, one after the other ----
-    const int wy0 = sr * ST - 2 * max_r, wx0 = sc * ST - 2 * max_r;
-    {
+    const int wy0 = sr * STY - 2 * max_r, wx0 = sc * STX - 2 * max_r;
+    if (!(write_skipped & 4)) {
       const uint32_t* pl[4] = {d_bits + plane * words_per_plane, d_class + (3 * plane) * words_per_plane,
                                d_class + (3 * plane + 1) * words_per_plane, d_class + (3 * plane + 2) * words_per_plane};
-      constexpr int WI = 3;  // side * wgroups <= 180 * 6 <= WI * NP
+      constexpr int WI = ((STY + 2 * MAXR) * ((WSTR + 31) / 32) + NP - 1) / NP;
       uint32_t lo[WI][4], hi[WI][4];
 #pragma unroll
       for (int it = 0; it < WI; ++it) {
         const int i = threadIdx.x + it * NP;
         const int j = i / wgroups, k = i - j * wgroups;
         const int y = wy0 + j, xs = wx0 + 32 * k;
-        const int x_lo = max(xs, 0), x_hi = min(min(xs + 32, wx0 + side), w);
-        const bool live = i < side * wgroups && y >= 0 && y < h && x_lo < x_hi;
+        const int x_lo = max(xs, 0), x_hi = min(min(xs + 32, wx0 + side_x), w);
+        const bool live = i < side_y * wgroups && y >= 0 && y < h && x_lo < x_hi;
         const int64_t wi = live ? ((int64_t)y * w + x_lo) >> 5 : 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -183,10 +181,10 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
 #pragma unroll
       for (int it = 0; it < WI; ++it) {
         const int i = threadIdx.x + it * NP;
-        if (i >= side * wgroups) break;
+        if (i >= side_y * wgroups) break;
         const int j = i / wgroups, k = i - j * wgroups;
         const int y = wy0 + j, xs = wx0 + 32 * k;
-        const int x_lo = max(xs, 0), x_hi = min(min(xs + 32, wx0 + side), w);
+        const int x_lo = max(xs, 0), x_hi = min(min(xs + 32, wx0 + side_x), w);
         uint32_t pv[4] = {0u, 0u, 0u, 0u};  // edge bit, c0, c1, c2 of the group's 32 pixels
         if (y >= 0 && y < h && x_lo < x_hi) {
           const int sh = (int)(((int64_t)y * w + x_lo) & 31), n = x_hi - x_lo;
@@ -200,103 +198,70 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           if (q >= nd) break;
-          uint32_t out = 0x0C0C0C0Cu;
-          if ((pv[0] >> (4 * q)) & 0xFu) {
-            out = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const int bit = 4 * q + b;
-              const uint32_t bin = (((pv[2] >> bit) & 1u) << 2) | (((pv[1] >> bit) & 1u) << 1) | ((pv[3] >> bit) & 1u);
-              out |= (((pv[0] >> bit) & 1u) ? bin : 0x0Cu) << (8 * b);
-            }
-          }
-          rowp[q] = out;
+          // four pixels -> four bytes: bin = 4 c1 + 2 c0 + c2 where the pixel is an edge, else 0x0C
+          const uint32_t bins = 4u * spread4(pv[2] >> (4 * q)) + 2u * spread4(pv[1] >> (4 * q)) + spread4(pv[3] >> (4 * q));
+          const uint32_t m = spread4(pv[0] >> (4 * q)) * 0xFFu;
+          rowp[q] = (bins & m) | (0x0C0C0C0Cu & ~m);
         }
       }
     }
     const uint32_t* ukeys = d_ukeys + (int64_t)plane * circle_cap;
     __syncthreads();
-    const int n0 = lfirst[4], n1 = lfirst[5], n2 = lfirst[6], n3 = lfirst[7];
-    const int f0 = lfirst[0], f1 = lfirst[1], f2 = lfirst[2], f3 = lfirst[3];
-    const int n_all = n0 + n1 + n2 + n3;
-    // Rounds of at most SCAP circles (one round on noisy images).  A round sorts its circles by (radius, bank
-    // class of the centre's window dword) in LDS and deals every radius to half-waves so that the 32 lanes of a
-    // half-wave sit on different LDS banks: a perimeter read then takes one or two LDS cycles per half-wave
-    // instead of the ~4 of 32 random dwords, and the walk is bound by exactly those cycles.
-    for (int base = 0; base < n_all; base += SCAP) {
-      const int n_round = min(SCAP, n_all - base);
-      for (int i = threadIdx.x; i < NBK; i += NP) cursor[i] = 0;
-      if (threadIdx.x == 0) *next = 0;
-      __syncthreads();
-      // -- keys of the round: bucket = radius * 32 + bank class; rank within the bucket from the LDS counter --
-      uint32_t ent[KPT];
-      int bkt[KPT], rnk[KPT];
+    if (wave == 0) {  // chunks of 64 circles per radius
+      int cnt = 0;
+      if (lane < nr)
+        for (int s = 0; s < NSUB; ++s) cnt += seg[s * SEGW + lane + 1] - seg[s * SEGW + lane];
+      const int chunks = (cnt + 63) >> 6;
+      const int incl = mg_wave_scan_incl_i32(chunks);
+      if (lane < nr) chunk0[lane] = incl - chunks;
+      if (lane == nr - 1) chunk0[nr] = incl;
+    }
+    __syncthreads();
+    const int total_chunks = chunk0[nr];
+    // Chunk loop, software-pipelined: the keys of the NEXT chunk are requested before the current chunk is
+    // scored (a wave's chunks are otherwise one global round trip each).
+    int rho_n = 0, s_n = 0;
+    int64_t i_n = 0;
+    bool valid_n = false;
+    uint32_t key_n = 0;
+    auto fetch = [&]() -> bool {
+      int c = 0;
+      if (lane == 0) c = atomicAdd(next, 1);
+      c = __builtin_amdgcn_readfirstlane(c);
+      if (c >= total_chunks) return false;
+      // the chunk's radius: the last rho with chunk0[rho] <= c (empty radii share their successor's start)
+      rho_n = __builtin_popcountll(__ballot(lane < nr && chunk0[lane] <= c)) - 1;
+      int m = 64 * (c - chunk0[rho_n]) + lane;  // position in the concatenation of the sub-tiles' segments of rho
+      s_n = -1;
 #pragma unroll
-      for (int u = 0; u < KPT; ++u) {
-        const int m = base + threadIdx.x + u * NP;  // position in the concatenation of the four lists
-        const bool live = m < base + n_round;
-        const int sub = live ? (m >= n0) + (m >= n0 + n1) + (m >= n0 + n1 + n2) : 0;
-        const int off = m - (sub == 0 ? 0 : sub == 1 ? n0 : sub == 2 ? n0 + n1 : n0 + n1 + n2);
-        const int fs = sub == 0 ? f0 : sub == 1 ? f1 : sub == 2 ? f2 : f3;
-        const uint32_t key = ukeys[live ? (int64_t)fs + off : 0];
-        // entry: off << 14 | sub << 12 | row << 6 | col (off < 2^18: a tile holds at most 64 * 64 * 32 circles)
-        ent[u] = ((uint32_t)off << 14) | ((uint32_t)sub << 12) | (key & 0xFFFu);
-        const int wrow = (sub >> 1) * TS + (int)((key >> 6) & 63u) + max_r, wcol = (sub & 1) * TS + (int)(key & 63u) + max_r;
-        bkt[u] = live ? (int)((key >> 12) & 31u) * 32 + ((13 * wrow + (wcol >> 2)) & 31) : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < KPT; ++u) rnk[u] = bkt[u] >= 0 ? atomicAdd(&cursor[bkt[u]], 1) : 0;
-      __syncthreads();
-      {  // exclusive prefix over the buckets (two per thread)
-        const int a = cursor[2 * threadIdx.x], b = cursor[2 * threadIdx.x + 1];
-        int total;
-        const int ex = mg_block_exscan(a + b, &total);
-        cursor[2 * threadIdx.x] = ex;
-        cursor[2 * threadIdx.x + 1] = ex + a;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < KPT; ++u)
-        if (bkt[u] >= 0) skeys[cursor[bkt[u]] + rnk[u]] = ent[u];
-      __syncthreads();
-      // -- waves per radius: radius rho owns sorted positions [rs, re); H = ceil(n / 32) half-waves --
-      if (wave == 0) {
-        int waves = 0;
-        if (lane < nr) {
-          const int rs = cursor[32 * lane], re = lane + 1 < 32 ? cursor[32 * lane + 32] : n_round;
-          waves = (((re - rs) + 31) / 32 + 1) / 2;
+      for (int s = 0; s < NSUB; ++s) {
+        const int a = seg[s * SEGW + rho_n], cnt = seg[s * SEGW + rho_n + 1] - a;
+        if (s_n < 0) {
+          if (m < cnt) {
+            s_n = s;
+            i_n = (int64_t)a + m;
+          } else {
+            m -= cnt;
+          }
         }
-        const int incl = mg_wave_scan_incl_i32(waves);
-        if (lane < nr) chunk0[lane] = incl - waves;
-        if (lane == nr - 1) chunk0[nr] = incl;
       }
-      __syncthreads();
-      const int total_chunks = chunk0[nr];
-      for (;;) {
-        int c = 0;
-        if (lane == 0) c = atomicAdd(next, 1);
-        c = __builtin_amdgcn_readfirstlane(c);
-        if (c >= total_chunks) break;
-        // the chunk's radius: the last rho with chunk0[rho] <= c (radii without circles share their successor's start)
-        const int rho = __builtin_popcountll(__ballot(lane < nr && chunk0[lane] <= c)) - 1;
-        const int j = c - chunk0[rho];
-        const int rs = cursor[32 * rho], re = rho + 1 < 32 ? cursor[32 * rho + 32] : n_round;
-        const int n_r = re - rs, hw_n = (n_r + 31) >> 5;
-        // half-wave hw takes the sorted positions hw, hw + H, hw + 2 H, ...: one circle per bank class (two where
-        // a class holds more than H circles)
-        const int hw = 2 * j + (lane >> 5), p = hw + hw_n * (lane & 31);
-        const bool valid = hw < hw_n && p < n_r;
-        const uint32_t e = skeys[valid ? rs + p : 0];
-        const int sub = (int)((e >> 12) & 3u);
-        const int wrow = (sub >> 1) * TS + (int)((e >> 6) & 63u) + max_r, wcol = (sub & 1) * TS + (int)(e & 63u) + max_r;
-        const int vaddr = WBASE + wrow * WSTR + wcol - BIAS;
-        int sum = 0;
-        if (!(write_skipped & 2))
-#ifdef MG_DBG_ONE_RADIUS
-        switch (14) {
-#else
+      valid_n = s_n >= 0;
+      if (!valid_n) s_n = 0, i_n = 0;
+      key_n = ukeys[i_n];  // (an idle lane reads a valid address: no branch around the load)
+      return true;
+    };
+    bool have = fetch();
+    while (have) {
+      const int rho = rho_n, s = s_n;
+      const int64_t i = i_n;
+      const bool valid = valid_n;
+      const uint32_t key = valid ? key_n : 0u;
+      have = fetch();
+      const int wrow = (s / SUBX) * TS + (int)((key >> 6) & 63u) + max_r, wcol = (s % SUBX) * TS + (int)(key & 63u) + max_r;
+      const int vaddr = WBASE + wrow * WSTR + wcol - BIAS;
+      int sum = 0;
+      if (!(write_skipped & 2))
         switch (rho + min_r) {
-#endif
 #define MG_CASE(R) case R: sum = score_r<R>(lds, vaddr, d_tabs); break;
           MG_CASE(2) MG_CASE(3) MG_CASE(4) MG_CASE(5) MG_CASE(6) MG_CASE(7) MG_CASE(8) MG_CASE(9) MG_CASE(10)
           MG_CASE(11) MG_CASE(12) MG_CASE(13) MG_CASE(14) MG_CASE(15) MG_CASE(16) MG_CASE(17) MG_CASE(18)
@@ -304,19 +269,16 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
 #undef MG_CASE
           default: break;
         }
-        const bool pass = valid && sum >= need[rho];
-        const int64_t i = (int64_t)lfirst[sub] + (int)(e >> 14);  // the circle's index in the plane's key list
-        if ((write_skipped & 1) && valid && !pass) d_scores[(int64_t)plane * circle_cap + i] = MG_SCORE_SKIPPED;
-        const uint64_t pm = __ballot(pass);
-        if (pm) {  // rare: append the survivors to the plane's list
-          int sbase = 0;
-          if (lane == 0) sbase = atomicAdd(&d_num_surv[plane], __builtin_popcountll(pm));
-          sbase = __builtin_amdgcn_readfirstlane(sbase);
-          const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-          if (pass && (int64_t)sbase + rank < surv_cap) d_surv[(int64_t)plane * surv_cap + sbase + rank] = (int32_t)i;
-        }
+      const bool pass = valid && sum >= need[rho];
+      if ((write_skipped & 1) && valid && !pass) d_scores[(int64_t)plane * circle_cap + i] = MG_SCORE_SKIPPED;
+      const uint64_t pm = __ballot(pass);
+      if (pm) {  // rare: append the survivors to the plane's list
+        int sbase = 0;
+        if (lane == 0) sbase = atomicAdd(&d_num_surv[plane], __builtin_popcountll(pm));
+        sbase = __builtin_amdgcn_readfirstlane(sbase);
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+        if (pass && (int64_t)sbase + rank < surv_cap) d_surv[(int64_t)plane * surv_cap + sbase + rank] = (int32_t)i;
       }
-      __syncthreads();  // the round's tables are reused by the next round
     }
   }
 }
@@ -459,22 +421,21 @@ extern "C" int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angl
   int64_t n_layers, words;
   if (mg_dedup_layout(h, w, min_r, max_r, &ntr, &ntc, &n_layers, &words) != MG_OK) return MG_EINVAL;
   if ((int64_t)ntr * ntc >= 32768) return MG_EINVAL;  // the 32-bit key
-  if ((size_t)per_total * 4 > 48 * 1024 || 4 * (nr + 1) > NP) return MG_EINVAL;
+  if ((size_t)per_total * 4 > 48 * 1024 || NSUB * (nr + 1) > NP) return MG_EINVAL;
   hipStream_t s = mg_stream(stream);
   if (hipMemsetAsync(d_num_surv, 0, (size_t)std::max(n_planes, 1) * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
-  const int side = ST + 2 * max_r;
-  const size_t lds_bytes = (size_t)WBASE + (((size_t)side * WSTR + 15) & ~(size_t)15) + (size_t)SCAP * 4;
-  const int nsr = (ntr + 1) / 2, nsc = (ntc + 1) / 2, n_st = nsr * nsc;
+  const size_t lds_bytes = (size_t)WBASE + (size_t)(STY + 2 * max_r) * WSTR;
+  const int nsr = (ntr + SUBY - 1) / SUBY, nsc = (ntc + SUBX - 1) / SUBX, n_st = nsr * nsc;
   const int64_t total_st = (int64_t)n_st * n_planes;
-  // persistent blocks, super-tiles dealt round-robin (neighbouring super-tiles run at the same time)
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_prefilter), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(WBASE + WSTR * WSTR + 16 + SCAP * 4)) != hipSuccess)
+                            (int)(WBASE + (STY + 2 * MAXR) * WSTR)) != hipSuccess)
       return MG_ELAUNCH;
     attr_set = true;
   }
+  // persistent blocks, super-tiles dealt round-robin (neighbouring super-tiles run at the same time)
   const int blocks = (int)std::min<int64_t>(total_st, 256 * 2 * 8);
   hipLaunchKernelGGL(k_prefilter, dim3(blocks), dim3(NP), lds_bytes, s, d_edge_bits, d_class_bits, words_per_plane, h, w,
                      d_unique_keys, circle_cap, d_layer_starts, ntr * ntc, ntr, ntc, nsc, n_st, total_st, min_r, max_r, nr,
