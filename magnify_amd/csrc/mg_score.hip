@@ -277,13 +277,32 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
         if (lane == 0) sbase = atomicAdd(&d_num_surv[plane], __builtin_popcountll(pm));
         sbase = __builtin_amdgcn_readfirstlane(sbase);
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-        if (pass && (int64_t)sbase + rank < surv_cap) d_surv[(int64_t)plane * surv_cap + sbase + rank] = (int32_t)i;
+        if (pass && (int64_t)sbase + rank < surv_cap)
+          reinterpret_cast<int2*>(d_surv)[(int64_t)plane * surv_cap + sbase + rank] = make_int2((int32_t)i, (int32_t)key);
       }
     }
   }
 }
 
 // ---- exact sums of the survivors --------------------------------------------------------------------
+// 16 lanes per survivor (4 survivors per wave): the reference's sum is sequential, but finding the edge pixels on
+// the perimeter and evaluating their gradient angles is not -- with one lane per survivor a wave ran as long as
+// its largest circle's ~100 angle evaluations, one global round trip each.
+//   1. lane t tests the perimeter points t, t + 16, ...; the group's hits are compacted, in perimeter order, into
+//      an LDS list;
+//   2. in passes of 16 hits: every lane evaluates one hit's angle and term, then the 16 terms are added in order
+//      (lane by lane, broadcast over the group) into the float64 sum every lane of the group carries -- with the
+//      reference's early exit: once sum + remaining hits cannot reach the threshold the circle is dropped.
+constexpr int XG = 16;               // lanes per survivor
+constexpr int XPTS = 2 * MAXP / XG;  // perimeter points per lane at most (10)
+
+template <int T>
+__device__ __forceinline__ double group_bcast(double v) {  // lane T of every row of 16 to the whole row
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + T, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + T, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(NT) void k_exact(const uint8_t* __restrict__ d_blur, const float* __restrict__ d_angle,
                                               const uint32_t* __restrict__ d_bits, int64_t words_per_plane, int h, int w,
                                               int32_t* __restrict__ d_circles, int64_t circle_cap,
@@ -296,90 +315,107 @@ __global__ __launch_bounds__(NT) void k_exact(const uint8_t* __restrict__ d_blur
                                               int32_t* __restrict__ d_max_rc, int32_t* __restrict__ d_num_scored,
                                               const int32_t* __restrict__ d_surv, int64_t surv_cap,
                                               const int32_t* __restrict__ d_num_surv) {
-  extern __shared__ __attribute__((aligned(16))) int32_t tab[];  // (dr << 16) | (dc & 0xFFFF) per perimeter point
+  extern __shared__ __attribute__((aligned(16))) double expd[];  // [per_total] expected angles, then [per_total] packed (dr, dc)
+  __shared__ uint16_t hits[NT / XG][2 * MAXP];                    // per group: the perimeter indices of its hits, in order
+  __shared__ int32_t starts[34];
   const int plane = blockIdx.y;
   const int64_t n = min((int64_t)d_num_surv[plane], surv_cap);
-  if ((int64_t)blockIdx.x * NT >= n) return;  // block-uniform
-  for (int i = threadIdx.x; i < per_total; i += NT) tab[i] = (d_per_rc[2 * i] << 16) | (d_per_rc[2 * i + 1] & 0xFFFF);
+  constexpr int GPB = NT / XG;  // survivors per block and pass
+  if ((int64_t)blockIdx.x * GPB >= n) return;  // block-uniform
+  int32_t* tab = reinterpret_cast<int32_t*>(expd + per_total);  // (dr << 16) | (dc & 0xFFFF)
+  for (int i = threadIdx.x; i < per_total; i += NT) {
+    tab[i] = (d_per_rc[2 * i] << 16) | (d_per_rc[2 * i + 1] & 0xFFFF);
+    expd[i] = d_per_expected[i];
+  }
+  if ((int)threadIdx.x <= max_r - min_r + 1) starts[threadIdx.x] = d_per_starts[threadIdx.x];
   __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0 && d_num_scored) d_num_scored[plane] = (int32_t)n;
   int32_t* circles = d_circles + (int64_t)plane * circle_cap * 3;
-  const uint32_t* ukeys = d_ukeys + (int64_t)plane * circle_cap;
   const uint32_t* bits = d_bits + plane * words_per_plane;
   const uint8_t* blur = d_blur + (int64_t)plane * h * w;
   const float* ang = d_angle ? d_angle + (int64_t)plane * h * w : nullptr;
   float* scores = d_scores + (int64_t)plane * circle_cap;
   const double PI = 3.141592653589793, INV_PI = 1.0 / 3.141592653589793;
-  for (int64_t k = (int64_t)blockIdx.x * NT + threadIdx.x; k < n; k += (int64_t)gridDim.x * NT) {
-    const int64_t i = d_surv[(int64_t)plane * surv_cap + k];
-    const uint32_t key = ukeys[i];
+  const int g = threadIdx.x / XG, t = threadIdx.x % XG, lane = threadIdx.x & 63;
+  uint16_t* my_hits = hits[g];
+  // every group of the wave runs the same number of rounds (the loops below hold wave-wide operations)
+  const int64_t rounds = (n + (int64_t)gridDim.x * GPB - 1) / ((int64_t)gridDim.x * GPB);
+  for (int64_t rd = 0; rd < rounds; ++rd) {
+    const int64_t k = (rd * gridDim.x + blockIdx.x) * GPB + g;
+    const bool active = k < n;
+    // record = (index in the plane's key list, key): written by the prefilter, no dependent load here
+    const int2 rec = active ? reinterpret_cast<const int2*>(d_surv)[(int64_t)plane * surv_cap + k] : make_int2(0, 0);
+    const int64_t i = rec.x;
+    const uint32_t key = (uint32_t)rec.y;
     const int tile = (int)(key >> 17);
     const int row = (tile / ntc) * TS - max_r + (int)((key >> 6) & 63u), col = (tile % ntc) * TS - max_r + (int)(key & 63u);
     const int rad = min_r + (int)((key >> 12) & 31u);
-    const int p0 = d_per_starts[rad - min_r], p1 = d_per_starts[rad - min_r + 1];
+    const int p0 = starts[rad - min_r], p1 = active ? starts[rad - min_r + 1] : p0;
     const double floor_sum = (double)min_roundness * (double)(p1 - p0) - 1e-3;
-    // the edge pixels on the perimeter, 32 points per mask word (perimeters <= 160 points), loads batched
-    uint32_t masks[5];
-    int left = 0;  // edge pixels not yet summed: each adds at most 1 (+1.2e-7, inside the margin)
+    // 1. this lane's perimeter points: edge pixel?  (all loads in flight together)
+    uint32_t wv[XPTS];
+    int bi[XPTS];
 #pragma unroll
-    for (int wd = 0; wd < 5; ++wd) {
-      uint32_t mask = 0;
-      const int base = p0 + 32 * wd;
-      if (base < p1) {
-#pragma unroll 8
-        for (int j = 0; j < 32; ++j) {
-          const int v = tab[min(base + j, p1 - 1)];
-          const int y = row + (v >> 16), x = col + (int)(int16_t)(v & 0xFFFF);
-          const bool inb = base + j < p1 && y >= 0 && y < h && x >= 0 && x < w;
-          const int bi = inb ? y * w + x : 0;
-          const uint32_t wv = bits[bi >> 5];
-          mask |= (inb ? (wv >> (bi & 31)) & 1u : 0u) << j;
-        }
-      }
-      masks[wd] = mask;
-      left += __builtin_popcount(mask);
+    for (int m = 0; m < XPTS; ++m) {
+      const int p = p0 + t + XG * m;
+      const int v = tab[min(p, per_total - 1)];
+      const int y = row + (v >> 16), x = col + (int)(int16_t)(v & 0xFFFF);
+      const bool inb = p < p1 && y >= 0 && y < h && x >= 0 && x < w;
+      bi[m] = inb ? y * w + x : -1;
+      wv[m] = bits[max(bi[m], 0) >> 5];
     }
+    int mine = 0;  // bit m: point t + 16 m is an edge pixel
+#pragma unroll
+    for (int m = 0; m < XPTS; ++m) mine |= (bi[m] >= 0 ? (int)((wv[m] >> (bi[m] & 31)) & 1u) : 0) << m;
+    // compaction in perimeter order (m major, lane minor): rank = hits of all lanes in earlier rows m + hits of the
+    // earlier lanes in this row
+    int n_hits = 0;
+#pragma unroll
+    for (int m = 0; m < XPTS; ++m) {
+      const uint64_t bal = __ballot((mine >> m) & 1);
+      const uint32_t grp = (uint32_t)(bal >> (lane & 48)) & 0xFFFFu;  // this group's 16 lanes
+      if ((mine >> m) & 1) my_hits[n_hits + __builtin_popcount(grp & ((1u << t) - 1u))] = (uint16_t)(p0 + t + XG * m);
+      n_hits += __builtin_popcount(grp);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 2. passes of 16 hits
     double acc = 0.0;
-    bool dead = (double)left < floor_sum;
-#pragma unroll
-    for (int wd = 0; wd < 5; ++wd) {
-      uint32_t mask = masks[wd];
-      const int base = p0 + 32 * wd;
-      constexpr int PF = 8;  // angle evaluations in flight
-      while (mask && !dead) {
-        int jj[PF];
-        float an[PF];
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          jj[u] = __ffs(mask) - 1;  // -1 once the word's hits are used up
-          mask &= mask - 1;
-          an[u] = 0.0f;
-          if (jj[u] >= 0) {
-            const int v = tab[base + jj[u]];
-            const int y = row + (v >> 16), x = col + (int)(int16_t)(v & 0xFFFF);
-            an[u] = ang ? ang[(int64_t)y * w + x] : mg_edge_angle(blur, h, w, y, x);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          if (jj[u] < 0 || dead) continue;
-          const int p = base + jj[u];
-          double d = fabs((double)an[u] - d_per_expected[p]);
-          if (d > PI) d = d - PI;
-          // x / pi, correctly rounded without the division (Markstein: y = RN(1/pi), q0 = RN(x y),
-          // r = x - q0 pi exactly by FMA, q = RN(q0 + r y) == RN(x / pi); verified against x / pi on 1e9
-          // operands of exactly this form)
-          const double x4 = 4.0 * fabs(d - PI / 2.0);
-          const double q0 = x4 * INV_PI;
-          const double q = fma(fma(-q0, PI, x4), INV_PI, q0);
-          acc += q - 1.0;
-          --left;
-          if (acc + (double)left < floor_sum) dead = true;  // exact: the remaining hits add <= 1 each
-        }
+    int left = n_hits;  // edge pixels not yet summed: each adds at most 1 (+1.2e-7, inside the margin)
+    bool dead = !active || (double)left < floor_sum;
+    for (int base = 0; base < n_hits && !dead; base += XG) {  // (group-uniform: the broadcasts stay inside a row of 16)
+      double term = 0.0;
+      if (!dead && base + t < n_hits) {
+        const int p = my_hits[base + t];
+        const int v = tab[p];
+        const int y = row + (v >> 16), x = col + (int)(int16_t)(v & 0xFFFF);
+        const float a = ang ? ang[(int64_t)y * w + x] : mg_edge_angle(blur, h, w, y, x);
+        double d = fabs((double)a - expd[p]);
+        if (d > PI) d = d - PI;
+        // x / pi, correctly rounded without the division (Markstein: y = RN(1/pi), q0 = RN(x y),
+        // r = x - q0 pi exactly by FMA, q = RN(q0 + r y) == RN(x / pi); verified against x / pi on 1e9
+        // operands of exactly this form)
+        const double x4 = 4.0 * fabs(d - PI / 2.0);
+        const double q0 = x4 * INV_PI;
+        term = fma(fma(-q0, PI, x4), INV_PI, q0) - 1.0;
       }
+      const int cnt = min(XG, n_hits - base);
+#define MG_ADD(T)                                                                       \
+  {                                                                                     \
+    const double v_ = group_bcast<T>(term);                                             \
+    if (!dead && T < cnt) {                                                             \
+      acc += v_;                                                                        \
+      --left;                                                                           \
+      if (acc + (double)left < floor_sum) dead = true; /* exact: the rest adds <= 1 each */ \
+    }                                                                                   \
+  }
+      MG_ADD(0) MG_ADD(1) MG_ADD(2) MG_ADD(3) MG_ADD(4) MG_ADD(5) MG_ADD(6) MG_ADD(7)
+      MG_ADD(8) MG_ADD(9) MG_ADD(10) MG_ADD(11) MG_ADD(12) MG_ADD(13) MG_ADD(14) MG_ADD(15)
+#undef MG_ADD
     }
+    __builtin_amdgcn_wave_barrier();  // the hit list is rewritten by the next round
+    if (t != 0 || !active) continue;
     if (dead) {
-      if (write_skipped) scores[i] = MG_SCORE_SKIPPED;
+      if (write_skipped & 1) scores[i] = MG_SCORE_SKIPPED;
       continue;
     }
     const float score = (float)acc / (float)(p1 - p0);
@@ -421,7 +457,7 @@ extern "C" int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angl
   int64_t n_layers, words;
   if (mg_dedup_layout(h, w, min_r, max_r, &ntr, &ntc, &n_layers, &words) != MG_OK) return MG_EINVAL;
   if ((int64_t)ntr * ntc >= 32768) return MG_EINVAL;  // the 32-bit key
-  if ((size_t)per_total * 4 > 48 * 1024 || NSUB * (nr + 1) > NP) return MG_EINVAL;
+  if ((size_t)per_total * 12 > 48 * 1024 || NSUB * (nr + 1) > NP) return MG_EINVAL;
   hipStream_t s = mg_stream(stream);
   if (hipMemsetAsync(d_num_surv, 0, (size_t)std::max(n_planes, 1) * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
@@ -443,7 +479,7 @@ extern "C" int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angl
                      d_surv_list, surv_cap, d_num_surv);
   MG_CHECK_LAUNCH();
   if (!(write_skipped & 8))
-  hipLaunchKernelGGL(k_exact, dim3(64, n_planes), dim3(NT), (size_t)per_total * 4, s, d_blur, d_angle, d_edge_bits,
+  hipLaunchKernelGGL(k_exact, dim3(32, n_planes), dim3(NT), (size_t)per_total * 12, s, d_blur, d_angle, d_edge_bits,
                      words_per_plane, h, w, d_circles, circle_cap, d_unique_keys, ntc, min_r, max_r, d_per_rc, per_total,
                      d_per_expected, d_per_starts, min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc,
                      d_num_scored, d_surv_list, surv_cap, d_num_surv);

@@ -326,7 +326,7 @@ class CircleFinder:
         if self.keyed_score:
             self.pair_table = torch.from_numpy(nat.score_pair_table().view(np.int64)).to(dev)
             self.layer_starts = torch.zeros((P, self.n_tiles, self.max_r - self.min_r + 2), dtype=i32, device=dev)
-            self.surv_list = torch.empty((P, self.cap), dtype=i32, device=dev)
+            self.surv_list = torch.empty((P, self.cap, 2), dtype=i32, device=dev)  # (list index, key) per survivor
             self.num_surv = torch.zeros((P,), dtype=i32, device=dev)
         self.nms_grid = None
         self.seeds = torch.zeros((P,), dtype=torch.int64, device=dev)
