@@ -120,57 +120,68 @@ class BeadFinder:
 # --------------------------------------------------------------------------------------
 
 
-def _linregress(x, y):
-    """slope, intercept as scipy.stats.linregress (find.py:710,719,735): ssxym / ssxm, ymean - slope * xmean."""
+def _group_stats(labels, num_clusters, *columns):
+    """Per-cluster counts and means of the given columns (rows with label < 0 belong to no cluster)."""
+    inside = labels >= 0
+    lab = labels[inside]
+    n = np.bincount(lab, minlength=num_clusters).astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        means = [np.bincount(lab, weights=c[inside], minlength=num_clusters) / n for c in columns]
+    return inside, lab, n, means
+
+
+def _line_fit(x, y):
+    """Least-squares line through (x, y): slope = cov(x, y) / var(x), intercept = mean(y) - slope * mean(x)
+    -- what scipy.stats.linregress returns (find.py:710,719,735)."""
     x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
-    ssxm, ssxym, _, _ = np.cov(x, y, bias=1).flat
-    slope = ssxym / ssxm
-    return slope, np.mean(y) - slope * np.mean(x)
+    dx, dy = x - x.mean(), y - y.mean()
+    slope = np.dot(dx, dy) / np.dot(dx, dx)
+    return slope, y.mean() - slope * x.mean()
 
 
 def label_clusters(points, offset, num_clusters, cluster_length, cluster_gap):
-    """find.py:680-695."""
+    """find.py:680-695: cluster i is the interval [offset + i (length + gap), ... + length); -1 outside.
+    One binary search of every point in the 2 n interval ends (no sort of the points, no loop over clusters)."""
     points = np.asarray(points, dtype=np.float64)
-    perm = np.argsort(points)
-    pts = points[perm]
-    labels = -np.ones(len(pts), dtype=int)
-    steps = [offset] + ([cluster_length, cluster_gap] * num_clusters)[:-1]
-    spans = np.searchsorted(pts, np.cumsum(steps))
-    for i in range(num_clusters):
-        labels[spans[2 * i] : spans[2 * i + 1]] = i
-    return labels[np.argsort(perm)]
+    ends = np.cumsum(np.concatenate([[offset], np.tile([cluster_length, cluster_gap], num_clusters)[:-1]]))  # as summed there
+    k = np.searchsorted(ends, points, side="right") - 1  # the last end <= point
+    return np.where((k >= 0) & (k % 2 == 0), k // 2, -1).astype(int)
 
 
 def regress_clusters(x, y, labels, num_clusters, ideal_num_points):
-    """find.py:698-748: per-cluster lines, shared median slope, intercepts blended with an evenly
-    spaced global estimate."""
+    """find.py:698-748: a line per cluster, the median of their slopes for all, per-cluster median intercepts at
+    that slope, blended -- by how complete a cluster is -- with the evenly spaced estimate from a line through
+    (cluster index, intercept).  All clusters at once: grouped sums for the fits, one sort for the medians."""
     x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    labels = np.asarray(labels)
     if num_clusters == 1:
-        if len(x) == 1:
-            return 0, y
-        return _linregress(x, y)
-    slopes = np.full(num_clusters, np.nan)
-    intercepts = np.full(num_clusters, np.nan)
-    groups = [(x[labels == i], y[labels == i]) for i in range(num_clusters)]
-    for i, (gx, gy) in enumerate(groups):
-        if len(gx) > 1:
-            slopes[i], intercepts[i] = _linregress(gx, gy)
-        elif (i == 0 or i == num_clusters - 1) and ideal_num_points[i] >= 2:
-            print("Boundary cluster has fewer than 2 points.The chip is unlikely to be segmented correctly.")
+        return (0, y) if len(x) == 1 else _line_fit(x, y)
+    ideal = np.asarray(ideal_num_points, dtype=np.float64)
+    inside, lab, n, (mx, my) = _group_stats(labels, num_clusters, x, y)
+    gx, gy = x[inside], y[inside]
+    dx, dy = gx - mx[lab], gy - my[lab]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        slopes = np.bincount(lab, weights=dx * dy, minlength=num_clusters) / np.bincount(lab, weights=dx * dx, minlength=num_clusters)
+    slopes[n < 2] = np.nan  # a line needs two points
+    if ((n[[0, -1]] < 2) & (ideal[[0, -1]] >= 2)).any():
+        print("Boundary cluster has fewer than 2 points.The chip is unlikely to be segmented correctly.")
     slope = np.nanmedian(slopes)
-    for i, (gx, gy) in enumerate(groups):
-        if len(gx) > 0:
-            intercepts[i] = np.median(gy - slope * gx)
-    ok = ~np.isnan(intercepts)
+    # median of y - slope x per cluster: sort the residuals inside their clusters, take the middle one (or two)
+    res = gy - slope * gx
+    order = np.lexsort((res, lab))
+    res = res[order]
+    first = np.concatenate([[0], np.cumsum(n)[:-1]]).astype(np.int64)
+    cnt = n.astype(np.int64)
+    have = cnt > 0
+    lo = np.where(have, first + (cnt - 1) // 2, 0)
+    hi = np.where(have, first + cnt // 2, 0)
+    intercepts = np.where(have, 0.5 * (res[lo] + res[hi]) if len(res) else np.nan, np.nan)
     idx = np.arange(num_clusters)
-    g_m, g_b = _linregress(idx[ok], intercepts[ok])
-    for i, (gx, _) in enumerate(groups):
-        if ideal_num_points[i] != 0 and ok[i]:
-            wgt = min(len(gx), ideal_num_points[i]) / ideal_num_points[i]
-            intercepts[i] = wgt * intercepts[i] + (1 - wgt) * (g_m * i + g_b)
-        else:
-            intercepts[i] = g_m * i + g_b
-    return slope, intercepts
+    g_m, g_b = _line_fit(idx[have], intercepts[have])
+    even = g_m * idx + g_b
+    with np.errstate(invalid="ignore", divide="ignore"):
+        wgt = np.where(have & (ideal != 0), np.minimum(n, ideal) / ideal, 0.0)
+    return slope, np.where(wgt > 0, wgt * np.where(have, intercepts, 0.0) + (1 - wgt) * even, even)
 
 
 def chamber_seed(seed: int, chamber: int, k: int) -> int:

@@ -104,9 +104,23 @@ class LazyFlatfield:
 
 
 def _field(value):
+    """Flat / dark field operand: a scalar, an image, or -- as in the reference (preprocess.py:64-81, read with
+    tifffile there) -- the path of a single-page TIFF holding the image.  The reference's zarr-directory branch
+    (preprocess.py:66-73) calls a non-existent ``xr.dataset.open_zarr`` and passes a DataArray as a path: it
+    cannot run there either and raises here."""
     if isinstance(value, (str, os.PathLike)):
-        raise NotImplementedError("flat/dark field files are read with tifffile in the reference "
-                                  "(preprocess.py:64-81); pass the image as an array")
+        import pathlib
+
+        path = pathlib.Path(value).expanduser()
+        if path.is_dir():
+            raise NotImplementedError("flat-field zarr directories: the reference's own branch for them "
+                                      "(preprocess.py:66-73) is broken; pass a TIFF file or an array")
+        if not path.exists():
+            raise FileNotFoundError(str(path))
+        from . import reader
+
+        pages, dims, _ = reader._open_tiff(str(path))
+        return np.asarray(pages[0]) if not dims else np.stack(pages)
     if isinstance(value, (DataArray,)):
         value = value.values
     return value

@@ -512,3 +512,105 @@ def test_score_pair_table_bounds_every_term():
                     # prefilter's threshold carries a 1e-3 margin for exactly this kind of rounding)
                     assert (term <= ub + 2e-7).all()
                     assert (ub - term.max(axis=1, keepdims=True) <= 1 / 64 + 1e-5).all()  # and not uselessly loose
+
+
+def _bead_result_dataset():
+    """A hand-built result with the reference's bead schema (find.py:503-555)."""
+    import magnify_amd as mg
+
+    m, c, t, L = 3, 2, 1, 8
+    rng = np.random.default_rng(1)
+    ds = mg.Dataset(attrs={"name": "assay0"})
+    ds["image"] = mg.DataArray(rng.integers(0, 4000, (c, t, 32, 40)).astype(np.uint16), ("channel", "time", "im_y", "im_x"))
+    ds["roi"] = mg.DataArray(rng.integers(0, 4000, (m, c, t, L, L)).astype(np.uint16), ("mark", "channel", "time", "roi_y", "roi_x"))
+    ds.coords["channel"] = mg.DataArray(np.array(["egfp", "cy5"]), ("channel",), name="channel")
+    ds.coords["fg"] = mg.DataArray(rng.random((m, t, L, L)) > 0.5, ("mark", "time", "roi_y", "roi_x"), name="fg")
+    ds.coords["bg"] = mg.DataArray(rng.random((m, t, L, L)) > 0.5, ("mark", "time", "roi_y", "roi_x"), name="bg")
+    ds.coords["x"] = mg.DataArray(rng.random((m, t)) * 40, ("mark", "time"), name="x")
+    ds.coords["y"] = mg.DataArray(rng.random((m, t)) * 32, ("mark", "time"), name="y")
+    ds.coords["valid"] = mg.DataArray(np.ones((m, t), dtype=bool), ("mark", "time"), name="valid")
+    return ds
+
+
+def test_to_xarray_with_real_xarray():
+    """The xarray output surface against a REAL xarray (skipped where it is not installed -- neither this
+    container nor the GPU box has it): Dataset.to_xarray() yields the reference's schema and a real
+    xr.DataArray / xr.Dataset input is accepted by the components' entry adapter."""
+    xr = pytest.importorskip("xarray")
+    from magnify_amd import xr_lite
+
+    ds = _bead_result_dataset()
+    out = ds.to_xarray()
+    assert isinstance(out, xr.Dataset)
+    assert out["roi"].dims == ("mark", "channel", "time", "roi_y", "roi_x") and out["roi"].dtype == np.uint16
+    assert out["image"].dims == ("channel", "time", "im_y", "im_x")
+    for name, dtype in (("fg", bool), ("bg", bool), ("valid", bool), ("x", np.float64), ("y", np.float64)):
+        assert name in out.coords and out.coords[name].dtype == dtype
+    assert out.coords["fg"].dims == ("mark", "time", "roi_y", "roi_x") and out.coords["x"].dims == ("mark", "time")
+    assert out.attrs["name"] == "assay0" and list(out.coords["channel"].values) == ["egfp", "cy5"]
+    np.testing.assert_array_equal(out["roi"].values, ds["roi"].values)
+    # user-side algebra of the README on the real object (README.md:21-22)
+    np.testing.assert_allclose(out.roi.where(out.fg).mean(dim=["roi_x", "roi_y"]).values,
+                               ds.roi.where(ds.fg).mean(dim=["roi_x", "roi_y"]).values)
+    # and back in: real xarray inputs (all reference tests pass xr.DataArray, tests/test_beads.py:54)
+    back = xr_lite.from_any(out)
+    assert set(back.data_vars) == {"image", "roi"} and back["roi"].dims == ds["roi"].dims
+    arr = xr_lite.from_any(xr.DataArray(np.zeros((4, 5), np.uint16), dims=("y", "x")))
+    assert arr.dims == ("y", "x") and arr.shape == (4, 5)
+    # chip results carry the (mark_row, mark_col) MultiIndex on mark (find.py:182-201, tests/test_chip.py:334-336)
+    chip = _bead_result_dataset()
+    chip.coords["mark_row"] = mg_dataarray(np.array([0, 0, 1]), ("mark",), "mark_row")
+    chip.coords["mark_col"] = mg_dataarray(np.array([0, 1, 0]), ("mark",), "mark_col")
+    chip._cache["mark_shape"] = (2, 2)
+    xc = chip.to_xarray()
+    assert "mark" in xc.indexes and list(xc.indexes["mark"].names) == ["mark_row", "mark_col"]
+
+
+def mg_dataarray(values, dims, name):
+    import magnify_amd as mg
+
+    return mg.DataArray(values, dims, name=name)
+
+
+def test_to_xarray_calls_with_the_reference_schema(monkeypatch):
+    """Where xarray is absent: to_xarray() is executed against a recording stand-in for the xarray module, which
+    checks WHAT is handed to xr.Dataset / xr.DataArray (names, dims, dtypes) -- the schema of SURVEY 8b."""
+    import sys
+    import types
+
+    calls = {}
+
+    class FakeDataset:
+        def __init__(self, data_vars, coords=None, attrs=None):
+            calls["dataset"] = (data_vars, coords, attrs)
+            self.indexed = None
+
+        def set_index(self, **kw):
+            self.indexed = kw
+            return self
+
+    class FakeDataArray:
+        def __init__(self, values, dims=None, coords=None, name=None, attrs=None):
+            calls["dataarray"] = (values, dims, coords, name, attrs)
+
+    fake = types.ModuleType("xarray")
+    fake.Dataset, fake.DataArray = FakeDataset, FakeDataArray
+    monkeypatch.setitem(sys.modules, "xarray", fake)
+    ds = _bead_result_dataset()
+    ds.attrs["__mg_private__"] = 1
+    out = ds.to_xarray()
+    data_vars, coords, attrs = calls["dataset"]
+    assert set(data_vars) == {"image", "roi"} and attrs == {"name": "assay0"} and out.indexed is None
+    assert data_vars["roi"][0] == ("mark", "channel", "time", "roi_y", "roi_x") and data_vars["roi"][1].dtype == np.uint16
+    assert data_vars["image"][0] == ("channel", "time", "im_y", "im_x")
+    assert coords["fg"][0] == ("mark", "time", "roi_y", "roi_x") and coords["fg"][1].dtype == bool
+    assert coords["x"][0] == ("mark", "time") and coords["x"][1].dtype == np.float64
+    assert coords["valid"][1].dtype == bool and list(coords["channel"][1]) == ["egfp", "cy5"]
+    ds.roi.to_xarray()
+    values, dims, acoords, name, _ = calls["dataarray"]
+    assert dims == ("mark", "channel", "time", "roi_y", "roi_x") and values.dtype == np.uint16 and name == "roi"
+    assert set(acoords) >= {"fg", "bg", "x", "y", "valid"}
+    ds.coords["mark_row"] = mg_dataarray(np.array([0, 0, 1]), ("mark",), "mark_row")
+    ds.coords["mark_col"] = mg_dataarray(np.array([0, 1, 0]), ("mark",), "mark_col")
+    ds._cache["mark_shape"] = (2, 2)
+    assert ds.to_xarray().indexed == {"mark": ("mark_row", "mark_col")}

@@ -166,6 +166,30 @@ def test_flatfield_in_pipeline_matches_oracle(mg):
     np.testing.assert_array_equal(xp.tile.values, rp.flatfield_correct(tiles, flat, 100.0))
 
 
+def test_flatfield_from_tiff_files(mg, tmp_path):
+    """flatfield / darkfield given as paths of TIFF files, as the reference reads them with tifffile
+    (preprocess.py:64-81): same result as the arrays themselves."""
+    from PIL import Image
+
+    from oracle import ref_pipeline as rp
+    from synth import noisy_bead_image, vignette
+
+    img, _ = noisy_bead_image(4, (200, 240), 4)
+    tiles = img.reshape(1, 1, 1, 1, 200, 240)
+    flat = vignette((200, 240))  # float32
+    dark = (90 + (np.arange(200 * 240).reshape(200, 240) % 7)).astype(np.uint16)
+    Image.fromarray(flat).save(tmp_path / "flat.tif")
+    Image.fromarray(dark).save(tmp_path / "dark.tif")
+    pipe = mg.Pipeline("read")
+    pipe.add_pipe("standardize_format")
+    pipe.add_pipe("flatfield_correct", flatfield=str(tmp_path / "flat.tif"), darkfield=tmp_path / "dark.tif")
+    pipe.add_pipe("stitch", overlap=0)
+    xp = pipe(mg.DataArray(tiles, ("channel", "time", "tile_row", "tile_col", "tile_y", "tile_x")))
+    np.testing.assert_array_equal(xp.image.values, rp.stitch(rp.flatfield_correct(tiles, flat, dark), 0))
+    with pytest.raises(FileNotFoundError):
+        mg.components.get("flatfield_correct")(flatfield=str(tmp_path / "nope.tif"))(xp)
+
+
 def test_stitcher_component(mg):
     # tests/test_stitch.py through the component object
     from magnify_amd.stitch import Stitcher
@@ -233,3 +257,60 @@ def test_mrbles_front_half(mg, tmp_path):
     with pytest.raises(ValueError):
         mg.mrbles(arr(mg, data, ("channel", "y", "x"), channel=chans), spectra=str(sp_csv), codes=str(bad),
                   min_bead_diameter=16, max_bead_diameter=24, overlap=0, num_iter=2000)
+
+
+# ---- the remaining scenarios of the reference's tests/test_beads.py, one to one ---------------------------
+
+
+def _positions_100(xp, n):
+    return {(round(xp.y[i].values.item() / 100) * 100, round(xp.x[i].values.item() / 100) * 100) for i in range(n)}
+
+
+def test_beads_varying_sizes(mg):
+    # tests/test_beads.py:131-157
+    pos = [[300, 300], [300, 700], [700, 300], [700, 700]]
+    img = draw_beads((1024, 1024), pos, np.array([16, 20, 24, 28]))
+    xp = mg.beads(data=arr(mg, img, ("y", "x")), min_bead_diameter=14, max_bead_diameter=32, overlap=0, num_iter=10000)
+    assert isinstance(xp, mg.Dataset) and xp.roi.sizes["mark"] == 4
+    areas = xp.fg.sum(dim=["roi_x", "roi_y"]).values
+    assert areas.max() / areas.min() > 1.5
+
+
+def test_beads_varying_intensity(mg):
+    # tests/test_beads.py:191-216
+    pos = [[300, 500], [500, 500], [700, 500]]
+    img = draw_beads((1024, 1024), pos, 20, [500, 1000, 2000])
+    xp = mg.beads(data=arr(mg, img, ("y", "x")), min_bead_diameter=16, max_bead_diameter=24, overlap=0, num_iter=10000)
+    assert xp.roi.sizes["mark"] == 3
+    radii = np.sqrt(xp.fg.sum(dim=["roi_x", "roi_y"]).values / np.pi)
+    assert np.all(radii > 0.85 * 10)
+
+
+def test_beads_multichannel_search_single(mg):
+    # tests/test_beads.py:282-324
+    pos = [[300, 300], [700, 700]]
+    data = np.stack([draw_beads((1024, 1024), pos), draw_beads((1024, 1024), pos)])
+    xp = mg.beads(data=arr(mg, data, ("channel", "y", "x"), channel=["red", "green"]), min_bead_diameter=16,
+                  max_bead_diameter=24, overlap=0, num_iter=5000, search_channel="red")
+    assert xp.roi.sizes["mark"] == 2
+    assert "red" in xp.channel.values and "green" in xp.channel.values
+    assert _positions_100(xp, 2) == {(300, 300), (700, 700)}
+    for area in xp.fg.sum(dim=["roi_x", "roi_y"]).values:
+        assert 0.8 * 10 < np.sqrt(area / np.pi) < 1.2 * 10
+
+
+def test_beads_multichannel_different_beads(mg):
+    # tests/test_beads.py:327-365
+    data = np.stack([draw_beads((1024, 1024), [[200, 200], [200, 800]]), draw_beads((1024, 1024), [[800, 200], [800, 800]])])
+    xp = mg.beads(data=arr(mg, data, ("channel", "y", "x"), channel=["red", "green"]), min_bead_diameter=16,
+                  max_bead_diameter=24, overlap=0, num_iter=10000, search_channel=["red", "green"])
+    assert xp.roi.sizes["mark"] == 4
+    assert _positions_100(xp, 4) == {(200, 200), (200, 800), (800, 200), (800, 800)}
+
+
+def test_beads_multichannel_subset_only(mg):
+    # tests/test_beads.py:368-391: a bead that only exists in a channel that is not searched is not found
+    data = np.stack([np.zeros((1024, 1024), dtype=np.uint16), draw_beads((1024, 1024), [[512, 512]])])
+    xp = mg.beads(data=arr(mg, data, ("channel", "y", "x"), channel=["red", "green"]), min_bead_diameter=16,
+                  max_bead_diameter=24, overlap=0, num_iter=1000, search_channel="red")
+    assert isinstance(xp, mg.Dataset) and xp.roi.sizes["mark"] == 0

@@ -268,3 +268,90 @@ def test_marker_filters(mg):
     assert rnd.valid.values.all()
     assert not mg.filter.filter_nonround(ds, min_roundness=2.0).valid.values.any()  # pixel-area over centre-line perimeter stays below 2
     assert {"filter_expression", "filter_leaky", "filter_nonround"} <= set(mg.components.get_all())
+
+
+# ---- the remaining scenarios of the reference's tests/test_chip.py, one to one ----------------------------
+
+
+def _grid(xp):
+    return xp.unstack().transpose("mark_row", "mark_col", ...)
+
+
+def test_rectangular_spacing(mg):
+    # tests/test_chip.py:224-251
+    xp = mg.microfluidic_chip(data=chip(mg, draw_chip((4, 4), 20, row_dist=80, col_dist=120)), shape=(4, 4),
+                              min_button_diameter=16, max_button_diameter=32, overlap=0, row_dist=80, col_dist=120,
+                              num_iter=5000)
+    xp = _grid(xp)
+    assert xp.roi.sizes["mark_row"] == 4 and xp.roi.sizes["mark_col"] == 4
+    assert 70 < xp.y[1, 0].values.item() - xp.y[0, 0].values.item() < 90
+    assert 110 < xp.x[0, 1].values.item() - xp.x[0, 0].values.item() < 130
+
+
+def test_2x2_chip(mg):
+    # tests/test_chip.py:259-283
+    xp = _grid(mg.microfluidic_chip(data=chip(mg, draw_chip((2, 2), 20)), shape=(2, 2), num_iter=1000, **KW))
+    assert xp.roi.sizes["mark_row"] == 2 and xp.roi.sizes["mark_col"] == 2
+    for i in range(2):
+        for j in range(2):
+            assert 0.9 * (j + 1) * 100 < xp.x[i, j].values.item() < 1.1 * (j + 1) * 100
+            assert 0.9 * (i + 1) * 100 < xp.y[i, j].values.item() < 1.1 * (i + 1) * 100
+
+
+def test_chip_multiple_search_timesteps(mg):
+    # tests/test_chip.py:467-499
+    img = draw_chip((3, 3), 20)
+    xp = mg.microfluidic_chip(data=chip(mg, np.stack([img] * 5), ("time", "y", "x"), time=[0, 1, 2, 3, 4]), shape=(3, 3),
+                              num_iter=5000, search_timestep=[0, 2], **KW)
+    assert xp.sizes["time"] == 5
+    xp = _grid(xp)
+    for t in (0, 2):
+        for row in range(3):
+            for col in range(3):
+                assert 0.9 * (col + 1) * 100 < xp.x[row, col, t].values.item() < 1.1 * (col + 1) * 100
+
+
+def test_chip_no_refinding_copies_from_searched(mg):
+    # tests/test_chip.py:563-610: a timestep that is not searched takes the positions of the searched one,
+    # even though its buttons moved
+    t0 = draw_chip((2, 2), 20, row_dist=100, col_dist=100)
+    t1 = np.zeros_like(t0)
+    t1[15:, 15:] = t0[:-15, :-15]
+    xp = mg.microfluidic_chip(data=chip(mg, np.stack([t0, t1]), ("time", "y", "x"), time=[0, 1]), shape=(2, 2),
+                              num_iter=5000, search_timestep=0, **KW)
+    xp = _grid(xp)
+    np.testing.assert_array_almost_equal(xp.x[:, :, 0].values, xp.x[:, :, 1].values)
+    np.testing.assert_array_almost_equal(xp.y[:, :, 0].values, xp.y[:, :, 1].values)
+    for row in range(2):
+        for col in range(2):
+            assert 0.9 * (col + 1) * 100 < xp.x[row, col, 0].values.item() < 1.1 * (col + 1) * 100
+            assert 0.9 * (row + 1) * 100 < xp.y[row, col, 0].values.item() < 1.1 * (row + 1) * 100
+
+
+def test_chip_multichannel_search_specific(mg):
+    # tests/test_chip.py:656-699: buttons visible in "bf" only, searched there
+    img = draw_chip((3, 3), 20)
+    xp = mg.microfluidic_chip(data=chip(mg, np.stack([img, np.zeros_like(img)]), ("channel", "y", "x"), channel=["bf", "gfp"]),
+                              shape=(3, 3), num_iter=5000, search_channel="bf", **KW)
+    xp = _grid(xp)
+    for row in range(3):
+        for col in range(3):
+            assert 0.9 * (col + 1) * 100 < xp.x[row, col].values.item() < 1.1 * (col + 1) * 100
+            assert 0.9 * (row + 1) * 100 < xp.y[row, col].values.item() < 1.1 * (row + 1) * 100
+    for area in xp.fg.sum(dim=["roi_x", "roi_y"]).values.flatten():
+        assert 0.8 * 10 < np.sqrt(area / np.pi) < 1.2 * 10
+
+
+def test_chip_multichannel_multitimestep(mg):
+    # tests/test_chip.py:702-738
+    img = draw_chip((2, 2), 20)
+    data = np.stack([[img] * 3, [img] * 3])
+    xp = mg.microfluidic_chip(data=chip(mg, data, ("channel", "time", "y", "x"), channel=["bf", "gfp"], time=[0, 1, 2]),
+                              shape=(2, 2), num_iter=5000, search_channel="bf", **KW)
+    assert xp.sizes["time"] == 3 and xp.sizes["channel"] == 2
+    xp = _grid(xp)
+    for t in range(3):
+        for row in range(2):
+            for col in range(2):
+                assert 0.9 * (col + 1) * 100 < xp.x[row, col, t].values.item() < 1.1 * (col + 1) * 100
+                assert 0.9 * (row + 1) * 100 < xp.y[row, col, t].values.item() < 1.1 * (row + 1) * 100
