@@ -7,8 +7,10 @@ encoding conventions, so that ``xr.open_dataset`` (and therefore the reference's
 decodes it: unsigned integers as the signed type of the same width with ``_Unsigned = "true"``,
 booleans as int8 with ``dtype = "bool"``, strings as char arrays over a ``string<N>`` dimension with
 ``_Encoding = "utf-8"``, int64 narrowed to int32 when it fits, non-index coordinates listed in the
-``coordinates`` attribute.  NetCDF-3 limits a variable to 4 GiB: larger ROI stacks must be saved per
-shard (ROI pixels stay sharded by GPU anyway).
+``coordinates`` attribute.  NetCDF-3 limits a variable to 4 GiB: a dataset with a larger variable (C4's
+``roi`` is 9.7 GB) is written as PARTS ``<file>.part000``, ``<file>.part001`` ... -- contiguous blocks of the
+marker axis, every part a complete NetCDF file of at most ``shard_bytes`` per variable -- and ``load`` puts
+them together again (ROI pixels stay sharded by GPU anyway, SURVEY 8e: a rank saves its own shard).
 
 As in the reference, a chip dataset is unstacked (mark -> mark_row, mark_col) before saving and
 restacked on load.
@@ -70,11 +72,63 @@ def _decode(var, attrs):
     return arr, dims
 
 
-def save(file, xp):
-    """file.py:6-8."""
+_SHARD = 1 << 31  # default size of the largest variable of a part
+
+
+def _nbytes(v):
+    a = v.values if not isinstance(v, np.ndarray) else v
+    return int(np.prod(a.shape, dtype=np.int64)) * (1 if a.dtype == np.bool_ else a.dtype.itemsize)
+
+
+def _take_block(ds: Dataset, dim, lo, hi, first):
+    """The block [lo, hi) of ``ds`` along ``dim``; variables without that dimension only in the first part."""
+    out = Dataset(attrs=dict(ds.attrs))
+
+    def cut(v):
+        if dim not in v.dims:
+            return v if first else None
+        idx = [slice(None)] * len(v.dims)
+        idx[v.dims.index(dim)] = slice(lo, hi)
+        return DataArray(np.asarray(v.values)[tuple(idx)], v.dims, None, v.name, dict(v.attrs or {}))
+
+    for k, c in ds.coords.items():
+        piece = cut(c)
+        if piece is not None:
+            out.coords[k] = piece
+    for k, v in ds.data_vars.items():
+        piece = cut(v)
+        if piece is not None:
+            out[k] = piece
+    return out
+
+
+def save(file, xp, shard_bytes=None):
+    """file.py:6-8.  ``shard_bytes``: write parts whose largest variable stays below it (default: parts only when
+    a variable exceeds NetCDF-3's 4 GiB, then 2 GiB each)."""
+    ds = xp.unstack() if isinstance(xp, Dataset) else Dataset({xp.name or "data": xp})
+    sizes = {k: _nbytes(v) for k, v in list(ds.data_vars.items()) + list(ds.coords.items())}
+    biggest = max(sizes.values(), default=0)
+    if shard_bytes is None and biggest <= _LIMIT:
+        return _write(file, ds)
+    limit = int(shard_bytes or _SHARD)
+    dim = next((d for d in ("mark", "mark_row", "time") if d in ds.sizes and ds.sizes[d] > 1), None)
+    if dim is None:
+        raise ValueError("a variable exceeds the part size and there is no marker / time axis to split along")
+    # rows of `dim` per part so that the largest variable carrying it fits
+    per_row = max((sizes[k] // max(ds.sizes[dim], 1) for k, v in list(ds.data_vars.items()) + list(ds.coords.items())
+                   if dim in v.dims), default=1)
+    rows = max(1, limit // max(per_row, 1))
+    n = ds.sizes[dim]
+    bounds = list(range(0, n, rows)) + [n]
+    for k, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+        part = _take_block(ds, dim, lo, hi, k == 0)
+        part.attrs.update(mg_part=k, mg_parts=len(bounds) - 1, mg_split_dim=dim, mg_split_lo=lo)
+        _write(f"{file}.part{k:03d}", part)
+
+
+def _write(file, ds):
     from scipy.io import netcdf_file
 
-    ds = xp.unstack() if isinstance(xp, Dataset) else Dataset({xp.name or "data": xp})
     coord_names = [k for k, c in ds.coords.items() if not (c.dims == (k,))]
     with netcdf_file(str(file), "w", version=2) as nc:
         def dim(name, size):
@@ -113,7 +167,40 @@ def save(file, xp):
 
 
 def load(file):
-    """file.py:11-17."""
+    """file.py:11-17.  A dataset that was saved in parts (``<file>.part000`` ...) is put together again along the
+    axis it was split on."""
+    import glob
+    import os
+
+    if not os.path.exists(str(file)):
+        parts = sorted(glob.glob(glob.escape(str(file)) + ".part[0-9][0-9][0-9]"))
+        if not parts:
+            raise FileNotFoundError(str(file))
+        pieces = [_read(p, restack=False) for p in parts]
+        n, dim = int(pieces[0].attrs["mg_parts"]), pieces[0].attrs["mg_split_dim"]
+        if len(pieces) != n or [int(p.attrs["mg_part"]) for p in pieces] != list(range(n)):
+            raise ValueError(f"{file}: parts missing (found {len(pieces)} of {n})")
+        xp = Dataset(attrs={k: v for k, v in pieces[0].attrs.items() if not k.startswith("mg_")})
+
+        def join(name, get):
+            first = get(pieces[0])
+            if dim not in first.dims:
+                return first
+            axis = first.dims.index(dim)
+            return DataArray(np.concatenate([np.asarray(get(p).values) for p in pieces], axis=axis), first.dims, None,
+                             name, dict(first.attrs or {}))
+
+        for k in pieces[0].coords:
+            xp.coords[k] = join(k, lambda p, k=k: p.coords[k])
+        for k in pieces[0].data_vars:
+            xp[k] = join(k, lambda p, k=k: p.data_vars[k])
+        if "mark_row" in xp.sizes and "mark_col" in xp.sizes:
+            xp = xp.stack_mark()
+        return xp
+    return _read(file, restack=True)
+
+
+def _read(file, restack):
     from scipy.io import netcdf_file
 
     def text(a):
@@ -131,6 +218,6 @@ def load(file):
     coords = {k: v for k, v in decoded.items() if k in listed or v.dims == (k,)}
     data_vars = {k: v for k, v in decoded.items() if k not in coords}
     xp = Dataset(data_vars, coords=coords, attrs=global_attrs)
-    if "mark_row" in xp.sizes and "mark_col" in xp.sizes:
+    if restack and "mark_row" in xp.sizes and "mark_col" in xp.sizes:
         xp = xp.stack_mark()
     return xp

@@ -174,43 +174,95 @@ class Reader:
         return Reader()
 
 
+def _tiff_layout(path):
+    """(page dims, page shape, page dtype, n_frames) of a TIFF without decoding more than its first page."""
+    from PIL import Image
+
+    with Image.open(path) as im:
+        n = getattr(im, "n_frames", 1)
+        desc = im.tag_v2.get(270, "") if hasattr(im, "tag_v2") else ""
+        first = np.array(im)
+    if n == 1:
+        return [], (), first.shape[:2], first.dtype, 1
+    found = {k: int(v) for k, v in re.findall(r"(channels|frames|slices)=(\d+)", desc if isinstance(desc, str) else "")}
+    if found.get("slices", 1) > 1:
+        raise ValueError("tiff files with a Z dimension are not yet supported.")
+    n_c, n_t = found.get("channels", 1), found.get("frames", 1)
+    if n_c * n_t != n:
+        raise ValueError(f"{path}: {n} pages but no ImageJ hyperstack description that explains them")
+    dims, shape = [], ()
+    if n_t > 1:
+        dims, shape = dims + ["time"], shape + (n_t,)
+    if n_c > 1:
+        dims, shape = dims + ["channel"], shape + (n_c,)
+    return dims, shape, first.shape[:2], first.dtype, n
+
+
+def _read_page(path, index, out):
+    """Decode ONE page of a TIFF into ``out`` (the reference maps every page to its own dask block and reads it
+    on demand, reader.py:265-292)."""
+    from PIL import Image
+
+    with Image.open(path) as im:
+        if index:
+            im.seek(index)
+        out[...] = np.asarray(im)
+
+
 def iter_time_chunks(pattern, chunk: int, pinned: bool = False):
     """Streamed ingest of a time series too large to hold: the files behind
-    ``pattern`` -- one 2-D page per (channel, time), groups ``(channel)`` and ``(time|format)`` as in
-    ``extract_paths`` -- are read ``chunk`` timepoints at a time, in time order, never all at once.
-    Yields ``(time_values, channels, block)`` with ``block`` a (T_chunk, C, H, W) array of the files'
-    dtype: a NumPy array, or with ``pinned`` a page-locked torch tensor ready for an asynchronous upload.
-    Tiled files (``(row)`` / ``(col)`` groups) and several assays per pattern are not streamed: use
-    ``Reader``."""
+    ``pattern`` are read ``chunk`` timepoints at a time, in time order, page by page, never all at once.
+    Groups as in ``extract_paths``: ``(channel)``, ``(time|format)``, and for tiled acquisitions ``(row)`` /
+    ``(col)``; a file holds one 2-D page or an ImageJ hyperstack whose pages run over time and / or channel
+    (a dimension is either in the path or in the file, reader.py:225-231).
+    Yields ``(time_values, channels, block)`` with ``block`` (T_chunk, C, H, W) -- tiled series:
+    (T_chunk, C, rows, cols, tile_y, tile_x), stitched later on the device (``stack.process_stream(overlap=...)``)
+    -- of the files' dtype: a NumPy array, or with ``pinned`` a page-locked torch tensor ready for an
+    asynchronous upload.  One assay per pattern."""
     path_dict, _ = extract_paths(os.fspath(pattern), assay="str", channel="str", time="time", row="int", col="int")
     if len(path_dict) == 0:
         raise FileNotFoundError(f"The pattern {pattern} did not lead to any files.")
-    if any(k[0] is not None or k[3] is not None or k[4] is not None for k in path_dict):
-        raise ValueError("iter_time_chunks streams single-tile, single-assay series only")
-    if any(k[2] is None for k in path_dict):
-        raise ValueError("the pattern needs a (time) group")
-    channels = sorted({k[1] for k in path_dict}, key=lambda c: (c is None, c))
-    times = sorted({k[2] for k in path_dict})
-    first, _, _ = _open_tiff(path_dict[(None, channels[0], times[0], None, None)])
-    h, w = first[0].shape[:2]
-    dtype = first[0].dtype
+    if len({k[0] for k in path_dict}) > 1:
+        raise ValueError("iter_time_chunks streams one assay per pattern")
+    in_file, inner, (h, w), dtype, _ = _tiff_layout(next(iter(path_dict.values())))
+    path_dims = {"channel": any(k[1] is not None for k in path_dict), "time": any(k[2] is not None for k in path_dict)}
+    for d in in_file:
+        if path_dims[d]:
+            raise ValueError("Dimensions specified in the path names and inside the tiff file overlap.")
+    if not path_dims["time"] and "time" not in in_file:
+        raise ValueError("the pattern needs a (time) group, or files with a time axis")
+    tiled = any(k[3] is not None or k[4] is not None for k in path_dict)
+    rows = sorted({k[3] for k in path_dict}, key=lambda v: (v is None, v))
+    cols = sorted({k[4] for k in path_dict}, key=lambda v: (v is None, v))
+    n_t_file = inner[in_file.index("time")] if "time" in in_file else 1
+    n_c_file = inner[in_file.index("channel")] if "channel" in in_file else 1
+    channels = sorted({k[1] for k in path_dict}, key=lambda c: (c is None, c)) if path_dims["channel"] else list(range(n_c_file))
+    times = sorted({k[2] for k in path_dict}) if path_dims["time"] else list(range(n_t_file))
+
+    def page_of(t, c, r, cc):  # -> (path, page index inside the file): pages run (time, channel), channel fastest
+        key = (next(iter(path_dict))[0], c if path_dims["channel"] else None, t if path_dims["time"] else None, r, cc)
+        if key not in path_dict:
+            raise FileNotFoundError(f"no file for channel {c!r}, time {t}, tile ({r}, {cc})")
+        ti = 0 if path_dims["time"] else t
+        ci = 0 if path_dims["channel"] else c
+        return path_dict[key], ti * n_c_file + ci
+
     for lo in range(0, len(times), int(chunk)):
         part = times[lo: lo + int(chunk)]
+        shape = (len(part), len(channels)) + ((len(rows), len(cols)) if tiled else ()) + (h, w)
         if pinned:
             import torch
 
-            block_t = torch.empty((len(part), len(channels), h, w), dtype=torch.from_numpy(np.empty(0, dtype)).dtype).pin_memory()
+            block_t = torch.empty(shape, dtype=torch.from_numpy(np.empty(0, dtype)).dtype).pin_memory()
             block = block_t.numpy()
         else:
-            block = np.empty((len(part), len(channels), h, w), dtype=dtype)
+            block = np.empty(shape, dtype=dtype)
         for i, t in enumerate(part):
             for j, c in enumerate(channels):
-                key = (None, c, t, None, None)
-                if key not in path_dict:
-                    raise FileNotFoundError(f"no file for channel {c!r} at time {t}")
-                pages, in_file, _ = _open_tiff(path_dict[key])
-                if in_file or pages[0].shape[:2] != (h, w):
-                    raise ValueError(f"{path_dict[key]}: expected one {h} x {w} page")
-                block[i, j] = pages[0]
+                for a, r in enumerate(rows):
+                    for b, cc in enumerate(cols):
+                        path, index = page_of(t, c, r, cc)
+                        dst = block[i, j, a, b] if tiled else block[i, j]
+                        _read_page(path, index, dst)
         stamps = [int(t.timestamp()) if isinstance(t, datetime.datetime) else t for t in part]
         yield stamps, [c for c in channels], (block_t if pinned else block)

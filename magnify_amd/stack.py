@@ -25,11 +25,21 @@ class StackProcessor:
     def __init__(self, n_t, n_c, h, w, dtype=torch.uint16, min_bead_diameter=10, max_bead_diameter=50,
                  low_edge_quantile=0.1, high_edge_quantile=0.9, num_iter=5_000_000, min_roundness=0.3,
                  roi_length=None, search_channels=(0,), mode="P", plane_batch=None, device="cuda", n_streams=1,
-                 sub_batches=None):
+                 sub_batches=None, tile_grid=None, overlap=0):
+        """``h, w``: the size of the (stitched) image.  ``tile_grid=(rows, cols, tile_y, tile_x)`` + ``overlap``:
+        the input stack is (T, C, rows, cols, tile_y, tile_x) and the flat-field pass also crops and joins the
+        tiles (stitch.py:22-39); ``h, w`` must then be the stitched size (``stitched_shape``)."""
         hp.require_gpu()
         if min_bead_diameter > max_bead_diameter:
             raise ValueError("min_bead_diameter must be <= max_bead_diameter.")
         self.T, self.C, self.h, self.w = n_t, n_c, h, w
+        self.overlap = int(overlap)
+        self.tile_grid = tuple(int(v) for v in tile_grid) if tile_grid is not None else (1, 1, h, w)
+        if tile_grid is None and overlap:
+            raise ValueError("overlap needs tile_grid")
+        if stitched_shape(*self.tile_grid, self.overlap) != (h, w):
+            raise ValueError(f"tile_grid {self.tile_grid} with overlap {overlap} stitches to "
+                             f"{stitched_shape(*self.tile_grid, self.overlap)}, not to {(h, w)}")
         self.min_r = math.floor(min_bead_diameter / 2)  # find.py:461-467
         self.max_r = math.ceil(max_bead_diameter / 2)
         self.L = roi_length if roi_length is not None else 2 * max_bead_diameter
@@ -65,12 +75,13 @@ class StackProcessor:
         self.minmax = torch.empty((n_t, n_c, 2), dtype=torch.float64, device=self.dev)
 
     def flatfield(self, stack: torch.Tensor, flatfield=1.0, darkfield=0.0, max2=None):
-        """stack (T, C, H, W) -> self.image (T, C, H, W), self.minmax (T, C, 2)."""
-        T, C, h, w = self.T, self.C, self.h, self.w
-        tiles = stack.view(T * C, 1, 1, 1, h, w)
+        """stack (T, C, H, W) -- or (T, C, rows, cols, tile_y, tile_x) with a tile grid -- -> self.image
+        (T, C, H, W), self.minmax (T, C, 2)."""
+        T, C = self.T, self.C
+        tiles = stack.view(T * C, 1, *self.tile_grid)
         # mode P: every time slice is its own assay -> its own pair of maxima (n_groups = T);
         # mode R: single assay, the maxima span the whole stack (preprocess.py:84,86)
-        hp.flatfield_stitch(tiles, 0, flatfield, darkfield, out=self.image, minmax_out=self.minmax, max2=max2,
+        hp.flatfield_stitch(tiles, self.overlap, flatfield, darkfield, out=self.image, minmax_out=self.minmax, max2=max2,
                             n_groups=T if self.mode == "P" else 1)
         return self.image
 
@@ -113,10 +124,10 @@ class StackProcessor:
             # uploads its own sub-batch into a device staging buffer right before it needs it, so the
             # PCIe transfer of one sub-batch overlaps the kernels of the others.
             if self.stage is None:
-                self.stage = torch.empty((T, C, h, w), dtype=stack.dtype, device=self.dev)
-            tiles = self.stage.view(T * C, 1, 1, 1, h, w)
+                self.stage = torch.empty((T, C) + self.tile_grid, dtype=stack.dtype, device=self.dev)
+            tiles = self.stage.view(T * C, 1, *self.tile_grid)
         else:
-            tiles = stack.view(T * C, 1, 1, 1, h, w) if stack is not None else None
+            tiles = stack.view(T * C, 1, *self.tile_grid) if stack is not None else None
 
         def work(k):
             try:
@@ -127,7 +138,7 @@ class StackProcessor:
                         if host:
                             self.stage[lo:hi].copy_(stack[lo:hi], non_blocking=True)
                         if tiles is not None:
-                            hp.flatfield_stitch(tiles[lo * C : hi * C], 0, flatfield, darkfield, out=self.image[lo:hi],
+                            hp.flatfield_stitch(tiles[lo * C : hi * C], self.overlap, flatfield, darkfield, out=self.image[lo:hi],
                                                 minmax_out=self.minmax[lo:hi], n_groups=hi - lo)
                         for j, ch in enumerate(self.search_channels):
                             planes = self.image[lo:hi, ch]
@@ -195,9 +206,17 @@ class StackProcessor:
         return out
 
 
-def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False, prefetch=2, **processor_kwargs):
+def stitched_shape(rows, cols, tile_y, tile_x, overlap):
+    """Size of the image Stitcher makes of a (rows, cols) grid of (tile_y, tile_x) tiles (stitch.py:22-39)."""
+    clip, rem = overlap // 2, overlap % 2
+    return rows * (tile_y - 2 * clip - rem), cols * (tile_x - 2 * clip - rem)
+
+
+def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False, prefetch=2, overlap=0, **processor_kwargs):
     """Mode-P processing of a time series that arrives chunk by chunk (config C5: ``reader.iter_time_chunks``
-    or any iterator of (T_chunk, C, H, W) blocks, optionally wrapped as (time_values, channels, block)).
+    or any iterator of (T_chunk, C, H, W) blocks -- or TILED blocks (T_chunk, C, rows, cols, tile_y, tile_x), which the
+    flat-field pass crops and joins with ``overlap`` on the device, so the stitched assay never exists on the host --
+    optionally wrapped as (time_values, channels, block)).
     A reader thread keeps ``prefetch`` chunks ahead, so decoding files overlaps the GPU's work on the chunk
     before; inside a chunk the upload overlaps compute when ``n_streams > 1`` is passed on.  Every
     timepoint is its own assay, and its RNG stream only depends on its global index: the results equal
@@ -229,10 +248,17 @@ def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False,
         block = item[-1] if isinstance(item, tuple) else item
         if not isinstance(block, torch.Tensor):
             block = torch.from_numpy(np.ascontiguousarray(block))
-        t, c, h, w = block.shape
-        key = (t, c, h, w, block.dtype)
+        key = (tuple(block.shape), block.dtype)
         if key not in procs:  # a shorter last chunk gets its own workspaces
-            procs[key] = StackProcessor(t, c, h, w, dtype=block.dtype, mode="P", **processor_kwargs)
+            if block.dim() == 6:  # (T, C, rows, cols, tile_y, tile_x): stitched by the flat-field pass
+                t, c = block.shape[:2]
+                h, w = stitched_shape(*block.shape[2:], overlap)
+                procs[key] = StackProcessor(t, c, h, w, dtype=block.dtype, mode="P", tile_grid=tuple(block.shape[2:]),
+                                            overlap=overlap, **processor_kwargs)
+            else:
+                t, c, h, w = block.shape
+                procs[key] = StackProcessor(t, c, h, w, dtype=block.dtype, mode="P", **processor_kwargs)
+        t = block.shape[0]
         out = procs[key](block, flatfield, darkfield, seed=(seed + 1000003 * done) & 0xFFFFFFFFFFFFFFFF, want_roi=want_roi)
         out["first_timepoint"] = done
         for k in ("sums", "counts"):  # small; the pooled buffers behind them are reused by the next chunk

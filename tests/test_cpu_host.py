@@ -614,3 +614,95 @@ def test_to_xarray_calls_with_the_reference_schema(monkeypatch):
     ds.coords["mark_col"] = mg_dataarray(np.array([0, 1, 0]), ("mark",), "mark_col")
     ds._cache["mark_shape"] = (2, 2)
     assert ds.to_xarray().indexed == {"mark": ("mark_row", "mark_col")}
+
+
+def test_iter_time_chunks_tiles_and_hyperstacks(tmp_path):
+    """reader.iter_time_chunks (the streaming half of SURVEY 8f N2): tiled series chunked by time, one page
+    decoded at a time, equal to the eager Reader; ImageJ hyperstacks with time / channel inside the file."""
+    from PIL import Image
+
+    from magnify_amd import reader
+
+    rng = np.random.default_rng(0)
+    T, C, R, Cc, ty, tx = 3, 2, 2, 3, 16, 20
+    data = rng.integers(0, 60000, (T, C, R, Cc, ty, tx)).astype(np.uint16)
+    for t in range(T):
+        for c in range(C):
+            for r in range(R):
+                for k in range(Cc):
+                    Image.fromarray(data[t, c, r, k]).save(tmp_path / f"x_ch{c}_202401{t + 10}_r{r}_c{k}.tif")
+    pattern = str(tmp_path / "x_(channel)_(time|%Y%m%d)_r(row)_c(col).tif")
+    blocks = list(reader.iter_time_chunks(pattern, 2))
+    assert [b[2].shape for b in blocks] == [(2, C, R, Cc, ty, tx), (1, C, R, Cc, ty, tx)] and blocks[0][1] == ["ch0", "ch1"]
+    np.testing.assert_array_equal(np.concatenate([b[2] for b in blocks]), data)
+    eager = list(reader.Reader()(pattern))[0]
+    assert eager.tile.dims == ("channel", "time", "tile_row", "tile_col", "tile_y", "tile_x")
+    np.testing.assert_array_equal(np.asarray(eager.tile.values).transpose(1, 0, 2, 3, 4, 5), data)
+    hs = rng.integers(0, 60000, (4, 2, 16, 20)).astype(np.uint16)
+    ims = [Image.fromarray(hs[t, c]) for t in range(4) for c in range(2)]
+    ims[0].save(tmp_path / "stack.tif", save_all=True, append_images=ims[1:],
+                description="ImageJ=1.53\nimages=8\nchannels=2\nframes=4\nhyperstack=true")
+    got = list(reader.iter_time_chunks(str(tmp_path / "stack.tif"), 3))
+    assert [b[2].shape for b in got] == [(3, 2, 16, 20), (1, 2, 16, 20)] and got[1][0] == [3]
+    np.testing.assert_array_equal(np.concatenate([b[2] for b in got]), hs)
+    with pytest.raises(FileNotFoundError):
+        list(reader.iter_time_chunks(str(tmp_path / "nothing_(time).tif"), 2))
+
+
+def test_save_load_in_parts(tmp_path):
+    """mg.save splits along the marker axis when asked to (or when a variable exceeds NetCDF-3's 4 GiB) and
+    mg.load reassembles the parts, chips included (file.py:6-17)."""
+    import magnify_amd as mg
+
+    ds = _bead_result_dataset()
+    mg.save(tmp_path / "beads.nc", ds, shard_bytes=300)  # roi is 3 marks x 256 B: one mark per part
+    import glob
+
+    parts = sorted(glob.glob(str(tmp_path / "beads.nc.part*")))
+    assert len(parts) == 3 and not (tmp_path / "beads.nc").exists()
+    back = mg.load(tmp_path / "beads.nc")
+    assert set(back.data_vars) == {"image", "roi"} and back.attrs["name"] == "assay0"
+    for k in ("image", "roi"):
+        np.testing.assert_array_equal(back[k].values, ds[k].values)
+        assert back[k].dims == ds[k].dims and back[k].dtype == ds[k].dtype
+    for k in ("fg", "bg", "x", "y", "valid", "channel"):
+        np.testing.assert_array_equal(back.coords[k].values, ds.coords[k].values)
+    one = mg.load(parts[1])  # every part is a complete file of its own
+    np.testing.assert_array_equal(one["roi"].values, ds["roi"].values[1:2])
+    assert "image" not in one.data_vars and int(one.attrs["mg_part"]) == 1
+    with pytest.raises(FileNotFoundError):
+        mg.load(tmp_path / "missing.nc")
+    import os
+
+    os.remove(parts[2])
+    with pytest.raises(ValueError):
+        mg.load(tmp_path / "beads.nc")
+
+
+def test_save_load_beyond_4_gib(tmp_path):
+    """A roi variable of more than 4 GiB (C4's is 9.7 GB; NetCDF-3 holds 4 GiB per variable): saved in parts of
+    2 GiB, loaded back identical.  The source is a sparse memory-mapped file with a few marked pixels."""
+    import magnify_amd as mg
+
+    m, c, L = 56000, 4, 100  # 56000 x 4 x 1 x 100 x 100 uint16 = 4.48 GB
+    src = np.lib.format.open_memmap(tmp_path / "roi.npy", mode="w+", dtype=np.uint16, shape=(m, c, 1, L, L))
+    marks = [0, 1, 26843, 26844, 26845, 55999]  # both sides of the part boundaries
+    for k in marks:
+        src[k, k % c, 0, k % L, (7 * k) % L] = 1 + k % 60000
+    ds = mg.Dataset(attrs={"name": "big"})
+    ds["roi"] = mg.DataArray(src, ("mark", "channel", "time", "roi_y", "roi_x"))
+    ds.coords["x"] = mg.DataArray(np.arange(m, dtype=np.float64)[:, None], ("mark", "time"), name="x")
+    assert src.nbytes > 2**32
+    mg.save(tmp_path / "big.nc", ds)
+    import glob
+
+    parts = sorted(glob.glob(str(tmp_path / "big.nc.part*")))
+    assert len(parts) == 3
+    del ds
+    back = mg.load(tmp_path / "big.nc")
+    roi = back["roi"].values
+    assert roi.shape == (m, c, 1, L, L) and roi.dtype == np.uint16
+    np.testing.assert_array_equal(back.coords["x"].values[:, 0], np.arange(m))
+    for k in marks:
+        assert roi[k, k % c, 0, k % L, (7 * k) % L] == 1 + k % 60000
+    assert int(roi.sum(dtype=np.int64)) == sum(1 + k % 60000 for k in marks)

@@ -273,3 +273,51 @@ def test_streamed_series_equals_whole_stack(mg, tmp_path):
             np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(np.concatenate(got_sums), whole_sums)
     assert sum(len(b) for b in whole["beads"]) > 30
+
+
+def test_streamed_tiled_series_equals_eager_pipeline(mg, tmp_path):
+    """Config C5's path with TILES: (row) / (col) / (channel) / (time) files -> reader.iter_time_chunks (one page
+    at a time, chunked by time) -> stack.process_stream(overlap=...): the flat-field pass crops and joins the
+    tiles on the device, so the stitched assay never exists on the host.  Per timepoint the result equals the
+    eager path (Reader -> flatfield_correct -> Stitcher -> StackProcessor on the stitched stack)."""
+    from PIL import Image
+
+    from magnify_amd import reader
+    from magnify_amd.stack import StackProcessor, process_stream, stitched_shape, synthetic_stack
+
+    T, C, R, Cc, ty, ov = 5, 2, 4, 4, 96, 10
+    step = ty - ov
+    side = (R - 1) * step + ty
+    canvas, _ = synthetic_stack(T, C, side, side, seed=616, beads_per_mpx=400.0)
+    canvas = canvas.cpu().numpy()
+    tiles = np.empty((T, C, R, Cc, ty, ty), dtype=np.uint16)
+    for r in range(R):
+        for c in range(Cc):
+            tiles[:, :, r, c] = canvas[:, :, r * step : r * step + ty, c * step : c * step + ty]
+            for t in range(T):
+                for ch in range(C):
+                    Image.fromarray(tiles[t, ch, r, c]).save(tmp_path / f"a_ch{ch}_202402{t + 10}_r{r}_c{c}.tif")
+    pattern = str(tmp_path / "a_(channel)_(time|%Y%m%d)_r(row)_c(col).tif")
+    kw = dict(num_iter=60000, search_channels=(0,))
+    # eager: the whole assay through the registered reader, then the oracle's stitch of the corrected tiles
+    xp = list(reader.Reader()(pattern))[0]
+    eager_tiles = np.asarray(xp.tile.values).transpose(1, 0, 2, 3, 4, 5)  # (T, C, R, Cc, ty, tx)
+    np.testing.assert_array_equal(eager_tiles, tiles)
+    h, w = stitched_shape(R, Cc, ty, ty, ov)
+    whole = StackProcessor(T, C, h, w, mode="P", tile_grid=(R, Cc, ty, ty), overlap=ov, **kw)
+    want = whole(torch.from_numpy(tiles).cuda(), 0.9, 90.0, seed=31)
+    want_sums = want["sums"].cpu().numpy()
+    for t in range(T):  # the device's stitched image == oracle flat-field (per assay) + stitch
+        ref = rp.stitch(rp.flatfield_correct(tiles[t][:, None], 0.9, 90.0), ov)[:, 0]
+        np.testing.assert_array_equal(whole.image[t].cpu().numpy(), ref)
+    assert sum(len(b) for b in want["beads"]) > 30
+    for chunk in (2, 5):
+        beads, sums = [], []
+        for out in process_stream(reader.iter_time_chunks(pattern, chunk, pinned=True), 0.9, 90.0, seed=31, overlap=ov, **kw):
+            assert out["channel"] == ["ch0", "ch1"]
+            beads += out["beads"]
+            sums.append(out["sums"].cpu().numpy())
+        assert len(beads) == T
+        for a, b in zip(beads, want["beads"]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(np.concatenate(sums), want_sums)
