@@ -136,7 +136,7 @@ class StackProcessor:
                 with torch.cuda.stream(stream):
                     for lo, hi in self.ranges[k :: self.n_streams]:
                         if host:
-                            self.stage[lo:hi].copy_(stack[lo:hi], non_blocking=True)
+                            self.stage.view(stack.shape)[lo:hi].copy_(stack[lo:hi], non_blocking=True)
                         if tiles is not None:
                             hp.flatfield_stitch(tiles[lo * C : hi * C], self.overlap, flatfield, darkfield, out=self.image[lo:hi],
                                                 minmax_out=self.minmax[lo:hi], n_groups=hi - lo)
