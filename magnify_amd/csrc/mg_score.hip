@@ -285,29 +285,22 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
 }
 
 // ---- exact sums of the survivors --------------------------------------------------------------------
-// 16 lanes per survivor (4 survivors per wave): the reference's sum is sequential, but finding the edge pixels on
-// the perimeter and evaluating their gradient angles is not -- with one lane per survivor a wave ran as long as
-// its largest circle's ~100 angle evaluations, one global round trip each.
-//   1. lane t tests the perimeter points t, t + 16, ...; the group's hits are compacted, in perimeter order, into
-//      an LDS list;
-//   2. in passes of 16 hits: every lane evaluates one hit's angle and term, then the 16 terms are added in order
-//      (lane by lane, broadcast over the group) into the float64 sum every lane of the group carries -- with the
-//      reference's early exit: once sum + remaining hits cannot reach the threshold the circle is dropped.
-constexpr int XG = 16;               // lanes per survivor
-constexpr int XPTS = 2 * MAXP / XG;  // perimeter points per lane at most (10)
-
-template <int T>
-__device__ __forceinline__ double group_bcast(double v) {  // lane T of every row of 16 to the whole row
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + T, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + T, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
+// The reference's sum is sequential per circle, but finding the edge pixels on a perimeter and evaluating their
+// gradient angles is not, and most survivors are dropped after a handful of terms (sum + remaining hits can no
+// longer reach the threshold).  A workgroup takes XS survivors per round:
+//   1. four lanes per survivor test its perimeter points against the edge bitmap -> a hit mask per survivor;
+//   2. a lane per survivor turns the mask into the list of its hits, in perimeter order;
+//   3. all lanes evaluate (survivor, hit) pairs: the next `ch` hits of every survivor that is still undecided --
+//      angle on demand from the blurred image, term in float64 -- `ch` grows as the undecided get fewer;
+//   4. a lane per survivor adds its terms in order with the early exit, and the undecided are listed again.
+constexpr int XS = 64;       // survivors per workgroup and round
+constexpr int XCH_MAX = 32;  // hits per survivor evaluated per step, at most
+constexpr int XPMAX = 2 * MAXP;
 
 __global__ __launch_bounds__(NT) void k_exact(const uint8_t* __restrict__ d_blur, const float* __restrict__ d_angle,
                                               const uint32_t* __restrict__ d_bits, int64_t words_per_plane, int h, int w,
-                                              int32_t* __restrict__ d_circles, int64_t circle_cap,
-                                              const uint32_t* __restrict__ d_ukeys, int ntc, int min_r, int max_r,
-                                              const int32_t* __restrict__ d_per_rc, int per_total,
+                                              int32_t* __restrict__ d_circles, int64_t circle_cap, int ntc, int min_r,
+                                              int max_r, const int32_t* __restrict__ d_per_rc, int per_total,
                                               const double* __restrict__ d_per_expected,
                                               const int32_t* __restrict__ d_per_starts, float min_roundness,
                                               int write_skipped, float* __restrict__ d_scores,
@@ -315,20 +308,17 @@ __global__ __launch_bounds__(NT) void k_exact(const uint8_t* __restrict__ d_blur
                                               int32_t* __restrict__ d_max_rc, int32_t* __restrict__ d_num_scored,
                                               const int32_t* __restrict__ d_surv, int64_t surv_cap,
                                               const int32_t* __restrict__ d_num_surv) {
-  extern __shared__ __attribute__((aligned(16))) double expd[];  // [per_total] expected angles, then [per_total] packed (dr, dc)
-  __shared__ uint16_t hits[NT / XG][2 * MAXP];                    // per group: the perimeter indices of its hits, in order
+  extern __shared__ __attribute__((aligned(16))) int32_t tab[];  // [per_total] (dr << 16) | (dc & 0xFFFF)
+  __shared__ double s_term[XS][XCH_MAX];
+  __shared__ uint32_t s_mask[XS][XPMAX / 32];
+  __shared__ uint8_t s_hits[XS][XPMAX];
+  __shared__ int s_row[XS], s_col[XS], s_p0[XS], s_p1[XS], s_nh[XS], s_base[XS], s_list[XS], s_n;
   __shared__ int32_t starts[34];
   const int plane = blockIdx.y;
   const int64_t n = min((int64_t)d_num_surv[plane], surv_cap);
-  constexpr int GPB = NT / XG;  // survivors per block and pass
-  if ((int64_t)blockIdx.x * GPB >= n) return;  // block-uniform
-  int32_t* tab = reinterpret_cast<int32_t*>(expd + per_total);  // (dr << 16) | (dc & 0xFFFF)
-  for (int i = threadIdx.x; i < per_total; i += NT) {
-    tab[i] = (d_per_rc[2 * i] << 16) | (d_per_rc[2 * i + 1] & 0xFFFF);
-    expd[i] = d_per_expected[i];
-  }
+  if ((int64_t)blockIdx.x * XS >= n) return;  // block-uniform
+  for (int i = threadIdx.x; i < per_total; i += NT) tab[i] = (d_per_rc[2 * i] << 16) | (d_per_rc[2 * i + 1] & 0xFFFF);
   if ((int)threadIdx.x <= max_r - min_r + 1) starts[threadIdx.x] = d_per_starts[threadIdx.x];
-  __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0 && d_num_scored) d_num_scored[plane] = (int32_t)n;
   int32_t* circles = d_circles + (int64_t)plane * circle_cap * 3;
   const uint32_t* bits = d_bits + plane * words_per_plane;
@@ -336,98 +326,136 @@ __global__ __launch_bounds__(NT) void k_exact(const uint8_t* __restrict__ d_blur
   const float* ang = d_angle ? d_angle + (int64_t)plane * h * w : nullptr;
   float* scores = d_scores + (int64_t)plane * circle_cap;
   const double PI = 3.141592653589793, INV_PI = 1.0 / 3.141592653589793;
-  const int g = threadIdx.x / XG, t = threadIdx.x % XG, lane = threadIdx.x & 63;
-  uint16_t* my_hits = hits[g];
-  // every group of the wave runs the same number of rounds (the loops below hold wave-wide operations)
-  const int64_t rounds = (n + (int64_t)gridDim.x * GPB - 1) / ((int64_t)gridDim.x * GPB);
+  const int t = threadIdx.x, lane = t & 63;
+  const int64_t rounds = (n + (int64_t)gridDim.x * XS - 1) / ((int64_t)gridDim.x * XS);
   for (int64_t rd = 0; rd < rounds; ++rd) {
-    const int64_t k = (rd * gridDim.x + blockIdx.x) * GPB + g;
-    const bool active = k < n;
-    // record = (index in the plane's key list, key): written by the prefilter, no dependent load here
-    const int2 rec = active ? reinterpret_cast<const int2*>(d_surv)[(int64_t)plane * surv_cap + k] : make_int2(0, 0);
-    const int64_t i = rec.x;
-    const uint32_t key = (uint32_t)rec.y;
-    const int tile = (int)(key >> 17);
-    const int row = (tile / ntc) * TS - max_r + (int)((key >> 6) & 63u), col = (tile % ntc) * TS - max_r + (int)(key & 63u);
-    const int rad = min_r + (int)((key >> 12) & 31u);
-    const int p0 = starts[rad - min_r], p1 = active ? starts[rad - min_r + 1] : p0;
-    const double floor_sum = (double)min_roundness * (double)(p1 - p0) - 1e-3;
-    // 1. this lane's perimeter points: edge pixel?  (all loads in flight together)
-    uint32_t wv[XPTS];
-    int bi[XPTS];
-#pragma unroll
-    for (int m = 0; m < XPTS; ++m) {
-      const int p = p0 + t + XG * m;
-      const int v = tab[min(p, per_total - 1)];
-      const int y = row + (v >> 16), x = col + (int)(int16_t)(v & 0xFFFF);
-      const bool inb = p < p1 && y >= 0 && y < h && x >= 0 && x < w;
-      bi[m] = inb ? y * w + x : -1;
-      wv[m] = bits[max(bi[m], 0) >> 5];
+    __syncthreads();  // tables in place / the previous round's lists are no longer read
+    // 0. the round's survivors (threads 0..63 = wave 0 own one each)
+    int64_t ci = 0;      // index in the plane's key list
+    int rad = 0;
+    bool active = false, dead = true;
+    double acc = 0.0, floor_sum = 0.0;
+    int left = 0;
+    if (t < XS) {
+      const int64_t k = (rd * gridDim.x + blockIdx.x) * XS + t;
+      active = k < n;
+      // record = (index in the plane's key list, key): written by the prefilter, no dependent load here
+      const int2 rec = active ? reinterpret_cast<const int2*>(d_surv)[(int64_t)plane * surv_cap + k] : make_int2(0, 0);
+      ci = rec.x;
+      const uint32_t key = (uint32_t)rec.y;
+      const int tile = (int)(key >> 17);
+      rad = min_r + (int)((key >> 12) & 31u);
+      s_row[t] = (tile / ntc) * TS - max_r + (int)((key >> 6) & 63u);
+      s_col[t] = (tile % ntc) * TS - max_r + (int)(key & 63u);
+      s_p0[t] = starts[rad - min_r];
+      s_p1[t] = active ? starts[rad - min_r + 1] : s_p0[t];
+      floor_sum = (double)min_roundness * (double)(s_p1[t] - s_p0[t]) - 1e-3;
     }
-    int mine = 0;  // bit m: point t + 16 m is an edge pixel
+    for (int i = t; i < XS * (XPMAX / 32); i += NT) (&s_mask[0][0])[i] = 0u;
+    __syncthreads();
+    // 1. hit masks: four lanes per survivor, four loads in flight per lane
+    {
+      const int s = t >> 2, j0 = t & 3;
+      const int row = s_row[s], col = s_col[s], p0 = s_p0[s], len = s_p1[s] - p0;
+      for (int j = j0; j < len; j += 16) {
+        uint32_t wv[4];
+        int bi[4];
 #pragma unroll
-    for (int m = 0; m < XPTS; ++m) mine |= (bi[m] >= 0 ? (int)((wv[m] >> (bi[m] & 31)) & 1u) : 0) << m;
-    // compaction in perimeter order (m major, lane minor): rank = hits of all lanes in earlier rows m + hits of the
-    // earlier lanes in this row
-    int n_hits = 0;
+        for (int u = 0; u < 4; ++u) {
+          const int jj = j + 4 * u;
+          const int v = tab[p0 + min(jj, len - 1)];
+          const int y = row + (v >> 16), x = col + (int)(int16_t)(v & 0xFFFF);
+          const bool inb = jj < len && y >= 0 && y < h && x >= 0 && x < w;
+          bi[u] = inb ? y * w + x : -1;
+          wv[u] = bits[max(bi[u], 0) >> 5];
+        }
 #pragma unroll
-    for (int m = 0; m < XPTS; ++m) {
-      const uint64_t bal = __ballot((mine >> m) & 1);
-      const uint32_t grp = (uint32_t)(bal >> (lane & 48)) & 0xFFFFu;  // this group's 16 lanes
-      if ((mine >> m) & 1) my_hits[n_hits + __builtin_popcount(grp & ((1u << t) - 1u))] = (uint16_t)(p0 + t + XG * m);
-      n_hits += __builtin_popcount(grp);
-    }
-    __builtin_amdgcn_wave_barrier();
-    // 2. passes of 16 hits
-    double acc = 0.0;
-    int left = n_hits;  // edge pixels not yet summed: each adds at most 1 (+1.2e-7, inside the margin)
-    bool dead = !active || (double)left < floor_sum;
-    for (int base = 0; base < n_hits && !dead; base += XG) {  // (group-uniform: the broadcasts stay inside a row of 16)
-      double term = 0.0;
-      if (!dead && base + t < n_hits) {
-        const int p = my_hits[base + t];
-        const int v = tab[p];
-        const int y = row + (v >> 16), x = col + (int)(int16_t)(v & 0xFFFF);
-        const float a = ang ? ang[(int64_t)y * w + x] : mg_edge_angle(blur, h, w, y, x);
-        double d = fabs((double)a - expd[p]);
-        if (d > PI) d = d - PI;
-        // x / pi, correctly rounded without the division (Markstein: y = RN(1/pi), q0 = RN(x y),
-        // r = x - q0 pi exactly by FMA, q = RN(q0 + r y) == RN(x / pi); verified against x / pi on 1e9
-        // operands of exactly this form)
-        const double x4 = 4.0 * fabs(d - PI / 2.0);
-        const double q0 = x4 * INV_PI;
-        term = fma(fma(-q0, PI, x4), INV_PI, q0) - 1.0;
+        for (int u = 0; u < 4; ++u) {
+          const int jj = j + 4 * u;
+          if (bi[u] >= 0 && ((wv[u] >> (bi[u] & 31)) & 1u)) atomicOr(&s_mask[s][jj >> 5], 1u << (jj & 31));
+        }
       }
-      const int cnt = min(XG, n_hits - base);
-#define MG_ADD(T)                                                                       \
-  {                                                                                     \
-    const double v_ = group_bcast<T>(term);                                             \
-    if (!dead && T < cnt) {                                                             \
-      acc += v_;                                                                        \
-      --left;                                                                           \
-      if (acc + (double)left < floor_sum) dead = true; /* exact: the rest adds <= 1 each */ \
-    }                                                                                   \
+    }
+    __syncthreads();
+    // 2. hit lists in perimeter order; the undecided survivors
+    if (t < XS) {
+      int nh = 0;
+#pragma unroll
+      for (int wd = 0; wd < XPMAX / 32; ++wd) {
+        uint32_t m = s_mask[t][wd];
+        while (m) {
+          s_hits[t][nh++] = (uint8_t)(32 * wd + __ffs(m) - 1);
+          m &= m - 1;
+        }
+      }
+      s_nh[t] = nh;
+      s_base[t] = 0;
+      left = nh;  // edge pixels not yet summed: each adds at most 1 (+1.2e-7, inside the margin)
+      dead = !active || (double)left < floor_sum;
+      const bool open = !dead && nh > 0;
+      const uint64_t om = __ballot(open);
+      if (open) s_list[__builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u))] = t;
+      if (t == 0) s_n = __builtin_popcountll(om);
+    }
+    __syncthreads();
+    // 3. + 4. until every survivor of the round is decided
+    for (int na = s_n; na > 0; na = s_n) {
+      const int ch = min(XCH_MAX, max(8, (2 * NT / na) & ~7));
+      for (int pair = t; pair < na * ch; pair += NT) {
+        const int s = s_list[pair / ch], j = pair % ch;
+        const int idx = s_base[s] + j;
+        if (idx < s_nh[s]) {
+          const int p = s_p0[s] + s_hits[s][idx];
+          const int v = tab[p];
+          const int y = s_row[s] + (v >> 16), x = s_col[s] + (int)(int16_t)(v & 0xFFFF);
+          const float a = ang ? ang[(int64_t)y * w + x] : mg_edge_angle(blur, h, w, y, x);
+          double d = fabs((double)a - d_per_expected[p]);
+          if (d > PI) d = d - PI;
+          // x / pi, correctly rounded without the division (Markstein: y = RN(1/pi), q0 = RN(x y),
+          // r = x - q0 pi exactly by FMA, q = RN(q0 + r y) == RN(x / pi); verified against x / pi on 1e9
+          // operands of exactly this form)
+          const double x4 = 4.0 * fabs(d - PI / 2.0);
+          const double q0 = x4 * INV_PI;
+          s_term[s][j] = fma(fma(-q0, PI, x4), INV_PI, q0) - 1.0;
+        }
+      }
+      __syncthreads();
+      if (t < XS) {
+        bool open = false;
+        if (!dead && s_base[t] < s_nh[t]) {
+          const int cnt = min(ch, s_nh[t] - s_base[t]);
+          for (int j = 0; j < cnt && !dead; ++j) {
+            acc += s_term[t][j];
+            --left;
+            if (acc + (double)left < floor_sum) dead = true;  // exact: the remaining hits add <= 1 each
+          }
+          s_base[t] += cnt;
+          open = !dead && s_base[t] < s_nh[t];
+        }
+        const uint64_t om = __ballot(open);
+        if (open) s_list[__builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u))] = t;
+        if (t == 0) s_n = __builtin_popcountll(om);
+      }
+      __syncthreads();
+    }
+    // 5. results
+    if (t < XS && active) {
+      if (dead) {
+        if (write_skipped & 1) scores[ci] = MG_SCORE_SKIPPED;
+      } else {
+        const float score = (float)acc / (float)(s_p1[t] - s_p0[t]);
+        scores[ci] = score;
+        if (score >= min_roundness) {
+          const int k_ = atomicAdd(&d_num_alive[plane], 1);
+          d_alive[(int64_t)plane * circle_cap + k_] = (int32_t)ci;
+          circles[3 * ci] = s_row[t], circles[3 * ci + 1] = s_col[t], circles[3 * ci + 2] = rad;
+          atomicMax(&d_max_rc[2 * plane], s_row[t]);
+          atomicMax(&d_max_rc[2 * plane + 1], s_col[t]);
+        }
+      }
+    }
   }
-      MG_ADD(0) MG_ADD(1) MG_ADD(2) MG_ADD(3) MG_ADD(4) MG_ADD(5) MG_ADD(6) MG_ADD(7)
-      MG_ADD(8) MG_ADD(9) MG_ADD(10) MG_ADD(11) MG_ADD(12) MG_ADD(13) MG_ADD(14) MG_ADD(15)
-#undef MG_ADD
-    }
-    __builtin_amdgcn_wave_barrier();  // the hit list is rewritten by the next round
-    if (t != 0 || !active) continue;
-    if (dead) {
-      if (write_skipped & 1) scores[i] = MG_SCORE_SKIPPED;
-      continue;
-    }
-    const float score = (float)acc / (float)(p1 - p0);
-    scores[i] = score;
-    if (score >= min_roundness) {
-      const int k_ = atomicAdd(&d_num_alive[plane], 1);
-      d_alive[(int64_t)plane * circle_cap + k_] = (int32_t)i;
-      circles[3 * i] = row, circles[3 * i + 1] = col, circles[3 * i + 2] = rad;
-      atomicMax(&d_max_rc[2 * plane], row);
-      atomicMax(&d_max_rc[2 * plane + 1], col);
-    }
-  }
+  (void)lane;
 }
 
 }  // namespace
@@ -478,11 +506,13 @@ extern "C" int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angl
                      reinterpret_cast<const uint2*>(d_pair_table), d_per_starts, min_roundness, write_skipped, d_scores,
                      d_surv_list, surv_cap, d_num_surv);
   MG_CHECK_LAUNCH();
+  // blocks per plane: enough to fill the chip at any batch size, few enough to amortise the table load
+  const int xblocks = std::max(16, std::min(256, 4096 / std::max(n_planes, 1)));
   if (!(write_skipped & 8))
-  hipLaunchKernelGGL(k_exact, dim3(32, n_planes), dim3(NT), (size_t)per_total * 12, s, d_blur, d_angle, d_edge_bits,
-                     words_per_plane, h, w, d_circles, circle_cap, d_unique_keys, ntc, min_r, max_r, d_per_rc, per_total,
-                     d_per_expected, d_per_starts, min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc,
-                     d_num_scored, d_surv_list, surv_cap, d_num_surv);
+    hipLaunchKernelGGL(k_exact, dim3(xblocks, n_planes), dim3(NT), (size_t)per_total * 4, s, d_blur, d_angle, d_edge_bits,
+                       words_per_plane, h, w, d_circles, circle_cap, ntc, min_r, max_r, d_per_rc, per_total,
+                       d_per_expected, d_per_starts, min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc,
+                       d_num_scored, d_surv_list, surv_cap, d_num_surv);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
