@@ -43,7 +43,10 @@ def algorithmic_bytes(stage, p):
         "mg_candidate_circles": 28 * planes * p["num_iter"],  # 3 coordinate reads (8 B) + the 32-bit key
         # keys read once, the unique keys written once (tile by tile, from LDS)
         "mg_bitmap_to_circles": 4 * planes * p["num_iter"] + 4 * p["unique"],
-        "mg_score_circles": p["unique"] * (4 + p["mean_perimeter"] / 8 + 4),  # key + perimeter edge bits + score
+        # keyed scoring: every unique key once + the four bit planes (edges + 3 orientation planes) of the searched
+        # planes once + the survivors' records and scores; its real bound is the LDS (one byte read per perimeter
+        # point), the HBM bytes are small
+        "mg_score_circles": p["unique"] * 4 + planes * n / 8 * 4 + p.get("scored", 0) * 16,
         "mg_nms_round": p["alive"] * p["ring_len"] * 16 * p["nms_rounds"],
         "mg_collect_circles": p["alive"] * 4 + p["markers"] * 16,
         "mg_circle_labels": p["markers"] * p["mean_disk"] * 8,
@@ -83,8 +86,9 @@ def cpu_baseline(args, stack, flat_np, seeds, gpu_counts, gpu_fg_sums):
 # what actually bounds a stage when it is not HBM bandwidth; `roofline` still prices it
 # against the HBM peak, as the contract asks
 STAGE_NOTES = {
-    "mg_score_circles": "LDS-bound: ~2e10 perimeter tests per step are random LDS word reads (bank conflicts ~3.5 "
-                        "cycles each); its HBM bytes are the 4-byte circle keys, edge bits and scores only",
+    "mg_score_circles": "LDS-bound: one random LDS byte read per perimeter point and circle (~8 LDS cycles per wave "
+                        "read measured with 32 random dwords per half-wave, tools/micro/walk_bench.hip); its HBM bytes "
+                        "are the 4-byte circle keys and the bit planes only",
     "mg_canny_nms": "VALU-issue bound (OpenCV's sector compares / selects)",
     "mg_candidate_circles": "VALU bound (three float64 divisions per RANSAC iteration)",
 }
@@ -92,6 +96,37 @@ STAGE_NOTES = {
 STREAM_STAGES = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_to_uint8_blur", "mg_scharr_hist", "mg_canny_nms",
                  "mg_canny_hysteresis", "mg_edge_grid", "mg_edge_angles", "mg_circle_labels",
                  "mg_roi_gather_reduce_batched", "mg_roi_segment_reduce"]
+
+
+def source_hash():
+    """Hash of the sources that decide what the kernels do and how they are launched: the PMC traffic file under
+    profiles/ carries the hash it was measured on, and `traffic` is only reported while it still matches
+    (the GPU box has no .git to ask for a commit)."""
+    import glob
+    import hashlib
+
+    hsh = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "magnify_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "magnify_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(ROOT, "include", "*.h"))
+                   + [os.path.join(ROOT, "magnify_amd", f) for f in ("hotpath.py", "stack.py")])
+    for f in files:
+        hsh.update(os.path.basename(f).encode())
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def load_traffic(shape_key):
+    """Newest profiles/r*_pmc_traffic.json measured on exactly these sources and this workload, or None."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if rec.get("source_hash") == source_hash() and tuple(rec.get("shape", ())) == tuple(shape_key):
+            return rec["stages"], os.path.basename(f)
+    return None, None
 
 
 def stage_report(stages, steps, p, pmc, stream_bytes):
@@ -119,7 +154,9 @@ def stage_report(stages, steps, p, pmc, stream_bytes):
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "algorithmic_bytes_per_launch": ab, "avg_launch_ms": dom_ms / dom_n,
                 "launches_per_step": launches_per_step, "share_of_kernel_time": dom_ms / total_ms,
-                "note": STAGE_NOTES.get(dom)}
+                "note": STAGE_NOTES.get(dom),
+                # what the counters show to limit the stage (profiles/): `bound` keeps the contract's vocabulary
+                "limiter": {"mg_score_circles": "lds", "mg_canny_nms": "valu", "mg_candidate_circles": "valu"}.get(dom, "hbm")}
     stream_ms = sum(stages[s][0] for s in STREAM_STAGES if s in stages) / steps
     streaming = {"ms_per_step": stream_ms, "algorithmic_bytes": stream_bytes,
                  "achieved_GBs": stream_bytes / (stream_ms / 1e3) / 1e9 if stream_ms else None,
@@ -300,20 +337,22 @@ def main():
              "hist_passes": max(x.get("hist_passes", 1) for x in fstats),
              "sweeps": max(x.get("hysteresis_sweeps", 1) for x in fstats),
              "nms_rounds": max(x.get("nms_rounds", 1) for x in fstats),
-             "edges": edges, "bitmap_words": f.bitmap_words, "unique": unique, "alive": alive,
+             "edges": edges, "bitmap_words": f.bitmap_words, "unique": unique, "alive": alive, "scored": scored,
              "mean_perimeter": mean_perimeter, "ring_len": len(hp.nat.circle_points(proc.min_r, True)),
              "markers": markers_local, "mean_disk": 600, "L": proc.L}
-        pmc = None
-        try:  # HBM bytes per step from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json)
-            if (T, C, S, args.num_iter) == (64, 4, 4096, 5_000_000):
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["stages"]
-        except (OSError, KeyError, ValueError):
-            pmc = None
+        # HBM bytes per step from the committed rocprofv3 PMC passes: only when they were taken on these sources
+        pmc, pmc_file = load_traffic((T, C, S, args.num_iter))
         n_all, n_s = T * C * S * S, search_planes * S * S
         # SURVEY.md 8d's count minus the label map this build no longer writes (4 B/px of the searched
         # planes) or reads (4 B per window pixel): masks come straight from the bead tables
         stream_bytes = 6 * n_all + 8 * n_s + markers_local * proc.L**2 * (4 * C + 2)
         breakdown, roofline, streaming, total_ms = stage_report(stages, args.steps, p, pmc, stream_bytes)
+        roofline["traffic_source"] = pmc_file  # None: no PMC pass on these exact sources under profiles/
+        # SURVEY 8d's byte count of the whole step, B = 6 N_all + 12 N_s + K_u (12 + 5 P) + M L^2 (4 C + 6), with K_u
+        # the circles that reach the exact sum; against the wall-clock step (kernels + host round trips)
+        b8d = 6 * n_all + 12 * n_s + scored * (12 + 5 * mean_perimeter) + markers_local * proc.L**2 * (4 * C + 6)
+        whole = {"algorithmic_bytes_survey_8d": b8d, "ms_per_step": ms_per_step,
+                 "achieved_GBs": b8d / (ms_per_step / 1e3) / 1e9, "frac_of_peak": b8d / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS}
         isolated = None
         if world == 1 and proc.n_streams > 1 and not args.no_isolated:
             # the same step once more on ONE stream (untimed for `value`): kernel durations without the
@@ -354,6 +393,7 @@ def main():
             "strong": strong_extra,
             "markers_per_s": markers_total / (dt / args.steps), "markers": markers_total,
             "roofline": roofline,
+            "whole_step": whole,
             "streaming_part": streaming,
             "stages": breakdown,
             "isolated": isolated,
@@ -364,7 +404,7 @@ def main():
                       "kernel_ms_per_step": total_ms / args.steps},
         }
         result["hbm_copy_ceiling"] = hbm_copy_ceiling(dev)
-        for part in (roofline, streaming):
+        for part in (roofline, streaming, whole):
             if part and result["hbm_copy_ceiling"]:
                 gbs = part.get("achieved", part.get("achieved_GBs"))
                 part["frac_of_measured_copy"] = gbs / result["hbm_copy_ceiling"]["GBs"] if gbs else None

@@ -13,7 +13,8 @@ shutil.copy(glob.glob(f"{stats_dir}/**/*kernel_stats.csv", recursive=True)[0], f
 STAGE_OF = {"k_flatfield_max": "mg_flatfield_max", "k_apply_stitch": "mg_flatfield_apply_stitch", "k_u8_blur": "mg_to_uint8_blur",
             "k_scharr_hist": "mg_scharr_hist", "k_canny_nms": "mg_canny_nms", "k_hysteresis": "mg_canny_hysteresis",
             "k_cell_": "mg_edge_grid", "k_edge_angles": "mg_edge_angles", "k_candidates": "mg_candidate_circles",
-            "k_layer_": "mg_bitmap_to_circles", "k_tile_": "mg_bitmap_to_circles", "k_score_tiles": "mg_score_circles", "k_nms<": "mg_nms_round",
+            "k_layer_": "mg_bitmap_to_circles", "k_tile_": "mg_bitmap_to_circles", "k_score_tiles": "mg_score_circles",
+            "k_prefilter": "mg_score_circles", "k_exact": "mg_score_circles", "k_nms<": "mg_nms_round",
             "k_collect": "mg_collect_circles", "k_clamp": "mg_collect_circles", "k_circle_labels": "mg_circle_labels",
             "k_roi": "mg_roi_segment_reduce"}
 
@@ -38,7 +39,11 @@ for st in sorted(set(f) | set(w)):
     res[st] = {"fetch_bytes_per_step_corrected_x2": fetch, "fetch_bytes_per_step_raw": fetch / 2,
                "write_bytes_per_step": write, "hbm_bytes_per_step": fetch + write}
     print(f"{st:34s} fetch(x2) {fetch / 1e9:7.2f} GB  write {write / 1e9:7.2f} GB")
+sys.path.insert(0, ".")
+import bench  # noqa: E402  (source_hash: the file is only trusted while the sources are the ones it was measured on)
+
 json.dump({"workload": "C4 64x4x4096x4096 u16, mode P, num_iter 5e6 (bench.py defaults)",
+           "shape": [64, 4, 4096, 5000000], "source_hash": bench.source_hash(),
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per "
                    "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); KB -> bytes; per bench step",
-           "stages": res}, open("profiles/r1_pmc_traffic.json", "w"), indent=1)
+           "stages": res}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
