@@ -121,6 +121,16 @@ int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w, int mode, 
  * d_scratch == NULL selects the atomic hand-over. */
 int64_t mg_scharr_hist_scratch_words(int n_planes, int h, int w, int mode);
 
+/* np.quantile(grad, q) for the two Canny quantiles and cv::Canny's threshold preparation (utils.py:126-134),
+ * from the combined histogram of mg_scharr_hist (mode 0), on the device: ranks4 (HOST array) = the prev / next
+ * order-statistic indices of numpy's linear interpolation for the low and the high quantile, gamma_* its
+ * float32 weights (magnify_amd.hotpath.quantile_indexes).  Outputs d_thresh[n_planes][2] (the integer
+ * thresholds mg_canny_nms takes), d_quantiles[n_planes][2] (float32, what np.quantile returns) and
+ * d_unresolved[n_planes]: 1 where a rank falls into a coarse bin (the caller then resolves it with mode-1
+ * window passes of mg_scharr_hist; thresholds of such a plane are not valid). */
+int mg_edge_thresholds(const uint32_t* d_hist, int n_planes, const int64_t* ranks4, float gamma_low, float gamma_high,
+                       int32_t* d_thresh, float* d_quantiles, int32_t* d_unresolved, void* stream);
+
 /* Bitmaps over pixels use the linear layout bit i of word k <-> pixel 32 k + i (i = y * w + x);
  * words_per_plane >= ceil(h w / 32) + 1. */
 

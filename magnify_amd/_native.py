@@ -37,6 +37,7 @@ PROTOTYPES = {
     "mg_to_uint8_blur": [_p, _i, _i, _l, _i, _i, _l, _p, _p, _p, _p],
     "mg_scharr_hist": [_p, _i, _i, _i, _i, _p, _p, _p, _l, _p],
     "mg_scharr_hist_scratch_words": [_i, _i, _i, _i],
+    "mg_edge_thresholds": [_p, _i, _p, _f, _f, _p, _p, _p, _p],
     "mg_canny_nms": [_p, _i, _i, _i, _p, _p, _p, _p, _l, _p],
     "mg_canny_hysteresis": [_p, _p, _l, _i, _i, _i, _p, _p, _p, _p],
     "mg_unpack_bits": [_p, _l, _i, _l, _p, _p],

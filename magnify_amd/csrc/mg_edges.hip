@@ -425,6 +425,72 @@ __global__ __launch_bounds__(NT) void k_hist_reduce(const uint32_t* __restrict__
   out[2 * i + 1] += hi;  // which has completed: kernels on a stream run in order
 }
 
+// ---- K2b: np.quantile + cv::Canny's threshold preparation, from the histogram, on the device -----------------
+// One workgroup per plane.  The order statistics of ranks[0..3] (= prev / next index of np.quantile's linear
+// interpolation for the low and the high quantile) are the bins where the running sum of the histogram first
+// exceeds the rank; a fine bin IS the value m = dx^2 + dy^2.  Then, exactly as NumPy 2.x and OpenCV do it
+// (utils.py:120-134): g = sqrt(float32(m)) in float32, _lerp in float32 with the float32 weight gamma, the two
+// thresholds ordered, clamped to 32767, squared in float64 and floored.  A rank that falls into a COARSE bin
+// (strong gradients: noiseless images) cannot be resolved here: d_unresolved[plane] = 1 and the caller takes the
+// window-histogram path for that call.
+__global__ __launch_bounds__(NT) void k_edge_thresholds(const uint32_t* __restrict__ d_hist, int n_fine, int n_bins,
+                                                        long long r0, long long r1, long long r2, long long r3,
+                                                        float gamma_lo, float gamma_hi, int32_t* __restrict__ d_thresh,
+                                                        float* __restrict__ d_quantiles, int32_t* __restrict__ d_unresolved) {
+  __shared__ int s_bin[4];
+  const int plane = blockIdx.x;
+  const uint32_t* hist = d_hist + (int64_t)plane * n_bins;
+  const int per = (n_bins + NT - 1) / NT;
+  const int b0 = threadIdx.x * per, b1 = min(b0 + per, n_bins);
+  long long mine = 0;
+  for (int b = b0; b < b1; ++b) mine += hist[b];
+  // exclusive prefix of the chunk sums (64-bit: a plane holds up to 2^31 pixels)
+  __shared__ long long s_pre[NT];
+  s_pre[threadIdx.x] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long run = 0;
+    for (int i = 0; i < NT; ++i) {
+      const long long v = s_pre[i];
+      s_pre[i] = run;
+      run += v;
+    }
+  }
+  if (threadIdx.x < 4) s_bin[threadIdx.x] = n_bins;  // rank beyond the data: unresolved
+  __syncthreads();
+  const long long ranks[4] = {r0, r1, r2, r3};
+  long long run = s_pre[threadIdx.x];
+  for (int b = b0; b < b1; ++b) {
+    const long long nxt = run + hist[b];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (run <= ranks[k] && ranks[k] < nxt) s_bin[k] = b;  // first bin whose running sum exceeds the rank
+    run = nxt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool ok = s_bin[0] < n_fine && s_bin[1] < n_fine && s_bin[2] < n_fine && s_bin[3] < n_fine;
+    d_unresolved[plane] = ok ? 0 : 1;
+    float q[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float ga = (float)sqrt((double)s_bin[2 * k]), gb = (float)sqrt((double)s_bin[2 * k + 1]);  // == float32 sqrt
+      const float gamma = k == 0 ? gamma_lo : gamma_hi;
+      const float diff = gb - ga;
+      q[k] = gamma >= 0.5f ? gb - diff * (1.0f - gamma) : ga + diff * gamma;  // numpy's _lerp, float32 throughout
+    }
+    double lo = (double)fminf(q[0], q[1]), hi = (double)fmaxf(q[0], q[1]);
+    lo = fmin(lo, 32767.0);
+    hi = fmin(hi, 32767.0);
+    if (lo > 0.0) lo = lo * lo;
+    if (hi > 0.0) hi = hi * hi;
+    d_thresh[2 * plane] = (int32_t)floor(lo);
+    d_thresh[2 * plane + 1] = (int32_t)floor(hi);
+    d_quantiles[2 * plane] = q[0];
+    d_quantiles[2 * plane + 1] = q[1];
+  }
+}
+
 // ---- bit helpers on the linear (y * w + x) bitmaps --------------------------------------------
 __device__ __forceinline__ uint32_t bits_at(const uint32_t* __restrict__ bits, int64_t bit0, int n) {
   // n (1..32) consecutive bits starting at linear bit index bit0
@@ -895,6 +961,18 @@ extern "C" int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w,
                        d_scratch, (int)(g.x * g.y), n_bins, d_hist);
     MG_CHECK_LAUNCH();
   }
+  return MG_OK;
+}
+
+extern "C" int mg_edge_thresholds(const uint32_t* d_hist, int n_planes, const int64_t* ranks4, float gamma_low,
+                                  float gamma_high, int32_t* d_thresh, float* d_quantiles, int32_t* d_unresolved,
+                                  void* stream) {
+  if (!d_hist || !ranks4 || !d_thresh || !d_quantiles || !d_unresolved || n_planes < 0) return MG_EINVAL;
+  if (n_planes == 0) return MG_OK;
+  hipLaunchKernelGGL(k_edge_thresholds, dim3(n_planes), dim3(NT), 0, mg_stream(stream), d_hist, FINE, FINE + COARSE,
+                     (long long)ranks4[0], (long long)ranks4[1], (long long)ranks4[2], (long long)ranks4[3], gamma_low,
+                     gamma_high, d_thresh, d_quantiles, d_unresolved);
+  MG_CHECK_LAUNCH();
   return MG_OK;
 }
 

@@ -277,6 +277,9 @@ class CircleFinder:
         # per-workgroup histogram slots: plain stores + a reduce kernel instead of global atomics
         self.hist_scratch = torch.empty((int(nat.lib().mg_scharr_hist_scratch_words(P, h, w, 0)),), dtype=i32, device=dev)
         self.thresh = torch.zeros((P, 2), dtype=i32, device=dev)
+        self.quant_d = torch.zeros((P, 2), dtype=torch.float32, device=dev)  # np.quantile's two values per plane
+        self.unresolved = torch.zeros((P,), dtype=i32, device=dev)
+        self._thresh_on_host, self._quantiles = False, None
         self.changed = torch.zeros((4, P), dtype=i32, device=dev)
         tx, ty = nat.C.c_int(0), nat.C.c_int(0)
         nat.check(nat.lib().mg_hysteresis_tiles(h, w, nat.C.byref(tx), nat.C.byref(ty)), "mg_hysteresis_tiles")
@@ -356,6 +359,48 @@ class CircleFinder:
               self.hist_scratch.numel(), s)
         n = h * w
         idx = [quantile_indexes(n, q) for q in (low_q, high_q)]  # (prev, next, gamma) per quantile
+        # Thresholds on the device (mg_edge_thresholds: no host round trip, no ATen kernels) unless the previous call
+        # showed that this kind of image needs the window passes (ranks inside coarse bins: noiseless images);
+        # whether they were needed THIS time rides on the hysteresis convergence check below.
+        on_device = not self._thresh_on_host
+        if on_device:
+            ranks4 = np.array([idx[0][0], idx[0][1], idx[1][0], idx[1][1]], dtype=np.int64)
+            _call("mg_edge_thresholds", self.hist.data_ptr(), P, ranks4.ctypes.data, float(idx[0][2]), float(idx[1][2]),
+                  self.thresh.data_ptr(), self.quant_d.data_ptr(), self.unresolved.data_ptr(), s)
+            self._quantiles = None
+            self.stats["hist_passes"] = 1
+        else:
+            self._thresholds_on_host(idx, n)
+        n_edges, sweeps, needed, unresolved = self._edges_from_thresholds(on_device)
+        if on_device and unresolved:
+            self._thresh_on_host = True
+            self._thresholds_on_host(idx, n)
+            n_edges, sweeps, needed, _ = self._edges_from_thresholds(False)
+        elif not on_device and self.stats["hist_passes"] == 1:
+            self._thresh_on_host = False  # every rank sat in a fine bin: the device path serves the next call
+        self.stats["hysteresis_sweeps"] = sweeps
+        self._hyst_hint = needed
+        if self.keep_debug_maps:
+            self.edges = torch.empty((P, h, w), dtype=torch.uint8, device=self.dev)
+            _call("mg_unpack_bits", self.edge_bits.data_ptr(), self.words, P, h * w, self.edges.data_ptr(), s)
+        self.coord_cap = max(1, int(n_edges.max()))
+        if self.coords is None or self.coords.shape[1] < self.coord_cap:
+            self.coords = torch.empty((P, int(self.coord_cap * 1.25) + 1, 2), dtype=torch.int32, device=self.dev)
+        self.coord_cap = self.coords.shape[1]
+        _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, P, h, w, self.grid, self.cell_counts.data_ptr(),
+              self.cell_starts.data_ptr(), self.num_edges.data_ptr(), self.coords.data_ptr(), self.coord_cap, s)
+        if self.need_angle_map():
+            if self.angle is None:
+                self.angle = torch.empty((P, h, w), dtype=torch.float32, device=self.dev)
+            _call("mg_edge_angles", self.blur.data_ptr(), P, h, w, self.coords.data_ptr(), self.coord_cap,
+                  self.num_edges.data_ptr(), self.angle.data_ptr(), s)
+        self.n_edges_host = n_edges
+        return n_edges
+
+    def _thresholds_on_host(self, idx, n):
+        """The rank search with window passes for ranks in coarse bins (strong gradients), np.quantile's
+        interpolation and cv::Canny's threshold preparation; sets self.thresh."""
+        L, P, h, w, s = nat.lib(), self.P, self.h, self.w, _stream()
         ranks = sorted({i for a, b, _ in idx for i in (a, b)})
         # bin of every needed rank, per plane (searched on the device: only P x 4 integers come back);
         # fine bins give the order statistic directly
@@ -402,16 +447,22 @@ class CircleFinder:
             diff = (gb - ga).astype(np.float32)
             vals.append((gb - diff * np.float32(1 - gamma)).astype(np.float32) if gamma >= 0.5
                         else (ga + diff * gamma).astype(np.float32))
-        self.quantiles = np.stack(vals, axis=1).astype(np.float32)
+        self._quantiles = np.stack(vals, axis=1).astype(np.float32)
         lo = np.minimum(vals[0], vals[1]).astype(np.float64)
         hi = np.maximum(vals[0], vals[1]).astype(np.float64)
         lo, hi = np.minimum(lo, 32767.0), np.minimum(hi, 32767.0)
         lo, hi = np.where(lo > 0, lo * lo, lo), np.where(hi > 0, hi * hi, hi)
         thresh = np.stack([np.floor(lo), np.floor(hi)], axis=1).astype(np.int32)
         self.thresh.copy_(torch.from_numpy(thresh))
+
+
+    def _edges_from_thresholds(self, fetch_unresolved):
+        """Canny NMS + hysteresis to convergence + the cell counts of the edge grid, from self.thresh.
+        Returns (n_edges per plane, sweeps run, sweeps needed, any plane whose device thresholds were unresolved)."""
+        L, P, h, w, s = nat.lib(), self.P, self.h, self.w, _stream()
         _call("mg_canny_nms", self.blur.data_ptr(), P, h, w, self.thresh.data_ptr(), self.weak_bits.data_ptr(),
               self.edge_bits.data_ptr(), _ptr(self.class_bits), self.words, s)
-        sweeps = 0
+        sweeps, unresolved, needed = 0, False, 0
         # sweeps per host check: first as many as the previous call needed (a sweep after convergence only
         # runs the tile-flag test), then two at a time -- one host round trip in the steady state
         group = max(2, min(int(self._hyst_hint), 64))
@@ -430,31 +481,28 @@ class CircleFinder:
             # (they are recomputed in the rare case that more sweeps are needed)
             _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, P, h, w, self.grid, self.cell_counts.data_ptr(),
                   self.cell_starts.data_ptr(), self.num_edges.data_ptr(), 0, 0, s)
-            both = torch.cat([self.changed[:group].sum(dim=1), self.num_edges.to(torch.int64)]).cpu().numpy()
-            per_sweep, n_edges = both[:group], both[group:].astype(np.int32)
+            parts = [self.changed[:group].sum(dim=1), self.num_edges.to(torch.int64)]
+            if fetch_unresolved:
+                parts.append(self.unresolved.sum(dtype=torch.int64).reshape(1))
+            both = torch.cat(parts).cpu().numpy()
+            per_sweep, n_edges = both[:group], both[group: group + P].astype(np.int32)
+            unresolved = bool(fetch_unresolved and both[-1] > 0)
+            if unresolved:  # these edges come from invalid thresholds: the caller redoes them
+                needed = sweeps
+                break
             if per_sweep[group - 1] == 0:
                 # sweeps this image needed = up to and including the first one that changed nothing
                 needed = sweeps - group + int(np.argmax(per_sweep == 0)) + 1
                 break
             group = 2
-        self.stats["hysteresis_sweeps"] = sweeps
-        self._hyst_hint = needed
-        if self.keep_debug_maps:
-            self.edges = torch.empty((P, h, w), dtype=torch.uint8, device=self.dev)
-            _call("mg_unpack_bits", self.edge_bits.data_ptr(), self.words, P, h * w, self.edges.data_ptr(), s)
-        self.coord_cap = max(1, int(n_edges.max()))
-        if self.coords is None or self.coords.shape[1] < self.coord_cap:
-            self.coords = torch.empty((P, int(self.coord_cap * 1.25) + 1, 2), dtype=torch.int32, device=self.dev)
-        self.coord_cap = self.coords.shape[1]
-        _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, P, h, w, self.grid, self.cell_counts.data_ptr(),
-              self.cell_starts.data_ptr(), self.num_edges.data_ptr(), self.coords.data_ptr(), self.coord_cap, s)
-        if self.need_angle_map():
-            if self.angle is None:
-                self.angle = torch.empty((P, h, w), dtype=torch.float32, device=self.dev)
-            _call("mg_edge_angles", self.blur.data_ptr(), P, h, w, self.coords.data_ptr(), self.coord_cap,
-                  self.num_edges.data_ptr(), self.angle.data_ptr(), s)
-        self.n_edges_host = n_edges
-        return n_edges
+        return n_edges, sweeps, needed, unresolved
+
+    @property
+    def quantiles(self):
+        """The two edge quantiles of every plane (float32, what np.quantile returns): (P, 2) on the host."""
+        if self._quantiles is None:
+            self._quantiles = self.quant_d.cpu().numpy()
+        return self._quantiles
 
     def need_angle_map(self):
         """The dense angle map (mg_edge_angles) is only written for the scoring path that reads it or for the
