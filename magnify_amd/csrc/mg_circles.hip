@@ -267,40 +267,32 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
     }
   }
   __syncthreads();
-  // Ordered emission straight from LDS: count every (tile, layer), reserve the group's slice of the
-  // plane's unique-key list with one atomicAdd (d_num_circles is the cursor), then every wave walks
-  // its layers -- lane = tile row, prefix by DPP scan -- and stores the keys in (tile, r, row, col)
-  // order.  Slices of different groups land in arrival order; everything downstream that needs the
-  // canonical order compares the keys themselves, never list positions.
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // Ordered emission straight from LDS.  The bit index inside a tile IS the low 17 bits of the key
+  // ((r << 12) | (row << 6) | col), so walking the tile's words in order yields its keys in ascending order.
+  // Every thread owns a run of consecutive words: count its bits, one block-wide exclusive scan of the counts
+  // (its entries at the layer boundaries are the per-(tile, radius) starts), reserve the group's slice of the
+  // plane's list with one atomicAdd (d_num_circles is the cursor), then every thread stores the keys of its run.
+  // (A wave per sparse layer -- ~40 keys in 4096 bits -- spent most of its instructions on empty rows.)
+  // Slices of different groups land in arrival order; everything downstream that needs the canonical order
+  // compares the keys themselves, never list positions.
   const int n_li = ntx * nr;
-  // one pass over the wave's layers (li = wave, wave + 4, ...): the rows stay in registers together with
-  // their inclusive lane prefix, whose last lane is the layer's count
-  constexpr int LPW = TX * 32 / (NT / 64);  // layers per wave at most (nr <= 32)
-  uint2 rows[LPW];
-  int incl[LPW];
-#pragma unroll
-  for (int u = 0; u < LPW; ++u) {
-    const int li = wave + u * (NT / 64);
-    rows[u] = make_uint2(0u, 0u);
-    incl[u] = 0;
-    if (li < n_li) {  // wave-uniform
-      rows[u] = reinterpret_cast<const uint2*>(lbits + li * LAYER_WORDS)[lane];
-      incl[u] = mg_wave_scan_incl_i32(__popc(rows[u].x) + __popc(rows[u].y));
-      const int total = __builtin_amdgcn_readlane(incl[u], 63);
-      if (lane == 0) s_cnt[li] = total;
+  const int n_words = n_li * LAYER_WORDS;
+  const int per = (n_words + NT - 1) / NT;
+  const int w0 = min((int)threadIdx.x * per, n_words), w1 = min(w0 + per, n_words);
+  int mine = 0;
+  for (int wd = w0; wd < w1; ++wd) mine += __popc(lbits[wd]);
+  int n_unique;
+  const int ex = mg_block_exscan(mine, &n_unique);
+  {
+    int run = ex;  // exclusive prefix at the thread's first word
+    for (int wd = w0; wd < w1; ++wd) {
+      if ((wd & (LAYER_WORDS - 1)) == 0) s_cnt[wd / LAYER_WORDS] = run;  // first word of a layer
+      run += __popc(lbits[wd]);
     }
   }
-  __syncthreads();
-  if (wave == 0) {  // exclusive prefix of the n_li <= 64 layer counts by one wave scan
-    const int c = lane < n_li ? s_cnt[lane] : 0;
-    const int inc = mg_wave_scan_incl_i32(c);
-    const int run = __builtin_amdgcn_readlane(inc, 63);
-    if (lane < n_li) s_cnt[lane] = inc - c;
-    if (lane == 0) {
-      s_cnt[n_li] = run;
-      s_base = run ? atomicAdd(&d_num_circles[plane], run) : 0;
-    }
+  if (threadIdx.x == 0) {
+    s_cnt[n_li] = n_unique;
+    s_base = n_unique ? atomicAdd(&d_num_circles[plane], n_unique) : 0;
   }
   __syncthreads();
   const int64_t base = s_base;
@@ -317,16 +309,14 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
     }
   }
   uint32_t* out = d_ukeys + (int64_t)plane * circle_cap;
-#pragma unroll
-  for (int u = 0; u < LPW; ++u) {
-    const int li = wave + u * (NT / 64);
-    uint64_t bits = ((uint64_t)rows[u].y << 32) | rows[u].x;
-    if (li >= n_li || !bits) continue;
-    int64_t pos = base + s_cnt[li] + incl[u] - (__popc(rows[u].x) + __popc(rows[u].y));
-    const int t = li / nr, ri = li - t * nr;
-    const uint32_t hi = ((uint32_t)(tile0 + t) << 17) | ((uint32_t)ri << 12) | ((uint32_t)lane << 6);
+  int64_t pos = base + ex;
+  for (int wd = w0; wd < w1; ++wd) {
+    uint32_t bits = lbits[wd];
+    if (!bits) continue;
+    const int t = wd / words;  // tile of the group; (wd - t * words) * 32 + bit = the key's low 17 bits
+    const uint32_t hi = ((uint32_t)(tile0 + t) << 17) | ((uint32_t)(wd - t * words) << 5);
     while (bits) {
-      const int b = __ffsll((unsigned long long)bits) - 1;
+      const int b = __ffs(bits) - 1;
       bits &= bits - 1;
       if (pos < circle_cap) out[pos] = hi | (uint32_t)b;
       ++pos;
