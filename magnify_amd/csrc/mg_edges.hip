@@ -517,6 +517,14 @@ __device__ __forceinline__ uint32_t row_word(const uint32_t* __restrict__ bits, 
   return bits_at(bits, (int64_t)y * w + lo, hi - lo) << (lo - x0);
 }
 
+// v = 2 v + (this lane's bit of a wave mask): the mask is the carry-in of one add-with-carry.
+__device__ __forceinline__ uint32_t shl1_or(uint32_t v, uint64_t mask) {
+  uint32_t out;
+  uint64_t carry_out;
+  asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(out), "=s"(carry_out) : "v"(v), "s"(mask));
+  return out;
+}
+
 // OR over each aligned group of 8 lanes, on the VALU's data-parallel-primitive paths (no LDS
 // crossbar trip): xor 1 and xor 2 inside the quads, then lane i <-> 7 - i swaps the two quads.
 __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
@@ -552,71 +560,106 @@ __global__ __launch_bounds__(NT) void k_canny_nms(const uint8_t* __restrict__ d_
   uint32_t* cls2 = d_class ? d_class + (3 * plane + 2) * words_per_plane : nullptr;
   constexpr int TG22 = 13573;
   const uint32_t in_row = gx + 4 <= w ? 0xFu : ((1u << max(w - gx, 0)) - 1u);  // the lane's pixels left of the row end
+  // Packed 16-bit arithmetic, two pixels per instruction: a row is held as four registers of pixel pairs
+  // (columns c0-2 .. c0+5); the Scharr sums S = 3 (above + below) + 10 centre <= 4080 and differences fit 16 bits;
+  // |gradient|^2 = dot2((dx, dy), (dx, dy)) in one instruction per pixel.
+  typedef short s2 __attribute__((ext_vector_type(2)));
+  typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+  struct Pairs4 {
+    u2 p[4];
+  };
+  auto unpack = [](const Row12& r) {
+    Pairs4 o;
+    o.p[0] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(0u, r.d0, 0x0C030C02u));  // pixels c0-2, c0-1
+    o.p[1] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(0u, r.d1, 0x0C010C00u));  // c0, c0+1
+    o.p[2] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(0u, r.d1, 0x0C030C02u));  // c0+2, c0+3
+    o.p[3] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(0u, r.d2, 0x0C010C00u));  // c0+4, c0+5
+    return o;
+  };
   // mag rows: 6 magnitudes (cols c0-1 .. c0+4) of image rows y-1, y, y+1; zero outside the image
   int mg[3][6];
-  int cdx[2][4], cdy[2][4];  // gradients of the lane's 4 pixels for the two newest mag rows
-  Row12 ra = read_row(tile, wave * RPW, c0), rb = read_row(tile, wave * RPW + 1, c0);
+  uint32_t cxy[2][4];  // (dx | dy << 16) of the lane's 4 pixels for the two newest mag rows
+  Pairs4 ua = unpack(read_row(tile, wave * RPW, c0)), ub = unpack(read_row(tile, wave * RPW + 1, c0));
 #pragma unroll
   for (int jr = 2; jr < RPW + 4; ++jr) {
-    const Row12 rc = read_row(tile, wave * RPW + jr, c0);
+    const Pairs4 uc = unpack(read_row(tile, wave * RPW + jr, c0));
     // magnitudes of image row ym (centre row of tile rows jr-2, jr-1, jr)
     const int ym = ty0 - 2 + wave * RPW + jr - 1;
 #pragma unroll
     for (int k = 0; k < 6; ++k) mg[0][k] = mg[1][k], mg[1][k] = mg[2][k];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cdx[0][q] = cdx[1][q], cdy[0][q] = cdy[1][q];
+    for (int q = 0; q < 4; ++q) cxy[0][q] = cxy[1][q];
     {
-      int ddx[6], ddy[6];  // pixels c0 - 1 .. c0 + 4
-      scharr_n<-1, 6>(ra, rb, rc, ddx, ddy);
+      s2 S[4], D[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        S[k] = __builtin_bit_cast(s2, (u2)((ua.p[k] + uc.p[k]) * (unsigned short)3 + ub.p[k] * (unsigned short)10));
+        D[k] = __builtin_bit_cast(s2, uc.p[k]) - __builtin_bit_cast(s2, ua.p[k]);
+      }
+      uint32_t xy[6];  // columns c0-1 .. c0+4
+#pragma unroll
+      for (int jp = 0; jp < 3; ++jp) {
+        // pair jp = columns (c0-1+2jp, c0+2jp): dx[x] = S[x+1] - S[x-1], dy[x] = 3 (D[x-1] + D[x+1]) + 10 D[x]
+        const s2 dxp = S[jp + 1] - S[jp];
+        const s2 mid = __builtin_bit_cast(s2, __builtin_amdgcn_alignbit(__builtin_bit_cast(uint32_t, D[jp + 1]),
+                                                                         __builtin_bit_cast(uint32_t, D[jp]), 16));
+        const s2 dyp = (D[jp] + D[jp + 1]) * (short)3 + mid * (short)10;
+        xy[2 * jp] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, dyp), __builtin_bit_cast(uint32_t, dxp), 0x05040100u);
+        xy[2 * jp + 1] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, dyp), __builtin_bit_cast(uint32_t, dxp), 0x07060302u);
+      }
+      const bool row_in = ym >= 0 && ym < h;
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         const int x = gx + k - 1;
-        mg[2][k] = (ym >= 0 && ym < h && x >= 0 && x < w) ? ddx[k] * ddx[k] + ddy[k] * ddy[k] : 0;
-        if (k >= 1 && k <= 4) {
-          cdx[1][k - 1] = ddx[k];
-          cdy[1][k - 1] = ddy[k];
-        }
+        const int m = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, xy[k]), __builtin_bit_cast(s2, xy[k]), 0, false);
+        mg[2][k] = (row_in && x >= 0 && x < w) ? m : 0;
+        if (k >= 1 && k <= 4) cxy[1][k - 1] = xy[k];
       }
     }
-    ra = rb;
-    rb = rc;
+    ua = ub;
+    ub = uc;
     if (jr < 4) continue;
     // NMS of image row yo = ym - 1 (mag rows 0, 1, 2 = yo - 1, yo, yo + 1; gradients in cd*[0])
     const int yo = ym - 1;
     uint32_t wb = 0, sb = 0, cb0 = 0, cb1 = 0, cb2 = 0;
     if (yo < h) {
+      // Every decision is a per-lane boolean = a wave mask in scalar registers: the compares write the masks,
+      // the logic runs on the scalar unit, and a plane's bit enters its accumulator as the carry-in of ONE
+      // v_addc (v = 2 v + bit).  No value selects: all four direction tests are evaluated and the gradient
+      // direction picks the result.  (The select-chain version spent two thirds of its instructions on
+      // v_cndmask / shift / or.)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        // Branch-free, and no run-time index into the register arrays (the compiler turns such an
-        // index into a compare/select chain over the whole array: that was half of this kernel).
+      for (int q = 3; q >= 0; --q) {
         const int m = mg[1][q + 1];
-        const int xs = cdx[0][q], ys = cdy[0][q];
-        const int x = abs(xs), y = abs(ys) << 15;
+        const int xs = (int)(int16_t)(cxy[0][q] & 0xFFFFu), ys = (int)cxy[0][q] >> 16;
+        const int x = abs(xs), ay = abs(ys), y = ay << 15;
         const int tg22x = x * TG22;
         const int tg67x = tg22x + (x << 16);
-        const bool horiz = y < tg22x;
-        const bool vert = !horiz && y > tg67x;
-        const bool neg = (xs ^ ys) < 0;  // diagonal: s = -1 where the signs differ
-        // previous / next neighbour along the gradient direction
-        const int pd = neg ? mg[0][q + 2] : mg[0][q], nd = neg ? mg[2][q] : mg[2][q + 2];
-        const int pv = horiz ? mg[1][q] : (vert ? mg[0][q + 1] : pd);
-        const int nx = horiz ? mg[1][q + 2] : (vert ? mg[2][q + 1] : nd);
+        const uint64_t horiz = __ballot(y < tg22x);
+        const uint64_t vert = __ballot(y > tg67x) & ~horiz;
+        const bool neg_b = (xs ^ ys) < 0;  // diagonal: s = -1 where the signs differ
+        const uint64_t neg = __ballot(neg_b);
         // > towards the previous pixel; >= towards the next one on the axes, > on the diagonals
-        const bool is_max = m > pv && (m + ((horiz || vert) ? 1 : 0)) > nx;
-        const bool cand = is_max && m > low && gx + q < w;
-        wb |= (cand ? 1u : 0u) << q;
-        sb |= ((cand && m > high) ? 1u : 0u) << q;
+        const uint64_t ok_h = __ballot(m > mg[1][q]) & __ballot(m >= mg[1][q + 2]);
+        const uint64_t ok_v = __ballot(m > mg[0][q + 1]) & __ballot(m >= mg[2][q + 1]);
+        const uint64_t ok_d = __ballot(m > mg[0][q]) & __ballot(m > mg[2][q + 2]);      // signs equal
+        const uint64_t ok_n = __ballot(m > mg[0][q + 2]) & __ballot(m > mg[2][q]);      // signs differ
+        const uint64_t is_max = (horiz & ok_h) | (vert & ok_v) | (~(horiz | vert) & ((neg & ok_n) | (~neg & ok_d)));
+        const uint64_t cand = is_max & __ballot(m > low) & __ballot(gx + q < w);
+        wb = shl1_or(wb, cand);
+        sb = shl1_or(sb, cand & __ballot(m > high));
         // class 0: [0, pi/4), 1: [pi/4, pi/2), 2: [pi/2, 3pi/4), 3: [3pi/4, pi)
-        const int ay = abs(ys);
-        cb0 |= ((neg ? ay <= x : ay >= x) ? 1u : 0u) << q;
-        cb1 |= (neg ? 1u : 0u) << q;
+        const bool le_b = ay <= x, ge_b = ay >= x;
+        const uint64_t le = __ballot(le_b), ge = __ballot(ge_b);
+        cb0 = shl1_or(cb0, (neg & le) | (~neg & ge));
+        cb1 = shl1_or(cb1, neg);
         // halves of a quarter: psi = atan(|dy| / |dx|) against pi/8 (psi < pi/4: tan = sqrt(2) - 1, i.e.
         // (|dx| + |dy|)^2 > 2 dx^2) or 3 pi/8 (tan = sqrt(2) + 1, i.e. (|dy| - |dx|)^2 > 2 dx^2); phi = psi or
         // pi - psi (signs differ), which mirrors the halves.  Irrational tangents: never an equality.
-        const bool lowq = neg ? ay <= x : ay < x;
+        const bool lowq = neg_b ? le_b : !ge_b;
         const int sq = lowq ? x + ay : ay - x;
-        const bool upper = sq * sq > 2 * x * x;
-        cb2 |= ((neg != upper) ? 1u : 0u) << q;
+        const uint64_t upper = __ballot(sq * sq > 2 * x * x);
+        cb2 = shl1_or(cb2, neg ^ upper);
       }
     }
     // 8 lanes x 4 bits -> one 32-bit word
