@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MG_LIB") or os.path.join(_HERE, "_lib", "libmagnify_hip.so")
+LIB_PATH = os.path.join(_HERE, "_lib", "libmagnify_hip.so")
 
 MG_U8, MG_U16, MG_F32, MG_F64 = 0, 1, 2, 3
 MG_NO_EDGE = 100.0

@@ -95,11 +95,7 @@ __device__ __forceinline__ int score_r(const uint8_t* lds, int vaddr, const uint
   int sum = 0;
 #pragma unroll
   for (int k = 0; k < P.n; ++k) {
-#ifdef MG_DBG_CONST_TAB
-    const uint2 t = make_uint2(0x40302010u + k, 0x10203040u);
-#else
     const uint2 t = tabs[R * MAXP + k];  // uniform address: scalar loads
-#endif
     const int off = P.dr[k] * WSTR + P.dc[k];
     us2 s;
     s.x = lds[vaddr + (BIAS + off)];
@@ -159,7 +155,7 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
     // WI) 32-pixel groups are issued before the first is used: the block would otherwise wait for two to four
     // global round trips per group, one after the other ----
     const int wy0 = sr * STY - 2 * max_r, wx0 = sc * STX - 2 * max_r;
-    if (!(write_skipped & 4)) {
+    {
       const uint32_t* pl[4] = {d_bits + plane * words_per_plane, d_class + (3 * plane) * words_per_plane,
                                d_class + (3 * plane + 1) * words_per_plane, d_class + (3 * plane + 2) * words_per_plane};
       constexpr int WI = ((STY + 2 * MAXR) * ((WSTR + 31) / 32) + NP - 1) / NP;
@@ -260,8 +256,7 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
       const int wrow = (s / SUBX) * TS + (int)((key >> 6) & 63u) + max_r, wcol = (s % SUBX) * TS + (int)(key & 63u) + max_r;
       const int vaddr = WBASE + wrow * WSTR + wcol - BIAS;
       int sum = 0;
-      if (!(write_skipped & 2))
-        switch (rho + min_r) {
+      switch (rho + min_r) {
 #define MG_CASE(R) case R: sum = score_r<R>(lds, vaddr, d_tabs); break;
           MG_CASE(2) MG_CASE(3) MG_CASE(4) MG_CASE(5) MG_CASE(6) MG_CASE(7) MG_CASE(8) MG_CASE(9) MG_CASE(10)
           MG_CASE(11) MG_CASE(12) MG_CASE(13) MG_CASE(14) MG_CASE(15) MG_CASE(16) MG_CASE(17) MG_CASE(18)
@@ -270,7 +265,7 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
           default: break;
         }
       const bool pass = valid && sum >= need[rho];
-      if ((write_skipped & 1) && valid && !pass) d_scores[(int64_t)plane * circle_cap + i] = MG_SCORE_SKIPPED;
+      if (write_skipped && valid && !pass) d_scores[(int64_t)plane * circle_cap + i] = MG_SCORE_SKIPPED;
       const uint64_t pm = __ballot(pass);
       if (pm) {  // rare: append the survivors to the plane's list
         int sbase = 0;
@@ -441,7 +436,7 @@ __global__ __launch_bounds__(NT) void k_exact(const uint8_t* __restrict__ d_blur
     // 5. results
     if (t < XS && active) {
       if (dead) {
-        if (write_skipped & 1) scores[ci] = MG_SCORE_SKIPPED;
+        if (write_skipped) scores[ci] = MG_SCORE_SKIPPED;
       } else {
         const float score = (float)acc / (float)(s_p1[t] - s_p0[t]);
         scores[ci] = score;
@@ -508,8 +503,7 @@ extern "C" int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angl
   MG_CHECK_LAUNCH();
   // blocks per plane: enough to fill the chip at any batch size, few enough to amortise the table load
   const int xblocks = std::max(16, std::min(256, 4096 / std::max(n_planes, 1)));
-  if (!(write_skipped & 8))
-    hipLaunchKernelGGL(k_exact, dim3(xblocks, n_planes), dim3(NT), (size_t)per_total * 4, s, d_blur, d_angle, d_edge_bits,
+  hipLaunchKernelGGL(k_exact, dim3(xblocks, n_planes), dim3(NT), (size_t)per_total * 4, s, d_blur, d_angle, d_edge_bits,
                        words_per_plane, h, w, d_circles, circle_cap, ntc, min_r, max_r, d_per_rc, per_total,
                        d_per_expected, d_per_starts, min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc,
                        d_num_scored, d_surv_list, surv_cap, d_num_surv);

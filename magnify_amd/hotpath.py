@@ -545,7 +545,7 @@ class CircleFinder:
                   self.words, P, h, w, self.circles.data_ptr(), self.cap, self.unique_keys.data_ptr(),
                   self.layer_starts.data_ptr(), self.min_r, self.max_r, self.per_rc.data_ptr(), self.per_exp.data_ptr(),
                   self.per_starts.data_ptr(), int(self.per_rc.shape[0]), self.pair_table.data_ptr(), float(min_roundness),
-                  int(self.keep_debug_maps) | int(os.environ.get("MG_SCORE_DEBUG", "0")), self.scores.data_ptr(), self.alive.data_ptr(), self.num_alive.data_ptr(),
+                  int(self.keep_debug_maps), self.scores.data_ptr(), self.alive.data_ptr(), self.num_alive.data_ptr(),
                   self.max_rc.data_ptr(), self.num_scored.data_ptr(), self.surv_list.data_ptr(), self.cap,
                   self.num_surv.data_ptr(), s, stage="mg_score_circles")
             return
