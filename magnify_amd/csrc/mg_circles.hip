@@ -243,27 +243,26 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
     for (int r = 0; r < n_ranges; ++r) s_pre[r + 1] += s_pre[r];
   }
   __syncthreads();
-  const int total = n_ranges ? s_pre[n_ranges] : 0;
   const uint32_t* keys = d_keys + (int64_t)plane * num_iter;
-  // 8 key loads in flight per thread (a thread's indices only grow, so the range search resumes)
+  // Range by range (a handful per workgroup), 8 key loads in flight per thread: inside a range the index
+  // arithmetic is 32-bit and loop-invariant (no per-key search for the range a key index belongs to).
   constexpr int KB = 8;
-  int r = 0;
-  for (int base = 0; base < total; base += NT * KB) {
-    uint32_t kv[KB];
+  for (int r = 0; r < n_ranges; ++r) {
+    const uint32_t* kr = keys + s_lo[r];
+    const int len = s_pre[r + 1] - s_pre[r];
+    for (int base = threadIdx.x; base < len; base += NT * KB) {
+      uint32_t kv[KB];
 #pragma unroll
-    for (int u = 0; u < KB; ++u) {
-      const int i = base + u * NT + (int)threadIdx.x;
-      kv[u] = MG_NO_KEY;
-      if (i < total) {
-        while (i >= s_pre[r + 1]) ++r;
-        kv[u] = keys[s_lo[r] + (i - s_pre[r])];
+      for (int u = 0; u < KB; ++u) {
+        const int i = base + u * NT;
+        kv[u] = i < len ? kr[i] : MG_NO_KEY;
       }
-    }
 #pragma unroll
-    for (int u = 0; u < KB; ++u) {
-      const uint32_t key = kv[u];
-      const uint32_t t = (key >> 17) - (uint32_t)tile0;  // wraps for foreign (and rejected) keys
-      if (t < (uint32_t)ntx) atomicOr(&lbits[t * words + ((key & 0x1FFFFu) >> 5)], 1u << (key & 31u));
+      for (int u = 0; u < KB; ++u) {
+        const uint32_t key = kv[u];
+        const uint32_t t = (key >> 17) - (uint32_t)tile0;  // wraps for foreign (and rejected) keys
+        if (t < (uint32_t)ntx) atomicOr(&lbits[t * words + ((key & 0x1FFFFu) >> 5)], 1u << (key & 31u));
+      }
     }
   }
   __syncthreads();
