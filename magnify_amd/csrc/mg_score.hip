@@ -28,7 +28,7 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int NP = 512;  // prefilter block: 8 waves share a window (4 blocks per CU by LDS: 32 waves per CU)
+constexpr int NP = 768;  // prefilter block: 8 waves share a window (4 blocks per CU by LDS: 32 waves per CU)
 constexpr int TS = MG_SCORE_TILE;
 constexpr int SUBY = MG_SCORE_SUBY, SUBX = MG_SCORE_SUBX, NSUB = SUBY * SUBX;  // centre tiles per super-tile
 constexpr int STY = SUBY * TS, STX = SUBX * TS;
