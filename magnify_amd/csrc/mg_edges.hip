@@ -287,12 +287,39 @@ constexpr int HIST_TILES = 3;
 
 __device__ __forceinline__ void hist_add4(const Row12& ra, const Row12& rb, const Row12& rc, int gx, int w, int mode,
                                           uint32_t base, int n_bins, uint32_t* hist, uint32_t& zeros) {
-  int dx[4], dy[4];
-  scharr_n<0, 4>(ra, rb, rc, dx, dy);
+  // packed 16-bit arithmetic, two pixels per instruction (columns c0-1 .. c0+4 as three pairs); |gradient|^2 by
+  // one dot2 per pixel (see k_canny_nms)
+  typedef short s2 __attribute__((ext_vector_type(2)));
+  typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+  u2 pa[3], pb2[3], pc[3];
+#define MG_UNPACK3(r, o)                                                                    \
+  o[0] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(r.d1, r.d0, 0x0C040C03u)); /* c0-1, c0 */ \
+  o[1] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(0u, r.d1, 0x0C020C01u));   /* c0+1, c0+2 */ \
+  o[2] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(r.d2, r.d1, 0x0C040C03u)); /* c0+3, c0+4 */
+  MG_UNPACK3(ra, pa)
+  MG_UNPACK3(rb, pb2)
+  MG_UNPACK3(rc, pc)
+#undef MG_UNPACK3
+  s2 S[3], D[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    S[k] = __builtin_bit_cast(s2, (u2)((pa[k] + pc[k]) * (unsigned short)3 + pb2[k] * (unsigned short)10));
+    D[k] = __builtin_bit_cast(s2, pc[k]) - __builtin_bit_cast(s2, pa[k]);
+  }
+  uint32_t xy[4];  // (dx | dy << 16) of pixels c0 .. c0+3
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    const s2 dxp = S[jp + 1] - S[jp];
+    const s2 mid = __builtin_bit_cast(s2, __builtin_amdgcn_alignbit(__builtin_bit_cast(uint32_t, D[jp + 1]),
+                                                                     __builtin_bit_cast(uint32_t, D[jp]), 16));
+    const s2 dyp = (D[jp] + D[jp + 1]) * (short)3 + mid * (short)10;
+    xy[2 * jp] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, dyp), __builtin_bit_cast(uint32_t, dxp), 0x05040100u);
+    xy[2 * jp + 1] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, dyp), __builtin_bit_cast(uint32_t, dxp), 0x07060302u);
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (gx + q >= w) continue;
-    const uint32_t m = (uint32_t)(dx[q] * dx[q] + dy[q] * dy[q]);
+    const uint32_t m = (uint32_t)__builtin_amdgcn_sdot2(__builtin_bit_cast(s2, xy[q]), __builtin_bit_cast(s2, xy[q]), 0, false);
     if (mode == 0) {
       if (m == 0) ++zeros;
       else {
