@@ -318,6 +318,14 @@ int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const float* d_sc
                  const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
                  int32_t* d_undecided, const uint32_t* d_tie_keys, int64_t max_alive, void* stream);
 
+/* Before the rounds (optional, exact): of the alive circles that share a centre only the first in suppression
+ * order (score desc, tie key asc) stays undecided, the others are marked rejected -- they have the same ring and
+ * are rejected whatever happens to the first (utils.py:254-292).  One bid on the centre's own claim-grid cell,
+ * which is restored before returning; d_state as for mg_nms_round. */
+int mg_nms_same_centre(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
+                       const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist, uint64_t* d_grid,
+                       int64_t grid_cap, uint8_t* d_state, const uint32_t* d_tie_keys, int64_t max_alive, void* stream);
+
 /* After the rounds have converged: restore the all-ones claim grid under the rings of all alive
  * circles, so that the grid needs its full initialisation only once. */
 int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,

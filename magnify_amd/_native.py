@@ -56,6 +56,7 @@ PROTOTYPES = {
     "mg_score_circles_keyed": [_p, _p, _p, _p, _l, _i, _i, _i, _p, _l, _p, _p, _i, _i, _p, _p, _p, _i, _p, _f, _i,
                                _p, _p, _p, _p, _p, _p, _l, _p, _p],
     "mg_nms_round": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _p, _l, _p],
+    "mg_nms_same_centre": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _l, _p, _p, _l, _p],
     "mg_collect_circles": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p],
     "mg_circle_labels": [_p, _l, _p, _i, _i, _i, _p, _i, _p, _i, _p],
     "mg_nms_cleanup": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _l, _p],

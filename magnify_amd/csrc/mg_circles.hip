@@ -735,11 +735,21 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
   uint64_t* grid = d_grid + (int64_t)plane * grid_cap;
   for (int64_t a = (int64_t)blockIdx.x * NT + threadIdx.x; a < n; a += (int64_t)gridDim.x * NT) {
     const int idx = alive[a];
-    if (PHASE != 2 && state[idx] != 0) continue;
+    if (PHASE != 2 && PHASE != 5 && state[idx] != 0) continue;
     const int row = circles[3 * (int64_t)idx], col = circles[3 * (int64_t)idx + 1];
     const uint32_t tk = tie ? tie[idx] : (uint32_t)idx;
     const uint64_t key = nms_key(scores[idx], tk);
-    if (PHASE == 2) {  // cleanup (after convergence): restore the all-ones grid under every ring
+    if (PHASE >= 3) {
+      // Same-centre reduction before the rounds: circles with one centre have one ring, so whatever the first of
+      // them in suppression order does -- claim the ring, or fail on a cell that is already claimed -- leaves every
+      // later one rejected without ever claiming (utils.py:254-292): only that first one enters the rounds.  One
+      // bid on the centre's own cell (3), the losers marked rejected (4), the cell restored (5): three tiny
+      // launches instead of a ring of bids, loads and withdrawals per duplicate.
+      uint64_t* cell = &grid[(int64_t)wrap(row + pad, n_rows) * n_cols + wrap(col + pad, n_cols)];
+      if (PHASE == 3) atomicMin(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)key);
+      else if (PHASE == 4) { if (*cell != key) state[idx] = 2; }
+      else *cell = ~0ull;
+    } else if (PHASE == 2) {  // cleanup (after convergence): restore the all-ones grid under every ring
       for (int j = 0; j < ring_len; ++j) {
         const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
         grid[(int64_t)rr * n_cols + cc] = ~0ull;
@@ -1058,6 +1068,27 @@ extern "C" int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const 
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_nms<1>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
                      min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided, d_tie_keys);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_nms_same_centre(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
+                                  const int32_t* d_alive, const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes,
+                                  int min_dist, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
+                                  const uint32_t* d_tie_keys, int64_t max_alive, void* stream) {
+  if (!d_circles || !d_scores || !d_alive || !d_num_alive || !d_max_rc || !d_grid || !d_state) return MG_EINVAL;
+  if (n_planes < 0 || n_planes > 65535 || min_dist <= 0) return MG_EINVAL;
+  if (n_planes == 0 || circle_cap == 0) return MG_OK;
+  hipStream_t s = mg_stream(stream);
+  const dim3 g(grid_x(max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap), n_planes);
+  hipLaunchKernelGGL((k_nms<3>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
+                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys);
+  MG_CHECK_LAUNCH();
+  hipLaunchKernelGGL((k_nms<4>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
+                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys);
+  MG_CHECK_LAUNCH();
+  hipLaunchKernelGGL((k_nms<5>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
+                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

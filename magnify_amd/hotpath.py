@@ -591,6 +591,10 @@ class CircleFinder:
             # rounds per host check: as many as the previous call needed (a round with nothing undecided
             # does no work), then two at a time.  The ordered output is gathered before the check and rides
             # on the same round trip (it is gathered again in the rare case that more rounds are needed).
+            # same-centre circles: only the first of each centre enters the rounds (exact; three tiny launches)
+            _call("mg_nms_same_centre", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
+                  self.num_alive.data_ptr(), self.max_rc.data_ptr(), P, min_dist, self.nms_grid.data_ptr(),
+                  self.nms_grid.shape[1], self.state.data_ptr(), _ptr(self._tie_keys), out_cap, s, stage="mg_nms_round")
             group = max(2, min(int(self._nms_hint), 64))
             if self.undecided.dim() != 2 or self.undecided.shape[0] < group:
                 self.undecided = torch.zeros((group, P), dtype=torch.int32, device=self.dev)
