@@ -80,6 +80,11 @@ int mg_flatfield_max(const void* d_tiles, int dtype, int64_t n_tiles, int n_grou
                      double flat, const void* d_flat, int flat_dtype,
                      double* d_max2, void* stream);
 
+/* 1 when the correction is the identity for this pixel type: integer pixels, scalar dark 0 and scalar flat 1 (the
+ * defaults of the reference's flatfield_correct, preprocess.py:62).  mg_flatfield_apply_stitch then only crops and
+ * copies, and pass 1 (mg_flatfield_max) is not needed. */
+int mg_flatfield_is_identity(int dtype, double dark, const void* d_dark, double flat, const void* d_flat);
+
 /* Pass 2, fused with the stitch crop/concat: out[p, R*hy, Cc*hx] in the input dtype,
  * value = trunc(((clip(x - dark, 0) / flat) * M1) / M2) with M1, M2 = d_max2[p / planes_per_group].
  * Tiles are laid out (plane, tile_row, tile_col, ty, tx); hy = ty - overlap etc.
@@ -161,13 +166,18 @@ int mg_hysteresis_tiles(int h, int w, int* tiles_x, int* tiles_y);
 int mg_unpack_bits(const uint32_t* d_bits, int64_t words_per_plane, int n_planes, int64_t n_bits, uint8_t* d_out,
                    void* stream);
 
-/* grid_array (utils.py:347-377) from the bitmap, in two phases so that the caller can size the
- * coordinate list: d_coords == NULL computes d_cell_counts / d_cell_starts [n_planes][gr*gc]
- * (gr = ceil(h / grid), gc = ceil(w / grid)) and d_num_edges[n_planes]; with d_coords the
- * cell-major / row-major-inside-cell list d_coords[n_planes][coord_cap][2] (row, col) is filled. */
+/* grid_array (utils.py:347-377) from the bitmap.  phases & 1: d_cell_counts / d_cell_starts [n_planes][gr*gc]
+ * (gr = ceil(h / grid), gc = ceil(w / grid)) and d_num_edges[n_planes]; phases & 2: the cell-major /
+ * row-major-inside-cell list d_coords[n_planes][coord_cap][2] (row, col) is filled.  A caller without an estimate of
+ * the edge count runs phase 1, reads d_num_edges and sizes the list; one with a capacity from an earlier call runs
+ * both at once (phases = 3): a plane with more edges than coord_cap then gets d_num_edges = 0 -- nothing downstream
+ * indexes beyond the list -- and its true count in d_edge_totals[n_planes] (optional), for the caller to check when it
+ * next synchronises.  d_scan_state (optional): mg_edge_grid_scan_words(...) zero-initialised 64-bit words owned by
+ * this caller; with it the prefix sum over the cells runs on many workgroups per plane instead of one. */
+int64_t mg_edge_grid_scan_words(int n_planes, int h, int w, int grid);
 int mg_edge_grid(const uint32_t* d_edge_bits, int64_t words_per_plane, int n_planes, int h, int w, int grid,
                  int32_t* d_cell_counts, int32_t* d_cell_starts, int32_t* d_num_edges, int32_t* d_coords,
-                 int64_t coord_cap, void* stream);
+                 int64_t coord_cap, uint64_t* d_scan_state, int32_t* d_edge_totals, int phases, void* stream);
 
 /* float32 gradient angle arctan2(dy, dx) (utils.py:118-119, 170) at every edge pixel of the
  * compact list, evaluated in float64 and rounded once: d_angle[n_planes][h][w] is written at

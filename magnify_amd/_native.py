@@ -32,6 +32,7 @@ PROTOTYPES = {
     "mg_cv_disk_halfwidths": [_i, _p],
     "mg_perimeter_table": [_i, _i, _p, _p, _p, _i],
     "mg_flatfield_max": [_p, _i, _l, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p],
+    "mg_flatfield_is_identity": [_i, _d, _p, _d, _p],
     "mg_flatfield_apply_stitch": [_p, _i, _l, _i, _i, _i, _i, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p, _p, _p],
     "mg_plane_minmax": [_p, _i, _i, _l, _i, _i, _l, _p, _p],
     "mg_to_uint8_blur": [_p, _i, _i, _l, _i, _i, _l, _p, _p, _p, _p],
@@ -42,7 +43,8 @@ PROTOTYPES = {
     "mg_canny_hysteresis": [_p, _p, _l, _i, _i, _i, _p, _p, _p, _p],
     "mg_unpack_bits": [_p, _l, _i, _l, _p, _p],
     "mg_hysteresis_tiles": [_i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
-    "mg_edge_grid": [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p],
+    "mg_edge_grid_scan_words": [_i, _i, _i, _i],
+    "mg_edge_grid": [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p, _p, _i, _p],
     "mg_candidate_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _p, _p],
     "mg_candidate_keys": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _i, _p, _p, _p],
     "mg_keys_to_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _l, _p, _p, _p, _p],
@@ -69,7 +71,7 @@ PROTOTYPES = {
     "mg_masked_sums": [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p],
 }
 
-RETURNS_INT64 = {"mg_scharr_hist_scratch_words"}
+RETURNS_INT64 = {"mg_scharr_hist_scratch_words", "mg_edge_grid_scan_words"}
 
 _lib = None
 

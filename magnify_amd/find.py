@@ -89,8 +89,9 @@ class BeadFinder:
         # masks straight from the bead table (what utils.circle_labels + the == i / == -1 tests yield,
         # find.py:561-586) -- no label map is written or read
         out = hotpath.roi_gather_reduce(image[None], [beads], L, None, disks=True)
-        fg = out["fg"].bool()[:, None].expand(m, n_t, L, L)  # geometry replicated over time (find.py:585-586)
-        bg = out["bg"].bool()[:, None].expand(m, n_t, L, L)
+        # the kernel writes 0 / 1 bytes: reinterpreted as bool, not converted (two passes over M L^2 bytes less)
+        fg = out["fg"].view(torch.bool)[:, None].expand(m, n_t, L, L)  # geometry replicated over time (find.py:585-586)
+        bg = out["bg"].view(torch.bool)[:, None].expand(m, n_t, L, L)
         assay["roi"] = DataArray(out["roi"], ("mark", "channel", "time", "roi_y", "roi_x"))
         xy = beads.astype(np.float64)
         assay = assay.assign_coords(

@@ -116,6 +116,15 @@ def _df_operand(value, ty, tx, device):
     return 0.0, arr, nat.dtype_code(arr.dtype)
 
 
+def flatfield_is_identity(dtype, flatfield=1.0, darkfield=0.0) -> bool:
+    """Integer pixels with the reference's default operands (flat 1, dark 0): the correction leaves every pixel as
+    it is (mg_flatfield_is_identity), so neither pass 1 nor the arithmetic of pass 2 is needed."""
+    scalar = lambda v: np.isscalar(v) or (isinstance(v, np.ndarray) and v.ndim == 0)  # noqa: E731
+    if not (scalar(flatfield) and scalar(darkfield)):
+        return False
+    return bool(nat.lib().mg_flatfield_is_identity(nat.dtype_code(dtype), float(darkfield), 0, float(flatfield), 0))
+
+
 def flatfield_max(tiles: torch.Tensor, flatfield=1.0, darkfield=0.0, n_groups=1) -> torch.Tensor:
     """Pass 1 of flatfield_correct: the two global maxima as a float64 (n_groups, 2) device tensor
     (``n_groups`` equal blocks along the leading axes: one per independent assay)."""
@@ -150,6 +159,8 @@ def flatfield_stitch(tiles: torch.Tensor, overlap: int, flatfield=1.0, darkfield
     fl, flt, flc = _df_operand(flatfield, ty, tx, tiles.device)
     if (c * t) % n_groups:
         raise ValueError("n_groups must divide the number of planes")
+    if apply_flatfield and flatfield_is_identity(tiles.dtype, flatfield, darkfield):
+        apply_flatfield = False
     if apply_flatfield and max2 is None:
         max2 = flatfield_max(tiles, flatfield, darkfield, n_groups)
     if out is None:
@@ -256,6 +267,8 @@ class CircleFinder:
     ``coords`` ...) stay available for inspection by the parity tests.
     """
 
+    MAX_GROUP = 64  # most hysteresis sweeps / suppression rounds launched between two host checks
+
     def __init__(self, n_planes, h, w, min_radius, max_radius, num_iter, device="cuda", grid_length=GRID_LENGTH):
         require_gpu()
         if min_radius > max_radius:
@@ -273,17 +286,30 @@ class CircleFinder:
         self.angle = None  # float32 (P, h, w), valid at edge pixels: only when something reads it (see need_angle_map)
         self.hist = torch.zeros((P, COMBINED_BINS), dtype=i32, device=dev)
         self.hist_base = torch.zeros((P,), dtype=i32, device=dev)
-        self._hyst_hint, self._nms_hint = 4, 2  # sweeps / rounds the previous call needed
         # per-workgroup histogram slots: plain stores + a reduce kernel instead of global atomics
         self.hist_scratch = torch.empty((int(nat.lib().mg_scharr_hist_scratch_words(P, h, w, 0)),), dtype=i32, device=dev)
         self.thresh = torch.zeros((P, 2), dtype=i32, device=dev)
         self.quant_d = torch.zeros((P, 2), dtype=torch.float32, device=dev)  # np.quantile's two values per plane
-        self.unresolved = torch.zeros((P,), dtype=i32, device=dev)
+        # Every per-plane counter the host ever looks at lives in ONE block: one fill clears it, one copy fetches it
+        # (rows: the eight counters, then `changed` per hysteresis sweep, then `undecided` per suppression round).
+        G = self.MAX_GROUP
+        self.status = torch.zeros((8 + 2 * G, P), dtype=i32, device=dev)
+        (self.num_edges, self.edge_totals, self.unresolved, self.num_alive, self.num_out, self.num_scored,
+         self.num_surv, self.num_circles) = (self.status[k] for k in range(8))
+        self.changed, self.undecided = self.status[8: 8 + G], self.status[8 + G: 8 + 2 * G]
+        self.status_host = torch.zeros((8 + 2 * G, P), dtype=i32).pin_memory()
         self._thresh_on_host, self._quantiles = False, None
-        self.changed = torch.zeros((4, P), dtype=i32, device=dev)
         tx, ty = nat.C.c_int(0), nat.C.c_int(0)
         nat.check(nat.lib().mg_hysteresis_tiles(h, w, nat.C.byref(tx), nat.C.byref(ty)), "mg_hysteresis_tiles")
-        self.tile_flags = torch.zeros((2, P, ty.value, tx.value), dtype=u8, device=dev)
+        # active-tile flags of the hysteresis sweeps, one layer per sweep of a group (+ the last layer of the group before)
+        self.tile_flags = torch.zeros((G + 1, P, ty.value, tx.value), dtype=u8, device=dev)
+        self.scan_state = torch.zeros((max(1, int(nat.lib().mg_edge_grid_scan_words(P, h, w, self.grid))),),
+                                      dtype=torch.int64, device=dev)
+        # Optimistic chain (see find): sweeps / rounds / capacities taken from the calls before, everything checked
+        # at the one host round trip at the end.  MG_CHECKED_CHAIN=1 keeps the three-round-trip chain.
+        self.optimistic = not os.environ.get("MG_CHECKED_CHAIN")
+        self._recent_sweeps, self._recent_rounds = [], []
+        self._out_sets, self._out_turn, self._out_cap = [None, None], 0, 0
         self.words = 2 * ((h * w + 63) // 64) + 2  # bitmap words per plane (even, one spare)
         self.edge_bits = torch.zeros((P, self.words), dtype=i32, device=dev)  # strong bits = edges
         self.weak_bits = torch.zeros((P, self.words), dtype=i32, device=dev)
@@ -292,7 +318,6 @@ class CircleFinder:
         self.keep_debug_maps = False  # True: also produce the {0,1} byte map and the angle map (tests)
         self.cell_counts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
         self.cell_starts = torch.zeros((P, self.n_cells), dtype=i32, device=dev)
-        self.num_edges = torch.zeros((P,), dtype=i32, device=dev)
         self.coords = None
         ntr, ntc, self.n_layers, self.bitmap_words = nat.dedup_layout(h, w, self.min_r, self.max_r)
         self.n_tiles = ntr * ntc
@@ -308,14 +333,10 @@ class CircleFinder:
         self.tile_ranges = torch.zeros((P, self.n_tiles, 2), dtype=i32, device=dev) if self.keyed else None
         self._tie_keys = None  # unique_keys while they describe self.circles (tie-breakers of the suppression)
         self.circles = torch.empty((P, self.cap, 3), dtype=i32, device=dev)
-        self.num_circles = torch.zeros((P,), dtype=i32, device=dev)
         self.scores = torch.empty((P, self.cap), dtype=torch.float32, device=dev)
         self.alive = torch.empty((P, self.cap), dtype=i32, device=dev)
-        self.num_alive = torch.zeros((P,), dtype=i32, device=dev)
-        self.num_scored = torch.zeros((P,), dtype=i32, device=dev)
         self.max_rc = torch.zeros((P, 2), dtype=i32, device=dev)
         self.state = torch.zeros((P, self.cap), dtype=u8, device=dev)
-        self.undecided = torch.zeros((P,), dtype=i32, device=dev)
         per_rc, per_exp, per_starts = nat.perimeter_table(self.min_r, self.max_r)
         self.per_rc = torch.from_numpy(per_rc).to(dev)
         self.per_exp = torch.from_numpy(per_exp).to(dev)
@@ -330,15 +351,34 @@ class CircleFinder:
             self.pair_table = torch.from_numpy(nat.score_pair_table().view(np.int64)).to(dev)
             self.layer_starts = torch.zeros((P, self.n_tiles, self.max_r - self.min_r + 2), dtype=i32, device=dev)
             self.surv_list = torch.empty((P, self.cap, 2), dtype=i32, device=dev)  # (list index, key) per survivor
-            self.num_surv = torch.zeros((P,), dtype=i32, device=dev)
         self.nms_grid = None
         self.seeds = torch.zeros((P,), dtype=torch.int64, device=dev)
         self.raw = None
         self.stats = {}
 
+    # -- host <-> device bookkeeping ---------------------------------------------------------------
+    def _fetch_status(self):
+        """The status block on the host (one pinned copy + a stream sync): rows as laid out in __init__."""
+        self.status_host.copy_(self.status, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self.status_host.numpy()
+
+    @staticmethod
+    def _hint(recent, floor):
+        """Launches to issue before the host looks: one more than the most any of the last calls needed (a sweep /
+        round after convergence costs a flag test), at least `floor`."""
+        return max(floor, (max(recent) + 1) if recent else floor)
+
+    @staticmethod
+    def _note(recent, needed):
+        recent.append(int(needed))
+        del recent[:-4]
+
     # -- stage 1: to_uint8 + blur + Scharr/quantiles + Canny + hysteresis + edge grid --------
     def edge_stage(self, planes: torch.Tensor, minmax, low_q: float, high_q: float, keep_u8=False,
-                   passthrough_u8=False):
+                   passthrough_u8=False, optimistic=False):
+        """``optimistic``: nothing comes back to the host -- the sweeps and the coordinate capacity are those of the
+        calls before and the caller (find) checks convergence / overflow when it fetches the status block."""
         L, P, h, w, s = nat.lib(), self.P, self.h, self.w, _stream()
         assert tuple(planes.shape) == (P, h, w)
         if planes.stride(2) != 1:
@@ -363,6 +403,7 @@ class CircleFinder:
         # showed that this kind of image needs the window passes (ranks inside coarse bins: noiseless images);
         # whether they were needed THIS time rides on the hysteresis convergence check below.
         on_device = not self._thresh_on_host
+        assert on_device or not optimistic
         if on_device:
             ranks4 = np.array([idx[0][0], idx[0][1], idx[1][0], idx[1][1]], dtype=np.int64)
             _call("mg_edge_thresholds", self.hist.data_ptr(), P, ranks4.ctypes.data, float(idx[0][2]), float(idx[1][2]),
@@ -371,24 +412,29 @@ class CircleFinder:
             self.stats["hist_passes"] = 1
         else:
             self._thresholds_on_host(idx, n)
-        n_edges, sweeps, needed, unresolved = self._edges_from_thresholds(on_device)
-        if on_device and unresolved:
-            self._thresh_on_host = True
-            self._thresholds_on_host(idx, n)
-            n_edges, sweeps, needed, _ = self._edges_from_thresholds(False)
-        elif not on_device and self.stats["hist_passes"] == 1:
-            self._thresh_on_host = False  # every rank sat in a fine bin: the device path serves the next call
-        self.stats["hysteresis_sweeps"] = sweeps
-        self._hyst_hint = needed
+        if optimistic:
+            self._canny()
+            self._sweeps(0, min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP))
+            self._edge_grid(3)
+            n_edges = None
+        else:
+            n_edges, sweeps, needed, unresolved = self._edges_from_thresholds(on_device)
+            if on_device and unresolved:
+                self._thresh_on_host = True
+                self._thresholds_on_host(idx, n)
+                n_edges, sweeps, needed, _ = self._edges_from_thresholds(False)
+            elif not on_device and self.stats["hist_passes"] == 1:
+                self._thresh_on_host = False  # every rank sat in a fine bin: the device path serves the next call
+            self.stats["hysteresis_sweeps"] = sweeps
+            self._note(self._recent_sweeps, needed)
+            need_cap = max(1, int(n_edges.max()))
+            if self.coords is None or self.coords.shape[1] < need_cap:
+                self.coords = torch.empty((P, int(need_cap * 1.25) + 1, 2), dtype=torch.int32, device=self.dev)
+            self._edge_grid(2)
+        self.coord_cap = self.coords.shape[1]
         if self.keep_debug_maps:
             self.edges = torch.empty((P, h, w), dtype=torch.uint8, device=self.dev)
             _call("mg_unpack_bits", self.edge_bits.data_ptr(), self.words, P, h * w, self.edges.data_ptr(), s)
-        self.coord_cap = max(1, int(n_edges.max()))
-        if self.coords is None or self.coords.shape[1] < self.coord_cap:
-            self.coords = torch.empty((P, int(self.coord_cap * 1.25) + 1, 2), dtype=torch.int32, device=self.dev)
-        self.coord_cap = self.coords.shape[1]
-        _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, P, h, w, self.grid, self.cell_counts.data_ptr(),
-              self.cell_starts.data_ptr(), self.num_edges.data_ptr(), self.coords.data_ptr(), self.coord_cap, s)
         if self.need_angle_map():
             if self.angle is None:
                 self.angle = torch.empty((P, h, w), dtype=torch.float32, device=self.dev)
@@ -396,6 +442,30 @@ class CircleFinder:
                   self.num_edges.data_ptr(), self.angle.data_ptr(), s)
         self.n_edges_host = n_edges
         return n_edges
+
+    def _canny(self):
+        _call("mg_canny_nms", self.blur.data_ptr(), self.P, self.h, self.w, self.thresh.data_ptr(), self.weak_bits.data_ptr(),
+              self.edge_bits.data_ptr(), _ptr(self.class_bits), self.words, _stream())
+
+    def _sweeps(self, done, group):
+        """Hysteresis sweeps done .. done + group - 1; sweep k of the group counts its changes in self.changed[k]
+        (cleared by the caller) and writes the tile flags of layer k + 1 (layer 0: the flags of the sweep before)."""
+        flags = self.tile_flags
+        if done > 0:
+            flags[0].copy_(flags[self._last_layer])
+        flags[1: group + 1].zero_()
+        for g in range(group):
+            _call("mg_canny_hysteresis", self.weak_bits.data_ptr(), self.edge_bits.data_ptr(), self.words, self.P, self.h,
+                  self.w, self.changed[g].data_ptr(), flags[g].data_ptr() if done + g > 0 else 0,
+                  flags[g + 1].data_ptr(), _stream())
+        self._last_layer = group
+
+    def _edge_grid(self, phases):
+        coords = self.coords if phases & 2 else None
+        _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, self.P, self.h, self.w, self.grid,
+              self.cell_counts.data_ptr(), self.cell_starts.data_ptr(), self.num_edges.data_ptr(), _ptr(coords),
+              coords.shape[1] if coords is not None else 0, self.scan_state.data_ptr(), self.edge_totals.data_ptr(), phases,
+              _stream())
 
     def _thresholds_on_host(self, idx, n):
         """The rank search with window passes for ranks in coarse bins (strong gradients), np.quantile's
@@ -459,34 +529,21 @@ class CircleFinder:
     def _edges_from_thresholds(self, fetch_unresolved):
         """Canny NMS + hysteresis to convergence + the cell counts of the edge grid, from self.thresh.
         Returns (n_edges per plane, sweeps run, sweeps needed, any plane whose device thresholds were unresolved)."""
-        L, P, h, w, s = nat.lib(), self.P, self.h, self.w, _stream()
-        _call("mg_canny_nms", self.blur.data_ptr(), P, h, w, self.thresh.data_ptr(), self.weak_bits.data_ptr(),
-              self.edge_bits.data_ptr(), _ptr(self.class_bits), self.words, s)
+        self._canny()
         sweeps, unresolved, needed = 0, False, 0
-        # sweeps per host check: first as many as the previous call needed (a sweep after convergence only
+        # sweeps per host check: first as many as the calls before needed (a sweep after convergence only
         # runs the tile-flag test), then two at a time -- one host round trip in the steady state
-        group = max(2, min(int(self._hyst_hint), 64))
-        if self.changed.shape[0] < group:
-            self.changed = torch.zeros((group, P), dtype=torch.int32, device=self.dev)
+        group = min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP)
         while True:
-            self.changed.zero_()
-            for g in range(group):
-                cur = self.tile_flags[sweeps & 1]
-                cur.zero_()
-                prev = self.tile_flags[(sweeps + 1) & 1] if sweeps > 0 else None
-                _call("mg_canny_hysteresis", self.weak_bits.data_ptr(), self.edge_bits.data_ptr(), self.words, P, h, w,
-                      self.changed[g].data_ptr(), _ptr(prev), cur.data_ptr(), s)
-                sweeps += 1
+            self.changed[:group].zero_()
+            self._sweeps(sweeps, group)
+            sweeps += group
             # the cell counts of the edge grid ride on the same host round trip as the convergence check
             # (they are recomputed in the rare case that more sweeps are needed)
-            _call("mg_edge_grid", self.edge_bits.data_ptr(), self.words, P, h, w, self.grid, self.cell_counts.data_ptr(),
-                  self.cell_starts.data_ptr(), self.num_edges.data_ptr(), 0, 0, s)
-            parts = [self.changed[:group].sum(dim=1), self.num_edges.to(torch.int64)]
-            if fetch_unresolved:
-                parts.append(self.unresolved.sum(dtype=torch.int64).reshape(1))
-            both = torch.cat(parts).cpu().numpy()
-            per_sweep, n_edges = both[:group], both[group: group + P].astype(np.int32)
-            unresolved = bool(fetch_unresolved and both[-1] > 0)
+            self._edge_grid(1)
+            st = self._fetch_status()
+            per_sweep, n_edges = st[8: 8 + group].sum(axis=1), st[0].copy()
+            unresolved = bool(fetch_unresolved and st[2].any())
             if unresolved:  # these edges come from invalid thresholds: the caller redoes them
                 needed = sweeps
                 break
@@ -510,7 +567,8 @@ class CircleFinder:
         return self.keep_debug_maps or not self.keyed_score
 
     # -- stage 2: candidates -> unique integer circles -> scores ------------------------------
-    def circle_stage(self, seeds, min_roundness: float, keep_raw=False, dedup_centres=False):
+    def circle_stage(self, seeds, min_roundness: float, keep_raw=False, dedup_centres=False, counters_clear=False):
+        """``counters_clear``: the caller has just cleared the whole status block (find's optimistic chain)."""
         L, P, h, w, s = nat.lib(), self.P, self.h, self.w, _stream()
         seeds = np.asarray(seeds, dtype=np.uint64).reshape(P)
         self.seeds.copy_(torch.from_numpy(seeds.view(np.int64)))
@@ -537,8 +595,8 @@ class CircleFinder:
             _call("mg_bitmap_to_circles", self.bitmap.data_ptr(), self.bitmap_words, P, h, w, self.min_r, self.max_r,
                   self.layer_offsets.data_ptr(), self.circles.data_ptr(), self.cap,
                   self.num_circles.data_ptr(), s)
-        self.num_alive.zero_()
-        self.num_scored.zero_()
+        if not counters_clear:
+            self.status[3:7].zero_()  # num_alive, num_out, num_scored, num_surv
         self.max_rc.fill_(-(2**31))
         if self.keyed_score and self._tie_keys is not None:
             _call("mg_score_circles_keyed", self.blur.data_ptr(), 0, self.edge_bits.data_ptr(), self.class_bits.data_ptr(),
@@ -562,81 +620,159 @@ class CircleFinder:
               self.num_alive.data_ptr(), self.max_rc.data_ptr(), self.num_scored.data_ptr(), s)
 
     # -- stage 3: greedy suppression + ordered output -------------------------------------------
-    def nms_stage(self, min_dist: int):
-        L, P, s = nat.lib(), self.P, _stream()
-        n_alive = self.num_alive.cpu().numpy()
-        out_cap = max(1, int(n_alive.max()))
-        out = torch.empty((P, out_cap, 3), dtype=torch.int32, device=self.dev)
-        out_scores = torch.empty((P, out_cap), dtype=torch.float32, device=self.dev)
-        scratch = torch.empty((P, out_cap), dtype=torch.int32, device=self.dev)
-        num_out = torch.zeros((P,), dtype=torch.int32, device=self.dev)
+    def _out_buffers(self, need):
+        """Ordered-output buffers (circles, scores, scratch) with room for ``need`` circles per plane; two sets used in
+        turn, so the tables a caller got from the previous ``find`` stay intact during this one."""
+        if need > self._out_cap:
+            self._out_cap = int(need * 1.25) + 16
+            self._out_sets = [None, None]
+        self._out_turn ^= 1
+        if self._out_sets[self._out_turn] is None:
+            P, cap = self.P, self._out_cap
+            self._out_sets[self._out_turn] = (torch.empty((P, cap, 3), dtype=torch.int32, device=self.dev),
+                                              torch.empty((P, cap), dtype=torch.float32, device=self.dev),
+                                              torch.empty((P, cap), dtype=torch.int32, device=self.dev))
+        return self._out_sets[self._out_turn]
 
-        def collect():
-            _call("mg_collect_circles", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
-                  self.num_alive.data_ptr(), self.state.data_ptr(), int(min_dist <= 0), P, out.data_ptr(),
-                  out_scores.data_ptr(), out_cap, num_out.data_ptr(), scratch.data_ptr(), _ptr(self._tie_keys), s)
+    def _collect(self, bufs, min_dist):
+        out, out_scores, scratch = bufs
+        _call("mg_collect_circles", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
+              self.num_alive.data_ptr(), self.state.data_ptr(), int(min_dist <= 0), self.P, out.data_ptr(),
+              out_scores.data_ptr(), out.shape[1], self.num_out.data_ptr(), scratch.data_ptr(), _ptr(self._tie_keys), _stream())
 
-        rounds = 0
-        if min_dist > 0 and n_alive.max() > 0:
-            pad = 2 * min_dist + 1
-            grid_cap = (self.h + self.max_r + 2 * pad) * (self.w + self.max_r + 2 * pad)
-            if self.nms_grid is None or self.nms_grid.shape[1] < grid_cap:
-                self.nms_grid = torch.empty((P, grid_cap), dtype=torch.int64, device=self.dev)
-                self.nms_grid.fill_(-1)  # once: every call restores the cells it touched (mg_nms_cleanup)
-                self.state.zero_()
-            if getattr(self, "_nms_dist", None) != min_dist:
-                self._nms_ring = torch.from_numpy(nat.circle_points(min_dist, True)).to(self.dev)
-                self._nms_dist = min_dist
-            ring = self._nms_ring
-            # rounds per host check: as many as the previous call needed (a round with nothing undecided
-            # does no work), then two at a time.  The ordered output is gathered before the check and rides
-            # on the same round trip (it is gathered again in the rare case that more rounds are needed).
-            # same-centre circles: only the first of each centre enters the rounds (exact; three tiny launches)
+    def _nms_prepare(self, min_dist):
+        pad = 2 * min_dist + 1
+        grid_cap = (self.h + self.max_r + 2 * pad) * (self.w + self.max_r + 2 * pad)
+        if self.nms_grid is None or self.nms_grid.shape[1] < grid_cap:
+            self.nms_grid = torch.empty((self.P, grid_cap), dtype=torch.int64, device=self.dev)
+            self.nms_grid.fill_(-1)  # once: every call restores the cells it touched (mg_nms_cleanup)
+            self.state.zero_()
+        if getattr(self, "_nms_dist", None) != min_dist:
+            self._nms_ring = torch.from_numpy(nat.circle_points(min_dist, True)).to(self.dev)
+            self._nms_dist = min_dist
+
+    def _nms_rounds(self, min_dist, first, count, out_cap):
+        """Suppression rounds; round k of this group counts what it left undecided in self.undecided[k].  ``first``:
+        the same-centre pass (only the first circle of a centre enters the rounds: exact, three tiny launches)."""
+        P, s, ring = self.P, _stream(), self._nms_ring
+        if first:
             _call("mg_nms_same_centre", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
                   self.num_alive.data_ptr(), self.max_rc.data_ptr(), P, min_dist, self.nms_grid.data_ptr(),
                   self.nms_grid.shape[1], self.state.data_ptr(), _ptr(self._tie_keys), out_cap, s, stage="mg_nms_round")
-            group = max(2, min(int(self._nms_hint), 64))
-            if self.undecided.dim() != 2 or self.undecided.shape[0] < group:
-                self.undecided = torch.zeros((group, P), dtype=torch.int32, device=self.dev)
+        for g in range(count):
+            _call("mg_nms_round", self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
+                  self.alive.data_ptr(), self.num_alive.data_ptr(), self.max_rc.data_ptr(), P,
+                  min_dist, ring.data_ptr(), ring.shape[0], self.nms_grid.data_ptr(),
+                  self.nms_grid.shape[1], self.state.data_ptr(), self.undecided[g].data_ptr(),
+                  _ptr(self._tie_keys), out_cap, s)
+
+    def _nms_cleanup(self, min_dist, out_cap):
+        _call("mg_nms_cleanup", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
+              self.num_alive.data_ptr(), self.max_rc.data_ptr(), self.P, min_dist, self._nms_ring.data_ptr(),
+              self._nms_ring.shape[0], self.nms_grid.data_ptr(), self.nms_grid.shape[1], self.state.data_ptr(),
+              out_cap, _stream())
+
+    def nms_stage(self, min_dist: int, optimistic=False):
+        """Checked chain: the alive counts come to the host first (they size the output), the rounds are checked for
+        convergence afterwards.  ``optimistic``: output capacity and rounds from the calls before; the caller's (find's)
+        single status fetch follows -- returns (buffers, rounds launched) and leaves the checks to ``_nms_finish``."""
+        if optimistic:
+            bufs = self._out_buffers(self._out_cap)
+            rounds = 0
+            if min_dist > 0:
+                self._nms_prepare(min_dist)
+                rounds = min(self._hint(self._recent_rounds, 2), self.MAX_GROUP)
+                self._nms_rounds(min_dist, True, rounds, bufs[0].shape[1])
+            self._collect(bufs, min_dist)
+            return bufs, rounds
+        n_alive = self._fetch_status()[3]
+        bufs = self._out_buffers(max(1, int(n_alive.max())))
+        return self._nms_finish(min_dist, bufs, 0, int(n_alive.max()), None)
+
+    def _nms_finish(self, min_dist, bufs, rounds, max_alive, st):
+        """Rounds until nothing is undecided (``rounds`` were launched already and ``st`` is the status fetched after
+        them; none: start here), the ordered output, the cleanup of the claim grid."""
+        out_cap = bufs[0].shape[1]
+        launched = rounds
+        if min_dist > 0 and max_alive > 0:
+            self._nms_prepare(min_dist)
+            group = rounds
             while True:
-                for g in range(group):
-                    _call("mg_nms_round", self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
-                          self.alive.data_ptr(), self.num_alive.data_ptr(), self.max_rc.data_ptr(), P,
-                          min_dist, ring.data_ptr(), ring.shape[0], self.nms_grid.data_ptr(),
-                          self.nms_grid.shape[1], self.state.data_ptr(), self.undecided[g].data_ptr(),
-                          _ptr(self._tie_keys), out_cap, s)
-                    rounds += 1
-                collect()
-                both = torch.cat([self.undecided[:group].sum(dim=1), num_out.to(torch.int64)]).cpu().numpy()
-                per_round, counts = both[:group], both[group:]
-                if per_round[group - 1] == 0:
-                    self._nms_hint = rounds - group + int(np.argmax(per_round == 0)) + 1
-                    break
-                group = 2
-                if rounds > 10000:
-                    raise RuntimeError("greedy suppression did not converge")
-        else:
-            collect()
-            counts = num_out.cpu().numpy()
+                if st is not None:
+                    per_round = st[8 + self.MAX_GROUP: 8 + self.MAX_GROUP + group].sum(axis=1)
+                    if per_round[group - 1] == 0:
+                        self._note(self._recent_rounds, rounds - group + int(np.argmax(per_round == 0)) + 1)
+                        break
+                    if rounds > 10000:
+                        raise RuntimeError("greedy suppression did not converge")
+                group = min(self._hint(self._recent_rounds, 2), self.MAX_GROUP) if rounds == 0 else 2
+                self._nms_rounds(min_dist, rounds == 0, group, out_cap)
+                rounds += group
+                # the ordered output is gathered before the check and rides on the same round trip (it is gathered
+                # again in the rare case that more rounds are needed)
+                self._collect(bufs, min_dist)
+                st = self._fetch_status()
+        elif st is None:
+            self._collect(bufs, min_dist)
+            st = self._fetch_status()
+        counts = st[4].copy()
         self.stats["nms_rounds"] = rounds
-        if rounds:
-            _call("mg_nms_cleanup", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
-                  self.num_alive.data_ptr(), self.max_rc.data_ptr(), P, min_dist, self._nms_ring.data_ptr(),
-                  self._nms_ring.shape[0], self.nms_grid.data_ptr(), self.nms_grid.shape[1], self.state.data_ptr(),
-                  out_cap, s)
+        if rounds or launched:
+            self._nms_cleanup(min_dist, out_cap)
         self._out_counts = counts.astype(np.int64)
-        return out, out_scores, num_out
+        return bufs[0], bufs[1], self.num_out
 
     def find(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw=False, keep_u8=False,
              passthrough_u8=False, host_results=True):
         """Returns per-plane lists (circles int32 (M,3) [row, col, r], scores float32 (M,)) on the
         host plus the device tensors (out, out_scores, num_out).  ``host_results=False``: only the
         counts come back -- (counts, (out, out_scores, num_out)); ``fetch_results`` copies the lists
-        later (e.g. after the ROI pass, which reads the tables on the device, has been launched)."""
-        n_edges = self.edge_stage(planes, minmax, low_q, high_q, keep_u8=keep_u8, passthrough_u8=passthrough_u8)
-        # with suppression to follow, passing circles that share a centre are reduced to their first
-        self.circle_stage(seeds, min_roundness, keep_raw=keep_raw, dedup_centres=min_dist > 0)
-        out, out_scores, num_out = self.nms_stage(min_dist)
+        later (e.g. after the ROI pass, which reads the tables on the device, has been launched).
+        The device tensors stay valid until the next-but-one ``find`` of this finder.
+
+        Host round trips: the checked chain has three (hysteresis convergence + edge counts, alive counts,
+        suppression convergence + output counts).  Once a call has gone through it, the next ones run OPTIMISTICALLY:
+        sweeps, rounds and buffer capacities as the calls before needed (plus one), every kernel launched without
+        looking, ONE fetch of the status block at the end -- which shows whether the thresholds were resolved, the
+        sweeps converged, the coordinate list and the output were large enough and the rounds converged.  Anything
+        else is repaired from that point with the checked chain (the results are the same either way: every stage is
+        a pure function of its inputs; a plane whose edges overflowed the list was skipped by the kernels after it)."""
+        opt = (self.optimistic and not self._thresh_on_host and self.coords is not None and self._out_cap > 0
+               and bool(self._recent_sweeps) and (min_dist <= 0 or bool(self._recent_rounds)))
+        self.stats["optimistic"] = False
+        if opt:
+            self.status.zero_()
+            self.edge_stage(planes, minmax, low_q, high_q, keep_u8=keep_u8, passthrough_u8=passthrough_u8, optimistic=True)
+            self.circle_stage(seeds, min_roundness, keep_raw=keep_raw, dedup_centres=min_dist > 0, counters_clear=True)
+            bufs, rounds = self.nms_stage(min_dist, optimistic=True)
+            st = self._fetch_status()
+            sweeps = self._last_layer
+            per_sweep = st[8: 8 + sweeps].sum(axis=1)
+            edges_ok = (not st[2].any() and per_sweep[sweeps - 1] == 0
+                        and int(st[1].max()) <= self.coords.shape[1])
+            if edges_ok:
+                n_edges = st[0].copy()
+                self.n_edges_host = n_edges
+                self.stats.update(hysteresis_sweeps=sweeps, optimistic=True)
+                self._note(self._recent_sweeps, int(np.argmax(per_sweep == 0)) + 1)
+                max_alive = int(st[3].max())
+                if max_alive > bufs[0].shape[1]:  # the ordered output did not fit: gather it again (the rounds hold)
+                    bufs = self._out_buffers(max_alive)
+                    self._collect(bufs, min_dist)
+                    st = self._fetch_status()
+                out, out_scores, num_out = self._nms_finish(min_dist, bufs, rounds, max_alive, st)
+            else:
+                # the edges were not final (or did not fit): restore the claim grid the rounds wrote into, then redo
+                if rounds:
+                    self._nms_cleanup(min_dist, bufs[0].shape[1])
+                if int(st[1].max()) > self.coords.shape[1]:
+                    self.coords = None  # sized again from the counts
+                opt = False
+        if not opt:
+            n_edges = self.edge_stage(planes, minmax, low_q, high_q, keep_u8=keep_u8, passthrough_u8=passthrough_u8)
+            # with suppression to follow, passing circles that share a centre are reduced to their first
+            self.circle_stage(seeds, min_roundness, keep_raw=keep_raw, dedup_centres=min_dist > 0)
+            out, out_scores, num_out = self.nms_stage(min_dist)
         counts = self._out_counts  # came back with the suppression's convergence check
         self.stats["n_edges"] = n_edges
         if not host_results:

@@ -94,7 +94,9 @@ class LazyFlatfield:
     def __init__(self, tiles: torch.Tensor, flatfield, darkfield):
         self.tiles, self.flatfield, self.darkfield = tiles, flatfield, darkfield
         self.shape, self.dtype = tuple(tiles.shape), tiles.dtype
-        self.max2 = hotpath.flatfield_max(tiles, flatfield, darkfield)  # pass 1: the two global maxima
+        # pass 1: the two global maxima (not needed when the correction is the identity: integer pixels, flat 1, dark 0)
+        self.max2 = (None if hotpath.flatfield_is_identity(tiles.dtype, flatfield, darkfield)
+                     else hotpath.flatfield_max(tiles, flatfield, darkfield))
 
     def materialize(self):
         c, t, nr, nc, ty, tx = self.shape

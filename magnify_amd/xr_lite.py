@@ -150,6 +150,8 @@ class DataArray:
             dims = tuple(dims[:i]) + tuple(rest) + tuple(dims[i + 1:])
         dims = tuple(d for d in dims if d in self.dims)
         perm = [self.dims.index(d) for d in dims]
+        if perm == list(range(self.ndim)):  # already in order: a pending (lazy) operand stays pending
+            return self._replace(self._data, dims, dict(self.coords))
         data = self.data.permute(*perm) if _is_tensor(self.data) else np.transpose(self.data, perm)
         return self._replace(data, dims, dict(self.coords))
 

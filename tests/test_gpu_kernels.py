@@ -485,3 +485,120 @@ def test_roi_segment_reduce_from_disks(hp, dtype, L):
             np.testing.assert_array_equal(sums[..., 0], win.astype(np.float64)[:, :, sub == i].sum(-1))
             np.testing.assert_array_equal(sums[..., 1], win.astype(np.float64)[:, :, sub == -1].sum(-1))
             assert tuple(res["counts"][g].cpu().numpy()) == (int((sub == i).sum()), int((sub == -1).sum()))
+
+
+# ---------------------------------------------------------------------------------------------
+# the optimistic chain (one host round trip per call) against the checked chain (three)
+# ---------------------------------------------------------------------------------------------
+
+
+def test_optimistic_chain_equals_checked_chain(hp):
+    """A sequence of calls on one finder: the first goes through the checked chain, the later ones run
+    optimistically with the sweeps / rounds / capacities of the calls before -- including calls where those do NOT
+    suffice (a coordinate list / output that is too small, too few sweeps / rounds, many more edges and beads than
+    before, a blank plane, a noiseless plane) and the chain has to repair itself.  Every call must return exactly what
+    a fresh, checked finder returns."""
+    shape = (320, 384)
+
+    def normal(k):
+        return np.stack([noisy_bead_image(k + j, shape, 6)[0] for j in range(2)])
+
+    def shrink_coords(cf):
+        cf.coords = cf.coords[:, :50].contiguous()
+
+    def shrink_output(cf):
+        cf._out_cap, cf._out_sets = 1, [None, None]
+
+    def few_rounds(cf):
+        cf._recent_rounds[:] = [0]
+
+    def few_sweeps(cf):
+        cf._recent_sweeps[:] = [0]
+
+    calls = [  # (planes, what is done to the finder before the call, optimistic expected: True / False / None = either)
+        (normal(50), None, False),   # first call: checked
+        (normal(60), None, True),
+        (normal(70), None, True),
+        (normal(80), None, True),
+        (normal(90), shrink_coords, False),
+        (normal(100), shrink_output, True),
+        (normal(110), few_rounds, True),
+        (normal(120), few_sweeps, None),
+        (np.stack([noisy_bead_image(130 + k, shape, 40, r_lo=6, r_hi=10, poisson=200.0)[0] for k in range(2)]), None, None),
+        (np.stack([np.zeros(shape, dtype=np.uint16), noisy_bead_image(141, shape, 6)[0]]), None, None),
+        (np.stack([draw_beads(shape, [[100, 100], [200, 250]], 30), noisy_bead_image(151, shape, 6)[0]]), None, None),
+        (normal(160), None, None),
+        (normal(170), None, True),
+    ]
+    cf = hp.CircleFinder(2, shape[0], shape[1], 5, 21, 60000)
+    took_fast = []
+    for n, (planes, sabotage, expect) in enumerate(calls):
+        if n > 0:  # enough sweeps / rounds / list capacity for any of these scenes: only the sabotage decides the path
+            cf._recent_sweeps[:], cf._recent_rounds[:] = [12], [12]
+            if cf.coords.shape[1] < 80000:  # (the edge counts of these scenes vary between 1 000 and 30 000)
+                cf.coords = torch.empty((2, 80000, 2), dtype=torch.int32, device="cuda")
+        if sabotage:
+            sabotage(cf)
+        seeds = [1000 + 2 * n, 1001 + 2 * n]
+        got, _ = cf.find(dev(planes), None, 0.1, 0.9, 0.3, 5, seeds)
+        took_fast.append(bool(cf.stats["optimistic"]))
+        ref = hp.CircleFinder(2, shape[0], shape[1], 5, 21, 60000)
+        ref.optimistic = False
+        want, _ = ref.find(dev(planes), None, 0.1, 0.9, 0.3, 5, seeds)
+        assert not ref.stats["optimistic"]
+        for p in range(2):
+            np.testing.assert_array_equal(got[p][0], want[p][0], err_msg=f"call {n} plane {p}")
+            np.testing.assert_array_equal(got[p][1], want[p][1], err_msg=f"call {n} plane {p}")
+        np.testing.assert_array_equal(cf.n_edges_host, ref.n_edges_host)
+        assert expect is None or took_fast[-1] == expect, (n, took_fast)
+    assert len(want[1][0]) >= 4  # the scenes do hold beads
+
+
+def test_edge_grid_chunked_scan(hp):
+    """The many-workgroup prefix sum over the cells (d_scan_state) against the one-workgroup one, and the capacity
+    guard of the one-call form (phases = 3): a plane with more edges than the list holds reports 0 edges and its
+    true count."""
+    from magnify_amd import _native as nat
+
+    rng = np.random.default_rng(8)
+    P, h, w, grid = 3, 700, 900, 8
+    words = 2 * ((h * w + 63) // 64) + 2
+    bits = np.zeros((P, words), dtype=np.uint32)
+    dens = [0.02, 0.2, 0.0]
+    for p in range(P):
+        m = (rng.random(h * w) < dens[p])
+        packed = np.packbits(m, bitorder="little")
+        bits[p].view(np.uint8)[: len(packed)] = packed
+    d_bits = dev(bits.view(np.int32))
+    n_cells = ((h + grid - 1) // grid) * ((w + grid - 1) // grid)
+    out = {}
+    for label in ("one", "chunks"):
+        counts = torch.zeros((P, n_cells), dtype=torch.int32, device="cuda")
+        starts = torch.zeros((P, n_cells), dtype=torch.int32, device="cuda")
+        num = torch.zeros((P,), dtype=torch.int32, device="cuda")
+        state = torch.zeros((int(nat.lib().mg_edge_grid_scan_words(P, h, w, grid)),), dtype=torch.int64, device="cuda")
+        for _ in range(2):  # twice: the second launch meets the first one's published totals
+            nat.check(nat.lib().mg_edge_grid(d_bits.data_ptr(), words, P, h, w, grid, counts.data_ptr(), starts.data_ptr(),
+                                             num.data_ptr(), 0, 0, state.data_ptr() if label == "chunks" else 0, 0, 1, 0),
+                      "mg_edge_grid")
+        torch.cuda.synchronize()
+        out[label] = (counts.cpu().numpy(), starts.cpu().numpy(), num.cpu().numpy())
+    for a, b in zip(out["one"], out["chunks"]):
+        np.testing.assert_array_equal(a, b)
+    counts, starts, num = out["one"]
+    np.testing.assert_array_equal(starts, np.cumsum(counts, axis=1) - counts)
+    np.testing.assert_array_equal(num, counts.sum(axis=1))
+    assert state.numel() == P * ((n_cells + 4095) // 4096) and state.numel() > P
+    # one call, capacity between the two densities
+    cap = int(num[0]) + 10
+    coords = torch.full((P, cap, 2), -7, dtype=torch.int32, device="cuda")
+    totals = torch.zeros((P,), dtype=torch.int32, device="cuda")
+    counts_d, starts_d, num_d = (torch.zeros_like(torch.from_numpy(x)).cuda() for x in out["one"])
+    nat.check(nat.lib().mg_edge_grid(d_bits.data_ptr(), words, P, h, w, grid, counts_d.data_ptr(), starts_d.data_ptr(),
+                                     num_d.data_ptr(), coords.data_ptr(), cap, state.data_ptr(), totals.data_ptr(), 3, 0),
+              "mg_edge_grid")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(totals.cpu().numpy(), num)
+    np.testing.assert_array_equal(num_d.cpu().numpy(), [num[0], 0, 0])
+    c0 = coords[0, : num[0]].cpu().numpy()
+    assert (c0 >= 0).all() and len(np.unique(c0[:, 0].astype(np.int64) * w + c0[:, 1])) == num[0]
