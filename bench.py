@@ -331,6 +331,8 @@ def main():
         else:
             unique, alive, scored = int(f.num_circles.sum().item()), int(f.num_alive.sum().item()), int(f.num_scored.sum().item())
             edges, fstats, search_planes = int(f.n_edges_host.sum()), [f.stats], f.P
+        finders = list(getattr(proc, "finders", None) or [f])
+        chain = {k: sum(x.calls[k] for x in finders) for k in ("optimistic", "repaired", "checked")}
         per_starts = f.per_starts.cpu().numpy()
         mean_perimeter = float(np.mean(np.diff(per_starts)))
         p = {"h": S, "w": S, "n_c": C, "n_t": T, "search_planes": search_planes, "num_iter": args.num_iter,
@@ -401,6 +403,9 @@ def main():
                       "streams": proc.n_streams, "sub_batches": len(getattr(proc, "ranges", [0])),
                       "alive_circles": alive, "edges": p["edges"],
                       "hysteresis_sweeps": p["sweeps"], "nms_rounds": p["nms_rounds"],
+                      # calls of find() since start-up (warm-up included): with ONE host round trip (optimistic),
+                      # with a repair after it, with the three round trips of the checked chain
+                      "find_calls": chain,
                       "kernel_ms_per_step": total_ms / args.steps},
         }
         result["hbm_copy_ceiling"] = hbm_copy_ceiling(dev)

@@ -147,7 +147,9 @@ int mg_edge_thresholds(const uint32_t* d_hist, int n_planes, const int64_t* rank
  * Scharr gradient: the quarter 2 c1 + c0 (same sign: |dy| < |dx| -> 0 else 1; opposite sign: |dy| > |dx| -> 2
  * else 3) and its upper half c2 (tan(pi/8) = sqrt(2) - 1 and tan(3 pi/8) = sqrt(2) + 1 as integer
  * inequalities (|dx| + |dy|)^2 > 2 dx^2, (|dy| - |dx|)^2 > 2 dx^2); consumed by the scoring prefilters
- * (mg_score_circles: quarters; mg_score_circles_keyed: eighths). */
+ * (mg_score_circles: quarters; mg_score_circles_keyed: eighths).
+ * The words behind the last pixel of a plane are never written: the caller zeroes the bitmaps once, when it
+ * allocates them (the words inside the image are overwritten by every call). */
 int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_thresh, uint32_t* d_weak,
                  uint32_t* d_strong, uint32_t* d_class, int64_t words_per_plane, void* stream);
 
@@ -318,7 +320,7 @@ int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angle, const ui
  * mg_keys_to_circles) or, when NULL, the index in d_circles (canonical after mg_bitmap_to_circles).
  * d_grid[n_planes][grid_cap] uint64 claim grid pre-set to all-ones;
  * d_state[n_planes][circle_cap] uint8 (0 undecided, 1 kept, 2 dropped) pre-zeroed for
- * alive circles; d_undecided[n_planes] is overwritten with the number still undecided.
+ * alive circles; d_undecided[n_planes] is set to 0, or to 1 when a circle is still undecided.
  * Ring = 4-connected perimeter of radius min_dist (d_ring_rc, ring_len); indices wrap
  * modulo the claim grid extent like negative numba indices do. */
 /* max_alive (both calls): an upper bound of d_num_alive known to the caller, used only to size the

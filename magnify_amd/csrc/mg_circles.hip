@@ -712,6 +712,11 @@ __device__ __forceinline__ int wrap(int v, int n) {
   return v;
 }
 
+// PHASE 0 (bid), 1 (decide), 2 (cleanup): one WAVE per alive circle, one lane per ring cell -- the ring's loads and
+// atomics of a circle are in flight together and the verdict is two ballots (a thread per circle walked its ring in
+// seven dependent steps: a chain of HBM latencies per round at any batch size).  PHASE 3-5: one thread per circle.
+// d_undecided[plane] becomes non-zero when a circle stays undecided (a flag, not a count: one atomicAdd per wave on
+// one address serialised 18 000 deep in the first round).
 template <int PHASE>
 __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circles, int64_t circle_cap,
                                             const float* __restrict__ d_scores, const int32_t* __restrict__ d_alive,
@@ -733,13 +738,12 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
   const int32_t* alive = d_alive + (int64_t)plane * circle_cap;
   uint8_t* state = d_state + (int64_t)plane * circle_cap;
   uint64_t* grid = d_grid + (int64_t)plane * grid_cap;
-  for (int64_t a = (int64_t)blockIdx.x * NT + threadIdx.x; a < n; a += (int64_t)gridDim.x * NT) {
-    const int idx = alive[a];
-    if (PHASE != 2 && PHASE != 5 && state[idx] != 0) continue;
-    const int row = circles[3 * (int64_t)idx], col = circles[3 * (int64_t)idx + 1];
-    const uint32_t tk = tie ? tie[idx] : (uint32_t)idx;
-    const uint64_t key = nms_key(scores[idx], tk);
-    if (PHASE >= 3) {
+  if (PHASE >= 3) {
+    for (int64_t a = (int64_t)blockIdx.x * NT + threadIdx.x; a < n; a += (int64_t)gridDim.x * NT) {
+      const int idx = alive[a];
+      if (PHASE != 5 && state[idx] != 0) continue;
+      const int row = circles[3 * (int64_t)idx], col = circles[3 * (int64_t)idx + 1];
+      const uint64_t key = nms_key(scores[idx], tie ? tie[idx] : (uint32_t)idx);
       // Same-centre reduction before the rounds: circles with one centre have one ring, so whatever the first of
       // them in suppression order does -- claim the ring, or fail on a cell that is already claimed -- leaves every
       // later one rejected without ever claiming (utils.py:254-292): only that first one enters the rounds.  One
@@ -749,76 +753,58 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
       if (PHASE == 3) atomicMin(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)key);
       else if (PHASE == 4) { if (*cell != key) state[idx] = 2; }
       else *cell = ~0ull;
-    } else if (PHASE == 2) {  // cleanup (after convergence): restore the all-ones grid under every ring
-      for (int j = 0; j < ring_len; ++j) {
-        const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
-        grid[(int64_t)rr * n_cols + cc] = ~0ull;
-      }
-      state[idx] = 0;
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t n_waves = ((int64_t)gridDim.x * NT) >> 6;
+  bool any_undecided = false;
+  for (int64_t a = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6; a < n; a += n_waves) {
+    const int idx = __builtin_amdgcn_readfirstlane(alive[a]);
+    if (PHASE != 2 && state[idx] != 0) continue;
+    const int row = circles[3 * (int64_t)idx], col = circles[3 * (int64_t)idx + 1];
+    const uint32_t tk = tie ? tie[idx] : (uint32_t)idx;
+    const uint64_t key = nms_key(scores[idx], tk);
+    auto cell_of = [&](int j) -> uint64_t* {
+      const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
+      return &grid[(int64_t)rr * n_cols + cc];
+    };
+    if (PHASE == 2) {  // cleanup (after convergence): restore the all-ones grid under every ring
+      for (int j = lane; j < ring_len; j += 64) *cell_of(j) = ~0ull;
+      if (lane == 0) state[idx] = 0;
     } else if (PHASE == 0) {  // claim: every undecided circle bids for its ring pixels
       // a cell that already holds a smaller key cannot be won (cells only ever decrease during the bids):
-      // look first, eight cells at a time, and spare the memory-side atomic for those
-      constexpr int RB = 8;
-      for (int j0 = 0; j0 < ring_len; j0 += RB) {
-        uint64_t* cell[RB];
-        uint64_t cur[RB];
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-          cell[u] = nullptr;
-          cur[u] = 0;
-          if (j0 + u < ring_len) {
-            const int rr = wrap(d_ring_rc[2 * (j0 + u)] + row + pad, n_rows);
-            const int cc = wrap(d_ring_rc[2 * (j0 + u) + 1] + col + pad, n_cols);
-            cell[u] = &grid[(int64_t)rr * n_cols + cc];
-            cur[u] = __builtin_nontemporal_load(cell[u]);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < RB; ++u)
-          if (cell[u] && cur[u] > key) atomicMin(reinterpret_cast<unsigned long long*>(cell[u]), (unsigned long long)key);
+      // look first and spare the memory-side atomic for those
+      for (int j = lane; j < ring_len; j += 64) {
+        uint64_t* cell = cell_of(j);
+        if (__builtin_nontemporal_load(cell) > key) atomicMin(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)key);
       }
     } else {  // decide
-      bool all_mine = true, hit_kept = false;
-      constexpr int RB = 8;  // ring cells loaded together (the loop is a chain of cache misses otherwise)
-      for (int j0 = 0; j0 < ring_len; j0 += RB) {
-        uint64_t g[RB];
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-          g[u] = key;
-          if (j0 + u < ring_len) {
-            const int rr = wrap(d_ring_rc[2 * (j0 + u)] + row + pad, n_rows);
-            const int cc = wrap(d_ring_rc[2 * (j0 + u) + 1] + col + pad, n_cols);
-            g[u] = grid[(int64_t)rr * n_cols + cc];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-          if (g[u] != key) {
-            all_mine = false;
-            if ((g[u] >> 32) == 0) hit_kept = true;  // a kept circle's mark
-          }
+      bool foreign = false, kept = false;
+      for (int j = lane; j < ring_len; j += 64) {
+        const uint64_t g = *cell_of(j);
+        if (g != key) {
+          foreign = true;
+          if ((g >> 32) == 0) kept = true;  // a kept circle's mark
         }
       }
+      const bool all_mine = __ballot(foreign) == 0, hit_kept = __ballot(kept) != 0;
       if (all_mine) {
-        state[idx] = 1;
+        if (lane == 0) state[idx] = 1;
         // mark the ring as kept: (0, tie) is below every real key, so no later bid replaces it
-        for (int j = 0; j < ring_len; ++j) {
-          const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
-          atomicMin(reinterpret_cast<unsigned long long*>(&grid[(int64_t)rr * n_cols + cc]), (unsigned long long)tk);
-        }
+        for (int j = lane; j < ring_len; j += 64)
+          atomicMin(reinterpret_cast<unsigned long long*>(cell_of(j)), (unsigned long long)tk);
       } else if (hit_kept) {
-        state[idx] = 2;
+        if (lane == 0) state[idx] = 2;
         // withdraw this circle's bids so that later circles can win these pixels
-        for (int j = 0; j < ring_len; ++j) {
-          const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
-          atomicCAS(reinterpret_cast<unsigned long long*>(&grid[(int64_t)rr * n_cols + cc]), (unsigned long long)key,
-                    ~0ull);
-        }
+        for (int j = lane; j < ring_len; j += 64)
+          atomicCAS(reinterpret_cast<unsigned long long*>(cell_of(j)), (unsigned long long)key, ~0ull);
       } else {
-        atomicAdd(&d_undecided[plane], 1);
+        any_undecided = true;
       }
     }
   }
+  if (PHASE == 1 && any_undecided && lane == 0 && d_undecided[plane] == 0) d_undecided[plane] = 1;
 }
 
 // ---- K11: collect kept circles in priority order -------------------------------------------------------
@@ -1076,7 +1062,8 @@ extern "C" int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const 
   if (hipMemsetAsync(d_undecided, 0, sizeof(int32_t) * n_planes, s) != hipSuccess) return MG_ELAUNCH;
   // the kernels walk d_alive with a grid-stride loop: max_alive (> 0: the caller's upper bound of
   // d_num_alive) only sizes the grid -- an all-capacity grid of empty blocks costs ~0.1 ms per launch
-  const dim3 g(grid_x(max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap), n_planes);
+  // (one wave per alive circle)
+  const dim3 g(grid_x(64 * (max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap)), n_planes);
   hipLaunchKernelGGL((k_nms<0>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
                      min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided, d_tie_keys);
   MG_CHECK_LAUNCH();
@@ -1115,7 +1102,7 @@ extern "C" int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, cons
     return MG_EINVAL;
   if (n_planes < 0 || n_planes > 65535 || min_dist <= 0 || ring_len <= 0) return MG_EINVAL;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
-  hipLaunchKernelGGL((k_nms<2>), dim3(grid_x(max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap), n_planes),
+  hipLaunchKernelGGL((k_nms<2>), dim3(grid_x(64 * (max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap)), n_planes),
                      dim3(NT), 0, mg_stream(stream), d_circles,
                      circle_cap, d_scores, d_alive, d_num_alive, d_max_rc, min_dist, d_ring_rc, ring_len, d_grid,
                      grid_cap, d_state, (int32_t*)nullptr, (const uint32_t*)nullptr);

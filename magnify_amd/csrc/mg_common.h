@@ -63,9 +63,11 @@ __device__ __forceinline__ double mg_wave_nanmin(double v) {
   return v;
 }
 
+// Look first, with a load that bypasses the (non-coherent) L1: workgroups that finish together would otherwise all
+// see the same stale value and all go through the compare-and-swap, one after the other on one cache line.
 __device__ __forceinline__ void mg_atomic_nanmax(double* addr, double v) {
   unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
-  unsigned long long old = *a;
+  unsigned long long old = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   while (true) {
     double cur = __longlong_as_double((long long)old);
     if (cur != cur) return;                // already NaN
@@ -77,7 +79,7 @@ __device__ __forceinline__ void mg_atomic_nanmax(double* addr, double v) {
 }
 __device__ __forceinline__ void mg_atomic_nanmin(double* addr, double v) {
   unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
-  unsigned long long old = *a;
+  unsigned long long old = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   while (true) {
     double cur = __longlong_as_double((long long)old);
     if (cur != cur) return;

@@ -423,7 +423,12 @@ __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ 
   }
   zeros = (uint32_t)mg_wave_sum_i32((int)zeros);
   uint32_t* out = d_hist + (int64_t)plane * n_bins;
-  if (lane == 0 && zeros) atomicAdd(&out[0], zeros);  // bin 0 goes straight to global memory
+  // bin 0: counted in registers.  With a slot it joins the workgroup's packed counters (<= 3 x 16384 pixels fit 16
+  // bits; one atomic per wave on the plane's one global counter serialised ~1400 deep), else global memory.
+  if (lane == 0 && zeros) {
+    if (slot) atomicAdd(&hist[0], zeros);
+    else atomicAdd(&out[0], zeros);
+  }
   __syncthreads();
   if (slot) {
     for (int i = threadIdx.x; i < n_bins / 2; i += NT) slot[i] = hist[i];
@@ -481,28 +486,30 @@ __global__ __launch_bounds__(NT) void k_edge_thresholds(const uint32_t* __restri
                                                         float gamma_lo, float gamma_hi, int32_t* __restrict__ d_thresh,
                                                         float* __restrict__ d_quantiles, int32_t* __restrict__ d_unresolved) {
   __shared__ int s_bin[4];
+  __shared__ uint32_t s_hist[FINE + COARSE];  // the plane's histogram, staged by coalesced loads (n_bins <= FINE + COARSE)
   const int plane = blockIdx.x;
-  const uint32_t* hist = d_hist + (int64_t)plane * n_bins;
+  const uint32_t* hist_g = d_hist + (int64_t)plane * n_bins;
+  for (int i = threadIdx.x; i < n_bins; i += NT) s_hist[i] = hist_g[i];
+  __syncthreads();
+  const uint32_t* hist = s_hist;
   const int per = (n_bins + NT - 1) / NT;
   const int b0 = threadIdx.x * per, b1 = min(b0 + per, n_bins);
   long long mine = 0;
   for (int b = b0; b < b1; ++b) mine += hist[b];
-  // exclusive prefix of the chunk sums (64-bit: a plane holds up to 2^31 pixels)
+  // exclusive prefix of the chunk sums (64-bit: a plane holds up to 2^31 pixels): Hillis-Steele over the workgroup
   __shared__ long long s_pre[NT];
   s_pre[threadIdx.x] = mine;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    long long run = 0;
-    for (int i = 0; i < NT; ++i) {
-      const long long v = s_pre[i];
-      s_pre[i] = run;
-      run += v;
-    }
+  for (int off = 1; off < NT; off <<= 1) {
+    const long long v = (int)threadIdx.x >= off ? s_pre[threadIdx.x - off] : 0;
+    __syncthreads();
+    s_pre[threadIdx.x] += v;
+    __syncthreads();
   }
   if (threadIdx.x < 4) s_bin[threadIdx.x] = n_bins;  // rank beyond the data: unresolved
   __syncthreads();
   const long long ranks[4] = {r0, r1, r2, r3};
-  long long run = s_pre[threadIdx.x];
+  long long run = s_pre[threadIdx.x] - mine;
   for (int b = b0; b < b1; ++b) {
     const long long nxt = run + hist[b];
 #pragma unroll
@@ -1139,10 +1146,12 @@ extern "C" int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, c
   const dim3 g = tile_grid(h, w, n_planes);
   if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
   hipStream_t s = mg_stream(stream);
+  // w % 32 == 0: every bitmap word inside the image belongs to one lane group, which stores it whole -- nothing to
+  // clear (the spare words behind the image are never written: the caller zeroes the buffers once, when it makes them)
   const size_t bytes = (size_t)n_planes * words_per_plane * 4;
-  if (hipMemsetAsync(d_weak, 0, bytes, s) != hipSuccess || hipMemsetAsync(d_strong, 0, bytes, s) != hipSuccess)
+  if ((w & 31) && (hipMemsetAsync(d_weak, 0, bytes, s) != hipSuccess || hipMemsetAsync(d_strong, 0, bytes, s) != hipSuccess ||
+                   (d_class && hipMemsetAsync(d_class, 0, 3 * bytes, s) != hipSuccess)))
     return MG_ELAUNCH;
-  if (d_class && (w & 31) && hipMemsetAsync(d_class, 0, 3 * bytes, s) != hipSuccess) return MG_ELAUNCH;
   hipLaunchKernelGGL(k_canny_nms, g, dim3(NT), 0, s, d_blur, h, w, d_thresh, words_per_plane, d_weak, d_strong,
                      d_class);
   MG_CHECK_LAUNCH();

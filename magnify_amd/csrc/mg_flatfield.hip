@@ -360,12 +360,15 @@ __global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tile
 #pragma unroll
   for (int b = 0; b < PB; ++b) vmin[b] = INFINITY, vmax[b] = -INFINITY, imin[b] = 0xFFFFFFFFu, imax[b] = 0u;
   const int64_t tile_elems = (int64_t)ty * tx;
-  const int row_end = min((int)(blockIdx.y + 1) * rows_per_block, h_out);
-  if (ox0 < w_out) {
+  // a workgroup takes the row groups blockIdx.y, blockIdx.y + gridDim.y, ...: one set of min/max atomics per
+  // workgroup however short the row groups are
+  if (ox0 < w_out)
+  for (int yg = blockIdx.y; yg * rows_per_block < h_out; yg += gridDim.y) {
+    const int row_end = min((yg + 1) * rows_per_block, h_out);
     const int tc0 = ox0 / hx;
     const int x0 = ox0 - tc0 * hx + clip;
     const bool one_tile = (ox0 + N <= w_out) && (x0 - clip + N <= hx);
-    for (int oy = blockIdx.y * rows_per_block; oy < row_end; ++oy) {
+    for (int oy = yg * rows_per_block; oy < row_end; ++oy) {
       const int tr = oy / hy;
       const int y = oy - tr * hy + clip;
       int64_t pix[N], toff[N];  // pixel index inside the tile, element offset of the tile in a plane
@@ -483,11 +486,12 @@ __global__ __launch_bounds__(256) void k_apply_stitch_aligned(const T* __restric
 #pragma unroll
   for (int b = 0; b < PB; ++b) imin[b] = 0xFFFFFFFFu, imax[b] = 0u;
   const int64_t tile_elems = (int64_t)ty * tx, plane_elems = (int64_t)n_tr * n_tc * tile_elems;
-  const int row_end = min((int)(blockIdx.y + 1) * rows_per_block, h_out);
-  if (ox0 < w_out) {
+  if (ox0 < w_out)
+  for (int yg = blockIdx.y; yg * rows_per_block < h_out; yg += gridDim.y) {  // (as in k_apply_stitch)
+    const int row_end = min((yg + 1) * rows_per_block, h_out);
     const int tc0 = ox0 / hx;
     const int x0 = ox0 - tc0 * hx + clip;
-    for (int oy = blockIdx.y * rows_per_block; oy < row_end; ++oy) {
+    for (int oy = yg * rows_per_block; oy < row_end; ++oy) {
       const int tr = oy / hy;
       const int64_t p0 = (int64_t)(oy - tr * hy + clip) * tx + x0;
       const int64_t src0 = ((int64_t)tr * n_tc + tc0) * tile_elems + p0;
@@ -616,13 +620,14 @@ int launch_max(const void* d_tiles, int64_t tiles_per_group, int n_groups, int64
                hipStream_t s) {
   if (tiles_per_group == 0 || n_groups == 0 || tile_elems == 0) return MG_OK;
   const int64_t nvec = tile_elems / VecOf<T>::N + 1;
-  const int per_group = std::max(1, 4096 / n_groups);
+  const int per_group = std::min(256, std::max(1, 4096 / n_groups));
   int blocks = (int)std::min<int64_t>((nvec + 255) / 256, per_group);
   const int64_t group_elems = tiles_per_group * tile_elems;
   if (IsIntegral<T>::value && !d_dark && !d_flat && flat > 0.0 && flat < 1e300 && fabs(dark) < 1e300 &&
       (reinterpret_cast<uintptr_t>(d_tiles) & 15) == 0 && (group_elems * (int64_t)sizeof(T)) % 16 == 0) {
     const int64_t gvec = group_elems / VecOf<T>::N;
-    const int gb = (int)std::max<int64_t>(1, std::min<int64_t>(gvec / 256, std::max(1, 2048 / n_groups)));
+    // (every workgroup ends with two compare-and-swap maxima on the group's cache line: few, long-running workgroups)
+    const int gb = (int)std::max<int64_t>(1, std::min<int64_t>(gvec / 256, std::min(256, std::max(64, 2048 / n_groups))));
     hipLaunchKernelGGL((k_flatfield_max_int<T>), dim3(gb, n_groups), dim3(256), 0, s, (const T*)d_tiles, group_elems, dark,
                        flat, d_max2);
     MG_CHECK_LAUNCH();
@@ -656,7 +661,11 @@ int launch_apply(const void* d_tiles, int64_t n_planes, int n_tr, int n_tc, int 
   int rows = ROWS_PER_BLOCK;
   const int64_t cols_planes = (int64_t)((w_out + 256 * N - 1) / (256 * N)) * ((n_planes + PLANES_PER_BLOCK - 1) / PLANES_PER_BLOCK);
   while (rows > 2 && cols_planes * ((h_out + rows - 1) / rows) < 2048) rows /= 2;
-  dim3 grid((w_out + 256 * N - 1) / (256 * N), (h_out + rows - 1) / rows,
+  // ... and at most ~1024 workgroups per plane group walk them (each ends with min/max atomics on the plane's one
+  // cache line: 2048 workgroups finishing together took 100 us over them)
+  int y_blocks = (h_out + rows - 1) / rows;
+  if (rows < ROWS_PER_BLOCK) y_blocks = (int)std::min<int64_t>(y_blocks, std::max<int64_t>(1, 1024 / std::max<int64_t>(1, cols_planes)));
+  dim3 grid((w_out + 256 * N - 1) / (256 * N), y_blocks,
             (unsigned)((n_planes + PLANES_PER_BLOCK - 1) / PLANES_PER_BLOCK));
   if (grid.y > 65535 || grid.z > 65535) return MG_EINVAL;
   const bool aligned = IsIntegral<T>::value && hx % N == 0 && tx % N == 0 && clip % N == 0 &&

@@ -108,7 +108,11 @@ __device__ __forceinline__ int score_r(const uint8_t* lds, int vaddr, const uint
 
 // ---- prefilter ----------------------------------------------------------------------------------------
 // LDS: [0, WBASE) small tables, [WBASE, +side_y * WSTR) the window.
-static_assert((NSUB * SEGW + SEGW + 32 + 8) * 4 <= WBASE, "small tables");
+// Survivors are collected per super-tile in LDS and appended to the plane's list with ONE global atomic: a returning
+// atomic per wave-with-survivors (~9 000 per plane, all on one address, while only one or two planes are being
+// worked on at any time) cost as much as the perimeter walks of a single plane.
+constexpr int SURV_OFF = 2048, SURV_LDS = (WBASE - SURV_OFF) / 8;
+static_assert((NSUB * SEGW + SEGW + 32 + 8) * 4 <= SURV_OFF, "small tables");
 
 // bits 0..3 of x -> bit 0 of bytes 0..3
 __device__ __forceinline__ uint32_t spread4(uint32_t x) { return ((x & 0xFu) * 0x00204081u) & 0x01010101u; }
@@ -128,6 +132,9 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
   int32_t* chunk0 = seg + NSUB * SEGW;             // [nr + 1]: first chunk of radius rho
   int32_t* need = chunk0 + SEGW;                   // [nr]: threshold on the sum of bounds (1/64)
   int32_t* next = need + 32;                       // the block's chunk counter
+  int32_t* n_held = next + 1;                      // survivors of this super-tile held in LDS (may count past SURV_LDS)
+  int32_t* g_base = next + 2;                      // where they go in the plane's list
+  int2* held = reinterpret_cast<int2*>(lds + SURV_OFF);  // [SURV_LDS] (index in the key list, key)
   uint8_t* win = lds + WBASE;
   const int side_y = STY + 2 * max_r, side_x = STX + 2 * max_r;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
       if (tr < ntr && tc < ntc) v = d_layer_starts[((int64_t)plane * n_tiles + tr * ntc + tc) * (nr + 1) + q];
       seg[s * SEGW + q] = v;  // a sub-tile beyond the grid: all zero = empty
     }
-    if (threadIdx.x == 0) *next = 0;
+    if (threadIdx.x == 0) *next = 0, *n_held = 0;
     // ---- the window: orientation bin of every edge pixel, 0x0C elsewhere.  All loads of a thread's (at most
     // WI) 32-pixel groups are issued before the first is used: the block would otherwise wait for two to four
     // global round trips per group, one after the other ----
@@ -267,14 +274,32 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
       const bool pass = valid && sum >= need[rho];
       if (write_skipped && valid && !pass) d_scores[(int64_t)plane * circle_cap + i] = MG_SCORE_SKIPPED;
       const uint64_t pm = __ballot(pass);
-      if (pm) {  // rare: append the survivors to the plane's list
-        int sbase = 0;
-        if (lane == 0) sbase = atomicAdd(&d_num_surv[plane], __builtin_popcountll(pm));
-        sbase = __builtin_amdgcn_readfirstlane(sbase);
-        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-        if (pass && (int64_t)sbase + rank < surv_cap)
-          reinterpret_cast<int2*>(d_surv)[(int64_t)plane * surv_cap + sbase + rank] = make_int2((int32_t)i, (int32_t)key);
+      if (pm) {  // rare: hold the survivors in LDS until the super-tile is done
+        int hbase = 0;
+        if (lane == 0) hbase = atomicAdd(n_held, __builtin_popcountll(pm));
+        hbase = __builtin_amdgcn_readfirstlane(hbase);
+        const int slot = hbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+        if (pass && slot < SURV_LDS) held[slot] = make_int2((int32_t)i, (int32_t)key);
+        const uint64_t om = __ballot(pass && slot >= SURV_LDS);
+        if (om) {  // LDS full (hundreds of survivors in one super-tile): straight to the plane's list
+          int sbase = 0;
+          if (lane == 0) sbase = atomicAdd(&d_num_surv[plane], __builtin_popcountll(om));
+          sbase = __builtin_amdgcn_readfirstlane(sbase);
+          const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
+          if (pass && slot >= SURV_LDS && (int64_t)sbase + rank < surv_cap)
+            reinterpret_cast<int2*>(d_surv)[(int64_t)plane * surv_cap + sbase + rank] = make_int2((int32_t)i, (int32_t)key);
+        }
       }
+    }
+    // ---- the super-tile's survivors -> the plane's list ----
+    __syncthreads();
+    const int n_out = min(*n_held, SURV_LDS);  // block-uniform
+    if (n_out > 0) {
+      if (threadIdx.x == 0) *g_base = atomicAdd(&d_num_surv[plane], n_out);
+      __syncthreads();
+      const int64_t gb = *g_base;
+      for (int k = threadIdx.x; k < n_out; k += NP)
+        if (gb + k < surv_cap) reinterpret_cast<int2*>(d_surv)[(int64_t)plane * surv_cap + gb + k] = held[k];
     }
   }
 }

@@ -78,17 +78,29 @@ class BeadFinder:
                                     else list(range(n_c)))
         beads = np.empty((0, 3), dtype=np.int32)
         finder = _finder(1, h, w, self.min_bead_radius, self.max_bead_radius, self.num_iter, image.device)
-        for channel in self.search_channels:
-            ch = _channel_index(assay, channel)
-            res, _ = finder.find(image[ch, 0:1], _plane_minmax(assay, image, (ch, 0)), self.low_edge_quantile,
-                                 self.high_edge_quantile, self.min_roundness, self.min_bead_radius,
-                                 [utils.next_seed()])
-            b = dedup_against(beads, res[0][0], 2 * self.min_bead_radius)  # find.py:490-500
-            beads = np.concatenate([beads, b])
-        m, L = len(beads), self.roi_length
-        # masks straight from the bead table (what utils.circle_labels + the == i / == -1 tests yield,
-        # find.py:561-586) -- no label map is written or read
-        out = hotpath.roi_gather_reduce(image[None], [beads], L, None, disks=True)
+        m, L = None, self.roi_length
+        if len(self.search_channels) == 1:
+            # one search channel (nothing to de-duplicate across channels, find.py:490-500): the ROI pass reads the
+            # bead table where the suppression left it on the device; the host copy of the table runs beside it
+            ch = _channel_index(assay, self.search_channels[0])
+            counts, (d_out, d_scores, _) = finder.find(
+                image[ch, 0:1], _plane_minmax(assay, image, (ch, 0)), self.low_edge_quantile, self.high_edge_quantile,
+                self.min_roundness, self.min_bead_radius, [utils.next_seed()], host_results=False)
+            out = hotpath.roi_gather_reduce(image[None], None, L, None, disks=True,
+                                            device_tables=(d_out, counts, self.max_bead_radius))
+            beads = finder.fetch_results(counts, d_out, d_scores, overlap=True)[0][0]
+        else:
+            for channel in self.search_channels:
+                ch = _channel_index(assay, channel)
+                res, _ = finder.find(image[ch, 0:1], _plane_minmax(assay, image, (ch, 0)), self.low_edge_quantile,
+                                     self.high_edge_quantile, self.min_roundness, self.min_bead_radius,
+                                     [utils.next_seed()])
+                b = dedup_against(beads, res[0][0], 2 * self.min_bead_radius)  # find.py:490-500
+                beads = np.concatenate([beads, b])
+            # masks straight from the bead table (what utils.circle_labels + the == i / == -1 tests yield,
+            # find.py:561-586) -- no label map is written or read
+            out = hotpath.roi_gather_reduce(image[None], [beads], L, None, disks=True)
+        m = len(beads)
         # the kernel writes 0 / 1 bytes: reinterpreted as bool, not converted (two passes over M L^2 bytes less)
         fg = out["fg"].view(torch.bool)[:, None].expand(m, n_t, L, L)  # geometry replicated over time (find.py:585-586)
         bg = out["bg"].view(torch.bool)[:, None].expand(m, n_t, L, L)

@@ -309,6 +309,7 @@ class CircleFinder:
         # at the one host round trip at the end.  MG_CHECKED_CHAIN=1 keeps the three-round-trip chain.
         self.optimistic = not os.environ.get("MG_CHECKED_CHAIN")
         self._recent_sweeps, self._recent_rounds = [], []
+        self.calls = {"optimistic": 0, "repaired": 0, "checked": 0}  # how the calls of this finder went (find)
         self._out_sets, self._out_turn, self._out_cap = [None, None], 0, 0
         self.words = 2 * ((h * w + 63) // 64) + 2  # bitmap words per plane (even, one spare)
         self.edge_bits = torch.zeros((P, self.words), dtype=i32, device=dev)  # strong bits = edges
@@ -353,6 +354,7 @@ class CircleFinder:
             self.surv_list = torch.empty((P, self.cap, 2), dtype=i32, device=dev)  # (list index, key) per survivor
         self.nms_grid = None
         self.seeds = torch.zeros((P,), dtype=torch.int64, device=dev)
+        self.seeds_host = torch.zeros((P,), dtype=torch.int64).pin_memory()
         self.raw = None
         self.stats = {}
 
@@ -570,8 +572,8 @@ class CircleFinder:
     def circle_stage(self, seeds, min_roundness: float, keep_raw=False, dedup_centres=False, counters_clear=False):
         """``counters_clear``: the caller has just cleared the whole status block (find's optimistic chain)."""
         L, P, h, w, s = nat.lib(), self.P, self.h, self.w, _stream()
-        seeds = np.asarray(seeds, dtype=np.uint64).reshape(P)
-        self.seeds.copy_(torch.from_numpy(seeds.view(np.int64)))
+        self.seeds_host.numpy()[:] = np.asarray(seeds, dtype=np.uint64).reshape(P).view(np.int64)
+        self.seeds.copy_(self.seeds_host, non_blocking=True)  # pinned: queued on the stream, the host does not wait
         self.raw = torch.empty((P, self.num_iter, 3), dtype=torch.float32, device=self.dev) if keep_raw else None
         if self.keyed:
             _call("mg_candidate_keys", self.coords.data_ptr(), self.coord_cap, self.cell_starts.data_ptr(),
@@ -763,11 +765,13 @@ class CircleFinder:
                 out, out_scores, num_out = self._nms_finish(min_dist, bufs, rounds, max_alive, st)
             else:
                 # the edges were not final (or did not fit): restore the claim grid the rounds wrote into, then redo
+                self.calls["repaired"] += 1
                 if rounds:
                     self._nms_cleanup(min_dist, bufs[0].shape[1])
                 if int(st[1].max()) > self.coords.shape[1]:
                     self.coords = None  # sized again from the counts
                 opt = False
+        self.calls["optimistic" if opt else "checked"] += 1
         if not opt:
             n_edges = self.edge_stage(planes, minmax, low_q, high_q, keep_u8=keep_u8, passthrough_u8=passthrough_u8)
             # with suppression to follow, passing circles that share a centre are reduced to their first
