@@ -347,7 +347,8 @@ int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, const float* d_
 
 /* Gather the kept circles in priority order (utils.py:195-199 output order):
  * d_out[n_planes][out_cap][3] int32 (row, col, r), d_out_scores, d_num_out[n_planes].
- * keep_all != 0 skips the state test (min_dist == 0: no suppression, utils.py:197). */
+ * keep_all != 0 skips the state test (min_dist == 0: no suppression, utils.py:197).
+ * d_scratch: int32[n_planes][3 * out_cap] work space (the kept circles' indices and 64-bit priority keys). */
 int mg_collect_circles(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
                        const int32_t* d_num_alive, const uint8_t* d_state, int keep_all, int n_planes,
                        int32_t* d_out, float* d_out_scores, int64_t out_cap, int32_t* d_num_out,

@@ -811,49 +811,53 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
 __global__ __launch_bounds__(NT) void k_collect_list(const int32_t* __restrict__ d_alive,
                                                      const int32_t* __restrict__ d_num_alive,
                                                      const uint8_t* __restrict__ d_state, int keep_all,
-                                                     int64_t circle_cap, int64_t out_cap,
+                                                     int64_t circle_cap, int64_t out_cap, const float* __restrict__ d_scores,
+                                                     const uint32_t* __restrict__ d_tie,
                                                      int32_t* __restrict__ d_scratch, int32_t* __restrict__ d_num_out) {
   const int plane = blockIdx.y;
   const int n = d_num_alive[plane];
+  int32_t* list = d_scratch + (int64_t)plane * 3 * out_cap;  // [out_cap] indices, then [out_cap][2] keys (lo, hi)
   for (int64_t a = (int64_t)blockIdx.x * NT + threadIdx.x; a < n; a += (int64_t)gridDim.x * NT) {
     const int idx = d_alive[(int64_t)plane * circle_cap + a];
     if (keep_all || d_state[(int64_t)plane * circle_cap + idx] == 1) {
       const int k = atomicAdd(&d_num_out[plane], 1);
-      if (k < out_cap) d_scratch[(int64_t)plane * out_cap + k] = idx;
+      if (k < out_cap) {
+        const uint64_t key = nms_key(d_scores[(int64_t)plane * circle_cap + idx],
+                                     d_tie ? d_tie[(int64_t)plane * circle_cap + idx] : (uint32_t)idx);
+        list[k] = idx;
+        list[out_cap + 2 * (int64_t)k] = (int32_t)(uint32_t)key;
+        list[out_cap + 2 * (int64_t)k + 1] = (int32_t)(uint32_t)(key >> 32);
+      }
     }
   }
 }
 
 // Rank of every kept circle in the (score desc, index asc) order = number of kept circles with a
-// smaller key; the keys are staged through LDS in chunks so that the m comparisons per circle are
-// LDS broadcasts instead of dependent global gathers.
+// smaller key; the keys (written next to the list by k_collect_list) are staged through LDS in chunks so that
+// the m comparisons per circle are LDS broadcasts.
 constexpr int RANK_CHUNK = 2048;
 
 __global__ __launch_bounds__(NT) void k_collect_rank(const int32_t* __restrict__ d_circles, int64_t circle_cap,
                                                      const float* __restrict__ d_scores,
                                                      const int32_t* __restrict__ d_scratch,
                                                      int32_t* __restrict__ d_num_out, int64_t out_cap,
-                                                     int32_t* __restrict__ d_out, float* __restrict__ d_out_scores,
-                                                     const uint32_t* __restrict__ d_tie) {
+                                                     int32_t* __restrict__ d_out, float* __restrict__ d_out_scores) {
   __shared__ __attribute__((aligned(16))) uint64_t keys[RANK_CHUNK];
   const int plane = blockIdx.y;
   const int m = (int)min((int64_t)d_num_out[plane], out_cap);
-  const int32_t* list = d_scratch + (int64_t)plane * out_cap;
+  const int32_t* list = d_scratch + (int64_t)plane * 3 * out_cap;
+  const uint32_t* kw = reinterpret_cast<const uint32_t*>(list + out_cap);
   const float* scores = d_scores + (int64_t)plane * circle_cap;
-  const uint32_t* tie = d_tie ? d_tie + (int64_t)plane * circle_cap : nullptr;
   // block-uniform trip count: every thread takes part in the staging barriers
   for (int64_t a0 = (int64_t)blockIdx.x * NT; a0 < m; a0 += (int64_t)gridDim.x * NT) {
     const int64_t a = a0 + threadIdx.x;
     const int idx = a < m ? list[a] : 0;
-    const uint64_t key = a < m ? nms_key(scores[idx], tie ? tie[idx] : (uint32_t)idx) : 0;
+    const uint64_t key = a < m ? (((uint64_t)kw[2 * a + 1] << 32) | kw[2 * a]) : 0;
     int rank = 0;
     for (int c0 = 0; c0 < m; c0 += RANK_CHUNK) {
       const int cn = min(RANK_CHUNK, m - c0);
       __syncthreads();
-      for (int b = threadIdx.x; b < cn; b += NT) {
-        const int j = list[c0 + b];
-        keys[b] = nms_key(scores[j], tie ? tie[j] : (uint32_t)j);
-      }
+      for (int b = threadIdx.x; b < cn; b += NT) keys[b] = ((uint64_t)kw[2 * (int64_t)(c0 + b) + 1] << 32) | kw[2 * (int64_t)(c0 + b)];
       __syncthreads();
       // two keys per 128-bit LDS broadcast read, eight keys per trip: the reads of a trip are in flight together
       // (one dependent 64-bit read per key made this loop a chain of LDS latencies: 111 us for 2000 circles)
@@ -1124,10 +1128,10 @@ extern "C" int mg_collect_circles(const int32_t* d_circles, int64_t circle_cap, 
   // out_cap bounds the alive counts in practice; the grid-stride loop covers the rest otherwise
   hipLaunchKernelGGL(k_collect_list, dim3(grid_x(std::min(circle_cap, std::max<int64_t>(out_cap, NT))), n_planes),
                      dim3(NT), 0, s, d_alive, d_num_alive, d_state,
-                     keep_all, circle_cap, out_cap, d_scratch, d_num_out);
+                     keep_all, circle_cap, out_cap, d_scores, d_tie_keys, d_scratch, d_num_out);
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_collect_rank, dim3(grid_x(out_cap), n_planes), dim3(NT), 0, s, d_circles, circle_cap, d_scores,
-                     d_scratch, d_num_out, out_cap, d_out, d_out_scores, d_tie_keys);
+                     d_scratch, d_num_out, out_cap, d_out, d_out_scores);
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_clamp_counts, dim3((n_planes + 255) / 256), dim3(256), 0, s, d_num_out, n_planes, out_cap);
   MG_CHECK_LAUNCH();

@@ -313,10 +313,13 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
 //   3. all lanes evaluate (survivor, hit) pairs: the next `ch` hits of every survivor that is still undecided --
 //      angle on demand from the blurred image, term in float64 -- `ch` grows as the undecided get fewer;
 //   4. a lane per survivor adds its terms in order with the early exit, and the undecided are listed again.
-constexpr int XS = 64;       // survivors per workgroup and round
+// XS survivors per workgroup and round: 64 at large batches; 16 at small ones, where the survivors of a plane would
+// otherwise sit in ~150 workgroups whose phases are chains of latencies (NT / XS lanes per survivor in phase 1,
+// more hits per step in phase 3).
 constexpr int XCH_MAX = 32;  // hits per survivor evaluated per step, at most
 constexpr int XPMAX = 2 * MAXP;
 
+template <int XS>
 __global__ __launch_bounds__(NT) void k_exact(const uint8_t* __restrict__ d_blur, const float* __restrict__ d_angle,
                                               const uint32_t* __restrict__ d_bits, int64_t words_per_plane, int h, int w,
                                               int32_t* __restrict__ d_circles, int64_t circle_cap, int ntc, int min_r,
@@ -373,16 +376,17 @@ __global__ __launch_bounds__(NT) void k_exact(const uint8_t* __restrict__ d_blur
     }
     for (int i = t; i < XS * (XPMAX / 32); i += NT) (&s_mask[0][0])[i] = 0u;
     __syncthreads();
-    // 1. hit masks: four lanes per survivor, four loads in flight per lane
+    // 1. hit masks: NT / XS lanes per survivor, four loads in flight per lane
     {
-      const int s = t >> 2, j0 = t & 3;
+      constexpr int LPS = NT / XS;
+      const int s = t / LPS, j0 = t % LPS;
       const int row = s_row[s], col = s_col[s], p0 = s_p0[s], len = s_p1[s] - p0;
-      for (int j = j0; j < len; j += 16) {
+      for (int j = j0; j < len; j += 4 * LPS) {
         uint32_t wv[4];
         int bi[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int jj = j + 4 * u;
+          const int jj = j + LPS * u;
           const int v = tab[p0 + min(jj, len - 1)];
           const int y = row + (v >> 16), x = col + (int)(int16_t)(v & 0xFFFF);
           const bool inb = jj < len && y >= 0 && y < h && x >= 0 && x < w;
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(NT) void k_exact(const uint8_t* __restrict__ d_blur
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int jj = j + 4 * u;
+          const int jj = j + LPS * u;
           if (bi[u] >= 0 && ((wv[u] >> (bi[u] & 31)) & 1u)) atomicOr(&s_mask[s][jj >> 5], 1u << (jj & 31));
         }
       }
@@ -528,8 +532,14 @@ extern "C" int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angl
   MG_CHECK_LAUNCH();
   // blocks per plane: enough to fill the chip at any batch size, few enough to amortise the table load
   const int xblocks = std::max(16, std::min(256, 4096 / std::max(n_planes, 1)));
-  hipLaunchKernelGGL(k_exact, dim3(xblocks, n_planes), dim3(NT), (size_t)per_total * 4, s, d_blur, d_angle, d_edge_bits,
-                       words_per_plane, h, w, d_circles, circle_cap, ntc, min_r, max_r, d_per_rc, per_total,
+  if (n_planes <= 4)
+    hipLaunchKernelGGL(k_exact<16>, dim3(4 * xblocks, n_planes), dim3(NT), (size_t)per_total * 4, s, d_blur, d_angle,
+                       d_edge_bits, words_per_plane, h, w, d_circles, circle_cap, ntc, min_r, max_r, d_per_rc, per_total,
+                       d_per_expected, d_per_starts, min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc,
+                       d_num_scored, d_surv_list, surv_cap, d_num_surv);
+  else
+    hipLaunchKernelGGL(k_exact<64>, dim3(xblocks, n_planes), dim3(NT), (size_t)per_total * 4, s, d_blur, d_angle,
+                       d_edge_bits, words_per_plane, h, w, d_circles, circle_cap, ntc, min_r, max_r, d_per_rc, per_total,
                        d_per_expected, d_per_starts, min_roundness, write_skipped, d_scores, d_alive, d_num_alive, d_max_rc,
                        d_num_scored, d_surv_list, surv_cap, d_num_surv);
   MG_CHECK_LAUNCH();

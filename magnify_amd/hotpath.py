@@ -24,7 +24,9 @@ def _ptr(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current stream on the current device (the short way: ``torch.cuda.current_stream()``
+    builds a Stream object, several microseconds per C-ABI call)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 class StageTimer:
@@ -79,11 +81,19 @@ TIMER = _NoTimer()
 def set_timer(timer):
     """Install a StageTimer (or None) used by every hot-path call."""
     global TIMER
-    TIMER = timer if timer is not None else _NoTimer()
+    TIMER = timer if timer is not None else _NO_TIMER
+
+
+_NO_TIMER = TIMER
 
 
 def _call(name, *args, stage=None):
     """One C-ABI call: timed (if a StageTimer is installed) and status-checked."""
+    if TIMER is _NO_TIMER:
+        rc = getattr(nat.lib(), name)(*args)
+        if rc:
+            nat.check(rc, name)
+        return
     with TIMER.stage(stage or name):
         nat.check(getattr(nat.lib(), name)(*args), name)
 
@@ -633,7 +643,7 @@ class CircleFinder:
             P, cap = self.P, self._out_cap
             self._out_sets[self._out_turn] = (torch.empty((P, cap, 3), dtype=torch.int32, device=self.dev),
                                               torch.empty((P, cap), dtype=torch.float32, device=self.dev),
-                                              torch.empty((P, cap), dtype=torch.int32, device=self.dev))
+                                              torch.empty((P, 3 * cap), dtype=torch.int32, device=self.dev))
         return self._out_sets[self._out_turn]
 
     def _collect(self, bufs, min_dist):
@@ -881,6 +891,23 @@ def release_labels(labels):
     _LABEL_POOL[key] = labels
 
 
+_STAGING = {}
+
+
+def _upload_i32(values, device):
+    """A small int32 table on the device through pinned staging (queued on the stream: a pageable source makes
+    the copy synchronous).  Three staging buffers per length are used in turn; a caller synchronises with the
+    device at least once per hot-path step, long before a buffer comes round again."""
+    n = len(values)
+    ring = _STAGING.get((n, str(device)))
+    if ring is None:
+        ring = _STAGING[(n, str(device))] = [[torch.empty((n,), dtype=torch.int32).pin_memory() for _ in range(3)], 0]
+    ring[1] = (ring[1] + 1) % 3
+    host = ring[0][ring[1]]
+    host.numpy()[:] = values
+    return host.to(device, non_blocking=True)
+
+
 def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, labels: torch.Tensor | None,
                       want_roi=True, want_masks=True, want_sums=True, reuse_buffers=False, disks=False,
                       device_tables=None, time_major=False):
@@ -924,7 +951,7 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         assert disks and d_tab.dtype == torch.int32 and d_tab.is_contiguous() and d_tab.shape[0] == a
         max_r = max(int(max_r), 2)
         tab = _halfwidth_table(max_r, dev)
-        d_off = torch.from_numpy(offsets.astype(np.int32)).to(dev, non_blocking=True)
+        d_off = _upload_i32(offsets, dev)
         _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
               int(time_major), d_tab.data_ptr(), d_tab.shape[1], d_off.data_ptr(), a, int(max(sizes)), m, L, tab.data_ptr(), max_r,
               _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())

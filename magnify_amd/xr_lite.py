@@ -205,7 +205,8 @@ class DataArray:
             if isinstance(k, (int, np.integer)):
                 out = out.select(axis, int(k)) if _is_tensor(out) else np.take(out, int(k), axis=axis)
             elif isinstance(k, slice):
-                out = out[(slice(None),) * axis + (k,)]
+                if k != slice(None):  # (a full slice is the array itself: no indexing call)
+                    out = out[(slice(None),) * axis + (k,)]
                 dims.append(d)
                 axis += 1
             else:
