@@ -155,7 +155,7 @@ int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_
 
 /* One sweep of 8-connected hysteresis, bit-parallel on the bitmaps: every 256 x 64 tile grows its
  * strong set into its weak set to a fixed point in LDS (halo from global memory) and ORs the new
- * bits into d_strong.  d_changed[n_planes] is incremented for planes that changed; call until a
+ * bits into d_strong.  d_changed[n_planes] becomes non-zero for planes that changed; call until a
  * sweep leaves it at zero: d_strong is then the edge map of utils.py:142.  Active-tile tracking:
  * d_flags_in / d_flags_out are uint8[n_planes][tiles_y][tiles_x] (mg_hysteresis_tiles); a tile is
  * skipped unless it or one of its 8 neighbours set its flag in the previous sweep; d_flags_out

@@ -834,7 +834,9 @@ __global__ __launch_bounds__(NT) void k_hysteresis(const uint32_t* __restrict__ 
     }
   }
   if (__syncthreads_or(wrote) && threadIdx.x == 0) {
-    atomicAdd(&d_changed[plane], 1u);
+    // a flag, not a count: a thousand tiles of a plane change in the first sweep and their atomics would queue on
+    // the plane's one counter (the look goes to L2: a stale L1 line would only cost a redundant store)
+    if (__hip_atomic_load(&d_changed[plane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) d_changed[plane] = 1u;
     if (d_flags_out) d_flags_out[(int64_t)plane * ntx * nty + blockIdx.y * ntx + blockIdx.x] = 1;
   }
 }

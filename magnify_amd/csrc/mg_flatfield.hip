@@ -264,20 +264,28 @@ __global__ __launch_bounds__(256) void k_flatfield_max_fast(const T* __restrict_
 #pragma unroll
     for (int j = 0; j < N; ++j) rc[j] = __builtin_amdgcn_rcpf(fl[j]);
     any = true;
-    for (int64_t g = 0; g < tiles_per_group; ++g) {
-      T x[N];
-      load_vec<T, N>(tiles + g * tile_elems + v * N, x);
+    // four tiles (channels) of the group per trip: their loads are issued together -- behind the data-dependent
+    // test below the compiler keeps them one round trip apart
+    for (int64_t g0 = 0; g0 < tiles_per_group; g0 += 4) {
+      T x4[4][N];
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
-        const uint32_t xi = (uint32_t)x[j];
-        xmax = max(xmax, xi);
-        const float t_f = fmaxf((float)xi - dk_f, 0.0f);
-        const bool in_range = fl[j] > 1e-30f && fl[j] < 1e30f;
-        if (in_range && t_f * rc[j] <= thr) continue;  // provably below the running maximum
-        double t = (double)xi - dark;
-        t = t < 0.0 ? 0.0 : t;
-        m2 = mg_nanmax(m2, t / (double)fl[j]);
-        thr = (m2 == m2 && m2 < 1e30) ? (float)m2 * (1.0f - 1e-5f) : -INFINITY;
+      for (int q = 0; q < 4; ++q)
+        if (g0 + q < tiles_per_group) load_vec<T, N>(tiles + (g0 + q) * tile_elems + v * N, x4[q]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (g0 + q >= tiles_per_group) break;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const uint32_t xi = (uint32_t)x4[q][j];
+          xmax = max(xmax, xi);
+          const float t_f = fmaxf((float)xi - dk_f, 0.0f);
+          const bool in_range = fl[j] > 1e-30f && fl[j] < 1e30f;
+          if (in_range && t_f * rc[j] <= thr) continue;  // provably below the running maximum
+          double t = (double)xi - dark;
+          t = t < 0.0 ? 0.0 : t;
+          m2 = mg_nanmax(m2, t / (double)fl[j]);
+          thr = (m2 == m2 && m2 < 1e30) ? (float)m2 * (1.0f - 1e-5f) : -INFINITY;
+        }
       }
     }
   }

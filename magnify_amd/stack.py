@@ -11,6 +11,8 @@ The time axis is the unit of sharding across GPUs (``magnify_amd.distributed``).
 """
 from __future__ import annotations
 
+import os
+
 import math
 
 import numpy as np
