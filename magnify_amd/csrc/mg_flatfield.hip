@@ -628,14 +628,14 @@ int launch_max(const void* d_tiles, int64_t tiles_per_group, int n_groups, int64
                hipStream_t s) {
   if (tiles_per_group == 0 || n_groups == 0 || tile_elems == 0) return MG_OK;
   const int64_t nvec = tile_elems / VecOf<T>::N + 1;
-  const int per_group = std::min(256, std::max(1, 4096 / n_groups));
+  const int per_group = std::min(512, std::max(1, 4096 / n_groups));
   int blocks = (int)std::min<int64_t>((nvec + 255) / 256, per_group);
   const int64_t group_elems = tiles_per_group * tile_elems;
   if (IsIntegral<T>::value && !d_dark && !d_flat && flat > 0.0 && flat < 1e300 && fabs(dark) < 1e300 &&
       (reinterpret_cast<uintptr_t>(d_tiles) & 15) == 0 && (group_elems * (int64_t)sizeof(T)) % 16 == 0) {
     const int64_t gvec = group_elems / VecOf<T>::N;
     // (every workgroup ends with two compare-and-swap maxima on the group's cache line: few, long-running workgroups)
-    const int gb = (int)std::max<int64_t>(1, std::min<int64_t>(gvec / 256, std::min(256, std::max(64, 2048 / n_groups))));
+    const int gb = (int)std::max<int64_t>(1, std::min<int64_t>(gvec / 256, std::min(512, std::max(64, 2048 / n_groups))));
     hipLaunchKernelGGL((k_flatfield_max_int<T>), dim3(gb, n_groups), dim3(256), 0, s, (const T*)d_tiles, group_elems, dark,
                        flat, d_max2);
     MG_CHECK_LAUNCH();

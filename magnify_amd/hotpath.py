@@ -376,10 +376,10 @@ class CircleFinder:
         return self.status_host.numpy()
 
     @staticmethod
-    def _hint(recent, floor):
-        """Launches to issue before the host looks: one more than the most any of the last calls needed (a sweep /
+    def _hint(recent, floor, spare=1):
+        """Launches to issue before the host looks: the most any of the last calls needed plus ``spare`` (a sweep /
         round after convergence costs a flag test), at least `floor`."""
-        return max(floor, (max(recent) + 1) if recent else floor)
+        return max(floor, (max(recent) + spare) if recent else floor)
 
     @staticmethod
     def _note(recent, needed):
@@ -693,7 +693,7 @@ class CircleFinder:
             rounds = 0
             if min_dist > 0:
                 self._nms_prepare(min_dist)
-                rounds = min(self._hint(self._recent_rounds, 2), self.MAX_GROUP)
+                rounds = min(self._hint(self._recent_rounds, 2, spare=0), self.MAX_GROUP)  # (a missing round is cheap to add)
                 self._nms_rounds(min_dist, True, rounds, bufs[0].shape[1])
             self._collect(bufs, min_dist)
             return bufs, rounds
@@ -717,7 +717,7 @@ class CircleFinder:
                         break
                     if rounds > 10000:
                         raise RuntimeError("greedy suppression did not converge")
-                group = min(self._hint(self._recent_rounds, 2), self.MAX_GROUP) if rounds == 0 else 2
+                group = min(self._hint(self._recent_rounds, 2, spare=0), self.MAX_GROUP) if rounds == 0 else 2
                 self._nms_rounds(min_dist, rounds == 0, group, out_cap)
                 rounds += group
                 # the ordered output is gathered before the check and rides on the same round trip (it is gathered

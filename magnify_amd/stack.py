@@ -11,7 +11,6 @@ The time axis is the unit of sharding across GPUs (``magnify_amd.distributed``).
 """
 from __future__ import annotations
 
-import os
 
 import math
 
