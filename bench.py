@@ -349,6 +349,12 @@ def main():
         # planes) or reads (4 B per window pixel): masks come straight from the bead tables
         stream_bytes = 6 * n_all + 8 * n_s + markers_local * proc.L**2 * (4 * C + 2)
         breakdown, roofline, streaming, total_ms = stage_report(stages, args.steps, p, pmc, stream_bytes)
+        # the same stages against SURVEY 8d's own count, which includes the label map (4 B written per searched pixel,
+        # 4 B read per window pixel) that this build never materialises: bytes saved, not bytes moved
+        survey_stream = 6 * n_all + 12 * n_s + markers_local * proc.L**2 * (4 * C + 6)
+        if streaming.get("ms_per_step"):
+            streaming["survey_8d_bytes_incl_label_map"] = survey_stream
+            streaming["frac_of_peak_by_survey_bytes"] = survey_stream / (streaming["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS
         roofline["traffic_source"] = pmc_file  # None: no PMC pass on these exact sources under profiles/
         # SURVEY 8d's byte count of the whole step, B = 6 N_all + 12 N_s + K_u (12 + 5 P) + M L^2 (4 C + 6), with K_u
         # the circles that reach the exact sum; against the wall-clock step (kernels + host round trips)
