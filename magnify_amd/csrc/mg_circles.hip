@@ -712,8 +712,8 @@ __device__ __forceinline__ int wrap(int v, int n) {
   return v;
 }
 
-// PHASE 0 (bid), 1 (decide), 2 (cleanup): one WAVE per alive circle, one lane per ring cell -- the ring's loads and
-// atomics of a circle are in flight together and the verdict is two ballots (a thread per circle walked its ring in
+// PHASE 0 (bid), 1 (decide), 2 (cleanup): the lanes of a wave work on the ring cells of one circle together -- its
+// loads and atomics are in flight at once and the verdict is two ballots (a thread per circle walked its ring in
 // seven dependent steps: a chain of HBM latencies per round at any batch size).  PHASE 3-5: one thread per circle.
 // d_undecided[plane] becomes non-zero when a circle stays undecided (a flag, not a count: one atomicAdd per wave on
 // one address serialised 18 000 deep in the first round).
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
                                             const int32_t* __restrict__ d_ring_rc, int ring_len,
                                             uint64_t* __restrict__ d_grid, int64_t grid_cap,
                                             uint8_t* __restrict__ d_state, int32_t* __restrict__ d_undecided,
-                                            const uint32_t* __restrict__ d_tie) {
+                                            const uint32_t* __restrict__ d_tie, int cpw) {
   const int plane = blockIdx.y;
   const int n = d_num_alive[plane];
   if (n == 0) return;
@@ -756,51 +756,114 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
     }
     return;
   }
+  // A wave takes cpw consecutive alive circles: lanes 0 .. cpw - 1 look their own circle up (coalesced; most are
+  // decided after the first round and the wave is done), then the wave works through the undecided ones NU at a time,
+  // all lanes on the ring cells of one circle -- the loads of the NU rings are in flight together, the verdict of a
+  // circle is two ballots.  cpw = 64 at large batches (a wave per circle cost ~75 us per launch for 367 000 waves that
+  // only looked at a state byte), fewer when the whole batch has few circles (the trips of a wave are a chain).
+  constexpr int NU = 4;
   const int lane = threadIdx.x & 63;
   const int64_t n_waves = ((int64_t)gridDim.x * NT) >> 6;
   bool any_undecided = false;
-  for (int64_t a = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6; a < n; a += n_waves) {
-    const int idx = __builtin_amdgcn_readfirstlane(alive[a]);
-    if (PHASE != 2 && state[idx] != 0) continue;
-    const int row = circles[3 * (int64_t)idx], col = circles[3 * (int64_t)idx + 1];
-    const uint32_t tk = tie ? tie[idx] : (uint32_t)idx;
-    const uint64_t key = nms_key(scores[idx], tk);
-    auto cell_of = [&](int j) -> uint64_t* {
-      const int rr = wrap(d_ring_rc[2 * j] + row + pad, n_rows), cc = wrap(d_ring_rc[2 * j + 1] + col + pad, n_cols);
-      return &grid[(int64_t)rr * n_cols + cc];
-    };
-    if (PHASE == 2) {  // cleanup (after convergence): restore the all-ones grid under every ring
-      for (int j = lane; j < ring_len; j += 64) *cell_of(j) = ~0ull;
-      if (lane == 0) state[idx] = 0;
-    } else if (PHASE == 0) {  // claim: every undecided circle bids for its ring pixels
-      // a cell that already holds a smaller key cannot be won (cells only ever decrease during the bids):
-      // look first and spare the memory-side atomic for those
-      for (int j = lane; j < ring_len; j += 64) {
-        uint64_t* cell = cell_of(j);
-        if (__builtin_nontemporal_load(cell) > key) atomicMin(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)key);
-      }
-    } else {  // decide
-      bool foreign = false, kept = false;
-      for (int j = lane; j < ring_len; j += 64) {
-        const uint64_t g = *cell_of(j);
-        if (g != key) {
-          foreign = true;
-          if ((g >> 32) == 0) kept = true;  // a kept circle's mark
+  for (int64_t w0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6; w0 * cpw < n; w0 += n_waves) {
+    const int64_t a = w0 * cpw + lane;
+    const bool have = lane < cpw && a < n;
+    const int my_idx = have ? alive[a] : 0;
+    const bool want = have && (PHASE == 2 || state[my_idx] == 0);
+    int my_row = 0, my_col = 0;
+    uint32_t my_tk = 0, key_lo = 0, key_hi = 0;
+    if (want) {
+      my_row = circles[3 * (int64_t)my_idx], my_col = circles[3 * (int64_t)my_idx + 1];
+      my_tk = tie ? tie[my_idx] : (uint32_t)my_idx;
+      const uint64_t k = nms_key(scores[my_idx], my_tk);
+      key_lo = (uint32_t)k, key_hi = (uint32_t)(k >> 32);
+    }
+    uint64_t todo = __ballot(want);
+    while (todo) {
+      int idx[NU], row[NU], col[NU], cnt = 0;
+      uint32_t tk[NU];
+      uint64_t key[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        idx[u] = 0, row[u] = 0, col[u] = 0, tk[u] = 0, key[u] = 0;
+        if (todo) {  // wave-uniform
+          const int src = __ffsll((unsigned long long)todo) - 1;
+          todo &= todo - 1;
+          idx[u] = __builtin_amdgcn_readlane(my_idx, src);
+          row[u] = __builtin_amdgcn_readlane(my_row, src);
+          col[u] = __builtin_amdgcn_readlane(my_col, src);
+          tk[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_tk, src);
+          key[u] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)key_hi, src) << 32) |
+                   (uint32_t)__builtin_amdgcn_readlane((int)key_lo, src);
+          cnt = u + 1;
         }
       }
-      const bool all_mine = __ballot(foreign) == 0, hit_kept = __ballot(kept) != 0;
-      if (all_mine) {
-        if (lane == 0) state[idx] = 1;
-        // mark the ring as kept: (0, tie) is below every real key, so no later bid replaces it
-        for (int j = lane; j < ring_len; j += 64)
-          atomicMin(reinterpret_cast<unsigned long long*>(cell_of(j)), (unsigned long long)tk);
-      } else if (hit_kept) {
-        if (lane == 0) state[idx] = 2;
-        // withdraw this circle's bids so that later circles can win these pixels
-        for (int j = lane; j < ring_len; j += 64)
-          atomicCAS(reinterpret_cast<unsigned long long*>(cell_of(j)), (unsigned long long)key, ~0ull);
-      } else {
-        any_undecided = true;
+      for (int j0 = 0; j0 < ring_len; j0 += 64) {  // (one trip for rings of up to 64 cells)
+        const int j = j0 + lane;
+        const bool on = j < ring_len;
+        const int dr = on ? d_ring_rc[2 * j] : 0, dc = on ? d_ring_rc[2 * j + 1] : 0;
+        uint64_t* cell[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+          cell[u] = &grid[(int64_t)wrap(dr + row[u] + pad, n_rows) * n_cols + wrap(dc + col[u] + pad, n_cols)];
+        if (PHASE == 2) {  // cleanup (after convergence): restore the all-ones grid under every ring
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+            if (u < cnt && on) *cell[u] = ~0ull;
+        } else if (PHASE == 0) {  // claim: every undecided circle bids for its ring pixels
+          // a cell that already holds a smaller key cannot be won (cells only ever decrease during the bids):
+          // look first and spare the memory-side atomic for those
+          uint64_t cur[NU];
+#pragma unroll
+          for (int u = 0; u < NU; ++u) cur[u] = (u < cnt && on) ? __builtin_nontemporal_load(cell[u]) : 0ull;
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+            if (u < cnt && on && cur[u] > key[u]) atomicMin(reinterpret_cast<unsigned long long*>(cell[u]), (unsigned long long)key[u]);
+        }
+      }
+      if (PHASE == 2) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+          if (u < cnt && lane == 0) state[idx[u]] = 0;
+      } else if (PHASE == 1) {  // decide
+        bool foreign[NU], kept[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) foreign[u] = false, kept[u] = false;
+        for (int j = lane; j < ring_len; j += 64) {
+          const int dr = d_ring_rc[2 * j], dc = d_ring_rc[2 * j + 1];
+          uint64_t g[NU];
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+            g[u] = u < cnt ? grid[(int64_t)wrap(dr + row[u] + pad, n_rows) * n_cols + wrap(dc + col[u] + pad, n_cols)] : key[u];
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+            if (g[u] != key[u]) {
+              foreign[u] = true;
+              if ((g[u] >> 32) == 0) kept[u] = true;  // a kept circle's mark
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          if (u >= cnt) break;  // wave-uniform
+          const bool all_mine = __ballot(foreign[u]) == 0, hit_kept = __ballot(kept[u]) != 0;
+          if (all_mine) {
+            if (lane == 0) state[idx[u]] = 1;
+            // mark the ring as kept: (0, tie) is below every real key, so no later bid replaces it
+            for (int j = lane; j < ring_len; j += 64)
+              atomicMin(reinterpret_cast<unsigned long long*>(
+                            &grid[(int64_t)wrap(d_ring_rc[2 * j] + row[u] + pad, n_rows) * n_cols + wrap(d_ring_rc[2 * j + 1] + col[u] + pad, n_cols)]),
+                        (unsigned long long)tk[u]);
+          } else if (hit_kept) {
+            if (lane == 0) state[idx[u]] = 2;
+            // withdraw this circle's bids so that later circles can win these pixels
+            for (int j = lane; j < ring_len; j += 64)
+              atomicCAS(reinterpret_cast<unsigned long long*>(
+                            &grid[(int64_t)wrap(d_ring_rc[2 * j] + row[u] + pad, n_rows) * n_cols + wrap(d_ring_rc[2 * j + 1] + col[u] + pad, n_cols)]),
+                        (unsigned long long)key[u], ~0ull);
+          } else {
+            any_undecided = true;
+          }
+        }
       }
     }
   }
@@ -1052,6 +1115,15 @@ extern "C" int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bit
   return MG_OK;
 }
 
+namespace {
+// circles a wave of the suppression rounds looks up at once: 64 when the batch has many (late rounds are then a
+// coalesced look at the state bytes), fewer when it has few (their rings are worked through one trip after another)
+inline int nms_circles_per_wave(int64_t alive_bound, int n_planes) {
+  const int64_t total = alive_bound * std::max(n_planes, 1);
+  return total >= 262144 ? 64 : total >= 32768 ? 16 : 4;
+}
+}  // namespace
+
 extern "C" int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
                             const int32_t* d_alive, const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes,
                             int min_dist, const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap,
@@ -1066,13 +1138,14 @@ extern "C" int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const 
   if (hipMemsetAsync(d_undecided, 0, sizeof(int32_t) * n_planes, s) != hipSuccess) return MG_ELAUNCH;
   // the kernels walk d_alive with a grid-stride loop: max_alive (> 0: the caller's upper bound of
   // d_num_alive) only sizes the grid -- an all-capacity grid of empty blocks costs ~0.1 ms per launch
-  // (one wave per alive circle)
-  const dim3 g(grid_x(64 * (max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap)), n_planes);
+  const int64_t bound = max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap;
+  const int cpw = nms_circles_per_wave(bound, n_planes);
+  const dim3 g(grid_x(bound * (64 / cpw)), n_planes);
   hipLaunchKernelGGL((k_nms<0>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                     min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided, d_tie_keys);
+                     min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided, d_tie_keys, cpw);
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_nms<1>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                     min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided, d_tie_keys);
+                     min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided, d_tie_keys, cpw);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -1087,13 +1160,13 @@ extern "C" int mg_nms_same_centre(const int32_t* d_circles, int64_t circle_cap, 
   hipStream_t s = mg_stream(stream);
   const dim3 g(grid_x(max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap), n_planes);
   hipLaunchKernelGGL((k_nms<3>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys);
+                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys, 64);
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_nms<4>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys);
+                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys, 64);
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_nms<5>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys);
+                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys, 64);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -1106,10 +1179,12 @@ extern "C" int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, cons
     return MG_EINVAL;
   if (n_planes < 0 || n_planes > 65535 || min_dist <= 0 || ring_len <= 0) return MG_EINVAL;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
-  hipLaunchKernelGGL((k_nms<2>), dim3(grid_x(64 * (max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap)), n_planes),
+  const int64_t bound = max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap;
+  const int cpw = nms_circles_per_wave(bound, n_planes);
+  hipLaunchKernelGGL((k_nms<2>), dim3(grid_x(bound * (64 / cpw)), n_planes),
                      dim3(NT), 0, mg_stream(stream), d_circles,
                      circle_cap, d_scores, d_alive, d_num_alive, d_max_rc, min_dist, d_ring_rc, ring_len, d_grid,
-                     grid_cap, d_state, (int32_t*)nullptr, (const uint32_t*)nullptr);
+                     grid_cap, d_state, (int32_t*)nullptr, (const uint32_t*)nullptr, cpw);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
