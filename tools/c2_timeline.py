@@ -83,7 +83,7 @@ def main():
             torch.cuda.synchronize()
         pr.disable()
         s = io.StringIO()
-        pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
+        pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(70)
         print(s.getvalue())
 
 
