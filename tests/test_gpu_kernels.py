@@ -105,6 +105,29 @@ def test_flatfield_f32_and_ragged(hp):
     np.testing.assert_array_equal(img.cpu().numpy(), rp.stitch(rp.flatfield_correct(t16, 0.9, 10.0), 3))
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32, np.float64])
+def test_flatfield_reference_defaults(hp, dtype):
+    """flat 1.0 / dark 0.0 (preprocess.py:62): the identity on integer pixels (the device only crops and copies: no
+    maxima pass, no arithmetic), NOT on floating point ones (x * M / M rounds); all-zero planes; maxima 0."""
+    rng = np.random.default_rng(11)
+    hi = 255 if dtype == np.uint8 else 60000
+    tiles = (rng.random((2, 2, 2, 3, 40, 56)) * hi).astype(dtype)
+    tiles[1, 0] = 0  # an all-zero channel / time inside a non-zero array
+    assert hp.flatfield_is_identity(torch.from_numpy(tiles).dtype, 1.0, 0.0) == (np.dtype(dtype).kind == "u")
+    assert not hp.flatfield_is_identity(torch.uint16, 1.0, 1.0) and not hp.flatfield_is_identity(torch.uint16, vignette((40, 56)), 0.0)
+    for overlap in (0, 6):
+        img, minmax = hp.flatfield_stitch(dev(tiles), overlap)
+        want = rp.stitch(rp.flatfield_correct(tiles, 1.0, 0.0), overlap)
+        np.testing.assert_array_equal(img.cpu().numpy(), want)
+        mm = minmax.cpu().numpy().reshape(2, 2, 2)
+        np.testing.assert_array_equal(mm[..., 0], want.min(axis=(-1, -2)))
+        np.testing.assert_array_equal(mm[..., 1], want.max(axis=(-1, -2)))
+    zeros = np.zeros((1, 1, 1, 1, 32, 48), dtype=dtype)
+    if np.dtype(dtype).kind == "u":  # 0 * 0 / 0: NaN -> 0 in the integer cast, here and in the oracle
+        img, _ = hp.flatfield_stitch(dev(zeros), 0)
+        assert not img.cpu().numpy().any()
+
+
 # ---------------------------------------------------------------------------------------------
 # A3 / A4: to_uint8 + blur
 # ---------------------------------------------------------------------------------------------
