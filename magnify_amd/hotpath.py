@@ -740,7 +740,8 @@ class CircleFinder:
         host plus the device tensors (out, out_scores, num_out).  ``host_results=False``: only the
         counts come back -- (counts, (out, out_scores, num_out)); ``fetch_results`` copies the lists
         later (e.g. after the ROI pass, which reads the tables on the device, has been launched).
-        The device tensors stay valid until the next-but-one ``find`` of this finder.
+        ``out`` / ``out_scores`` stay valid until the next-but-one ``find`` of this finder (two buffer sets used in
+        turn); ``num_out`` is a row of the status block and is cleared by the next ``find``.
 
         Host round trips: the checked chain has three (hysteresis convergence + edge counts, alive counts,
         suppression convergence + output counts).  Once a call has gone through it, the next ones run OPTIMISTICALLY:
