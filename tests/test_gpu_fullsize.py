@@ -93,7 +93,12 @@ def test_full_size_assays_match_c_oracle(mg):
     stack, _ = synthetic_stack(T, C, S, S, seed=4100)
     flat_np = vignette((S, S))
     proc = StackProcessor(T, C, S, S, num_iter=5_000_000, search_channels=(0,), mode="P")
+    # a first call (other seeds) goes through the checked chain; the call that is compared then runs with ONE host
+    # round trip, on the sweeps / rounds / capacities of the first (hotpath.CircleFinder.find)
+    proc(stack, torch.from_numpy(flat_np).cuda(), 100.0, seed=5)
+    assert not proc.finder.stats["optimistic"]
     out = proc(stack, torch.from_numpy(flat_np).cuda(), 100.0, seed=9)
+    assert proc.finder.stats["optimistic"] and proc.finder.calls == {"optimistic": 1, "repaired": 0, "checked": 1}
     host = stack.cpu().numpy()
     off = out["offsets"]
     for t in range(T):
