@@ -45,22 +45,37 @@ readers = Registry("magnify", "readers")
 components = Registry("magnify", "components")
 
 
+class _Factory:
+    """What ``component(name)`` puts into the registry for ``func(xp, **settings)``: calling it with the settings
+    gives the pipeline step ``step(xp)``; it presents ``func``'s name, docstring and signature without the dataset
+    parameter, which is what ``Pipeline.add_pipe(name, **settings)`` and introspection see (registry.py:16-29)."""
+
+    def __init__(self, func):
+        self._func = func
+        functools.update_wrapper(self, func)
+        dataset_param, *settings = inspect.signature(func).parameters.values()
+        self.__signature__ = inspect.Signature(settings)
+
+    def __call__(self, *args, **settings):
+        func = self._func
+
+        def step(xp, *more, **late):
+            return func(*args, xp, *more, **{**settings, **late})
+
+        step.__name__ = getattr(func, "__name__", "step")
+        step.func, step.args, step.keywords = func, args, settings  # (what functools.partial would expose)
+        return step
+
+
 def component(name):
-    """Register ``func(xp, **kwargs)`` under ``name`` as a factory whose signature is ``func``'s
-    minus its first parameter; returns ``func`` itself (registry.py:16-29)."""
+    """Decorator: register ``func(xp, **settings)`` under ``name``; ``func`` itself is returned unchanged, so a
+    module can keep calling it directly."""
 
-    def component_decorator(func):
-        @functools.wraps(func)
-        def component_factory(*args, **kwargs):
-            return functools.partial(func, *args, **kwargs)
-
-        signature = inspect.signature(func)
-        signature = signature.replace(parameters=list(signature.parameters.values())[1:])
-        component_factory.__signature__ = signature
-        components.register(name)(component_factory)
+    def register(func):
+        components.register(name)(_Factory(func))
         return func
 
-    return component_decorator
+    return register
 
 
 from .pipeline import Pipeline  # noqa: E402  (Pipeline looks the registries up lazily)
