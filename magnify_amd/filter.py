@@ -115,13 +115,41 @@ def outer_border_length(blob: np.ndarray) -> float:
     raise RuntimeError("border following did not close")
 
 
+def mask_perimeter(mask: np.ndarray) -> float:
+    """Total outer-border length of the 8-connected components of ``mask`` that do not lie inside a hole of another
+    component (filter.py:51-52: cv.findContours(..., RETR_EXTERNAL, ...) + cv.arcLength)."""
+    import scipy.ndimage
+
+    mask = np.asarray(mask, dtype=bool)
+    labels, n = scipy.ndimage.label(mask, structure=np.ones((3, 3), dtype=bool))
+    if n == 0:
+        return 0.0
+    # background connected to the frame (4-connected, the dual of the 8-connected foreground)
+    pad = np.zeros((mask.shape[0] + 2, mask.shape[1] + 2), dtype=bool)
+    pad[1:-1, 1:-1] = mask
+    bg, _ = scipy.ndimage.label(~pad)
+    outside = bg == bg[0, 0]
+    total = 0.0
+    firsts = scipy.ndimage.find_objects(labels)
+    for k in range(1, n + 1):
+        sl = firsts[k - 1]
+        comp = labels[sl] == k
+        # the pixel above the component's raster-first pixel belongs to the background region around its outer border
+        y0 = sl[0].start
+        x0 = sl[1].start + int(np.argmax(comp[0]))
+        if outside[y0, x0 + 1]:  # (padded coordinates: row y0 - 1 + 1, column x0 + 1)
+            total += outer_border_length(comp)
+    return total
+
+
 @registry.component("filter_nonround")
 def filter_nonround(assay, min_roundness=0.75, search_channel=None):
     """filter.py:40-62: a marker stays valid only if its foreground mask (time 0) is round enough,
     4 pi area / perimeter^2 > min_roundness, perimeter = total length of the outer borders of its connected
     components; a mask without any border length (empty or single pixels) is invalid.  The masks are a few
-    thousand small images per assay: traced on the host.  PARITY UNPINNED (OpenCV is not available to check
-    the border lengths against; nested components, which RETR_EXTERNAL would skip, are counted)."""
+    thousand small images per assay: traced on the host.  Components that lie inside a hole of another one are
+    skipped, as RETR_EXTERNAL skips them.  PARITY UNPINNED against OpenCV itself (not available here); checked against
+    an independent restatement of its border following (oracle/ref_contours.py, tests/test_cpu_host.py)."""
     import scipy.ndimage
 
     _channel_indexes(assay, search_channel)  # validates the names like the other filters
@@ -130,10 +158,8 @@ def filter_nonround(assay, min_roundness=0.75, search_channel=None):
     masks = (masks[:, 0].cpu().numpy() if hasattr(masks, "cpu") else np.asarray(masks)[:, 0]).astype(bool)
     var, valid = _valid_array(assay)
     flat = valid.reshape(len(masks), -1)
-    eight = np.ones((3, 3), dtype=bool)
     for i, mask in enumerate(masks):
-        labels, n = scipy.ndimage.label(mask, structure=eight)
-        perimeter = sum(outer_border_length(labels == k) for k in range(1, n + 1))
+        perimeter = mask_perimeter(mask)
         if perimeter == 0:
             flat[i] = False
             continue

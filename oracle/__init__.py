@@ -16,6 +16,9 @@ Pinning (see DESIGN.md "Oracle"):
     Canny, circle).  OpenCV is an un-vendored third-party dependency that is not
     installed here: PARITY UNPINNED at bit level for these four functions;
     pinned only end-to-end through the reference's own tolerance tests.
+  * ``ref_contours`` -- Suzuki-Abe border following + CHAIN_APPROX_SIMPLE + arcLength as ``cv.findContours`` /
+    ``cv.arcLength`` implement them (filter.py:51-52): PARITY UNPINNED against OpenCV itself; independent of the
+    product's Moore tracing, which it checks.
   * ``ref_pipeline`` -- restates xarray/dask-level code that cannot run here
     (stitch, flatfield_correct, BeadFinder, ButtonFinder); stitch is pinned by
     the reference's exact index assertions (tests/test_stitch.py), the finders

@@ -706,3 +706,58 @@ def test_save_load_beyond_4_gib(tmp_path):
     for k in marks:
         assert roi[k, k % c, 0, k % L, (7 * k) % L] == 1 + k % 60000
     assert int(roi.sum(dtype=np.int64)) == sum(1 + k % 60000 for k in marks)
+
+
+def test_filter_nonround_against_contour_oracle():
+    """The product's outer-border lengths (Moore tracing per labelled component, nested components skipped) against
+    the oracle's independent restatement of what the reference calls (filter.py:51-52): Suzuki-Abe border following
+    with RETR_EXTERNAL + CHAIN_APPROX_SIMPLE + arcLength -- on disks, random blobs, thin and diagonal structures,
+    holes, islands inside holes, masks touching the frame."""
+    from magnify_amd.filter import mask_perimeter
+    from oracle import ref_contours as rc
+
+    rng = np.random.default_rng(77)
+    masks = []
+    yy, xx = np.mgrid[0:40, 0:48]
+    for _ in range(40):  # unions of a few disks / rectangles, with bites taken out
+        m = np.zeros((40, 48), bool)
+        for _ in range(rng.integers(1, 5)):
+            cy, cx, r = rng.integers(0, 40), rng.integers(0, 48), rng.integers(1, 12)
+            if rng.random() < 0.6:
+                m |= (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+            else:
+                m[max(cy - r, 0):cy + r, max(cx - r // 2, 0):cx + r // 2 + 1] = True
+        for _ in range(rng.integers(0, 3)):
+            cy, cx, r = rng.integers(0, 40), rng.integers(0, 48), rng.integers(1, 6)
+            m &= ~((yy - cy) ** 2 + (xx - cx) ** 2 <= r * r)
+        masks.append(m)
+    for p in (0.1, 0.3, 0.5, 0.7, 0.9):  # salt and pepper: single pixels, diagonal contacts, tiny holes
+        masks += [rng.random((24, 24)) < p for _ in range(12)]
+    ring = np.ones((15, 15), bool)
+    ring[3:12, 3:12] = False
+    island = ring.copy()
+    island[6:9, 6:9] = True            # a component inside the hole of another: skipped by RETR_EXTERNAL
+    nested = island.copy()
+    nested[7, 7] = False               # ... with a hole of its own
+    masks += [ring, island, nested, np.ones((6, 9), bool), np.zeros((5, 5), bool), np.eye(9, dtype=bool),
+              np.fliplr(np.eye(9, dtype=bool)), np.triu(np.ones((12, 12), bool))]
+    n_nested = 0
+    for m in masks:
+        want = rc.mask_perimeter(m)
+        assert mask_perimeter(m) == pytest.approx(want, rel=1e-12, abs=1e-12)
+        n_nested += len(rc.external_contours(m)) < scipy_components(m)
+    assert rc.mask_perimeter(island) == rc.mask_perimeter(ring) == 56.0
+    assert n_nested >= 3  # the set does hold masks where not every component is an external one
+    # and the component's verdicts follow the oracle's roundness
+    fg = np.stack(masks[:40])[:, None]
+    xp = mg.Dataset({"roi": mg.DataArray(np.zeros((40, 1, 1, 40, 48), np.uint16), ("mark", "channel", "time", "roi_y", "roi_x"))},
+                    coords={"fg": (("mark", "time", "roi_y", "roi_x"), fg), "valid": (("mark", "time"), np.ones((40, 1), bool))})
+    got = mg.components.get("filter_nonround")(min_roundness=0.6)(xp).valid.values[:, 0]
+    want = [(rc.roundness(m) or 0.0) > 0.6 for m in masks[:40]]
+    assert got.tolist() == want and 5 < sum(want) < 35
+
+
+def scipy_components(mask):
+    import scipy.ndimage
+
+    return scipy.ndimage.label(mask, structure=np.ones((3, 3), bool))[1]
