@@ -1,5 +1,5 @@
 // A16/A17: grid fit and per-chamber masks of ButtonFinder (reference: src/magnify/find.py).
-//   - cluster_1d (find.py:632-677): cost of every integer offset, one thread per offset;
+//   - cluster_1d (find.py:632-677): cost of every integer offset, one wave per offset;
 //   - fg / bg masks of find_rois (find.py:383-400): cv.circle filled disk and annulus rasters;
 //   - masked sums with explicit per-marker masks (README.md:21-22 on chip outputs).
 #include <math.h>
@@ -22,38 +22,44 @@ __device__ __forceinline__ int lower_bound(const double* __restrict__ a, int n, 
 
 // cost(offset) = sum_k [ var_k * sqrt(ideal_k) + penalty * (ideal_k - n_k)^2 ], var_k = mean squared
 // distance to the cluster centre, empty clusters take the maximum var (find.py:647-668).
-__global__ __launch_bounds__(NT) void k_cluster1d(const double* __restrict__ pts, int n_pts, int n_offsets,
+// One wave per offset, one lane per cluster (64 at a time): the two binary searches and the (sequential, as in the
+// reference) sum over a cluster's points run side by side for all clusters; the total is added up by one lane in
+// cluster order.  (A thread per offset walked all clusters twice, ~2700 dependent loads: 225 us for the ~400
+// offsets of one axis on two workgroups.)
+__global__ __launch_bounds__(64) void k_cluster1d(const double* __restrict__ pts, int n_pts, int n_offsets,
                                                   int n_clusters, double cluster_length,
                                                   const double* __restrict__ ideal, double penalty,
                                                   double* __restrict__ costs) {
-  const int off = blockIdx.x * NT + threadIdx.x;
-  if (off >= n_offsets) return;
+  extern __shared__ double s_var[];              // [n_clusters] variance of the non-empty clusters
+  int* s_cnt = reinterpret_cast<int*>(s_var + n_clusters);  // [n_clusters] points per cluster
+  const int off = blockIdx.x, lane = threadIdx.x;
   double vmax = 0.0;  // costs of non-empty clusters are >= 0 and empty ones enter the max as 0
-  for (int k = 0; k < n_clusters; ++k) {
+  for (int k = lane; k < n_clusters; k += 64) {
     const double b0 = (double)k * cluster_length + (double)off, b1 = (double)(k + 1) * cluster_length + (double)off;
     const int lo = lower_bound(pts, n_pts, b0), hi = lower_bound(pts, n_pts, b1);
-    if (hi > lo) {
-      const double c = (b1 + b0) / 2.0;
-      double s = 0.0;
-      for (int i = lo; i < hi; ++i) s += (pts[i] - c) * (pts[i] - c);
-      vmax = fmax(vmax, s / (double)(hi - lo));
-    }
-  }
-  double total = 0.0;
-  for (int k = 0; k < n_clusters; ++k) {
-    const double b0 = (double)k * cluster_length + (double)off, b1 = (double)(k + 1) * cluster_length + (double)off;
-    const int lo = lower_bound(pts, n_pts, b0), hi = lower_bound(pts, n_pts, b1);
-    double var = vmax;
+    double var = 0.0;
     if (hi > lo) {
       const double c = (b1 + b0) / 2.0;
       double s = 0.0;
       for (int i = lo; i < hi; ++i) s += (pts[i] - c) * (pts[i] - c);
       var = s / (double)(hi - lo);
+      vmax = fmax(vmax, var);
     }
-    const double miss = ideal[k] - (double)(hi - lo);
-    total += var * sqrt(ideal[k]) + penalty * miss * miss;
+    s_var[k] = var;
+    s_cnt[k] = hi - lo;
   }
-  costs[off] = total;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, o));
+  __syncthreads();
+  if (lane == 0) {
+    double total = 0.0;
+    for (int k = 0; k < n_clusters; ++k) {
+      const double var = s_cnt[k] > 0 ? s_var[k] : vmax;
+      const double miss = ideal[k] - (double)s_cnt[k];
+      total += var * sqrt(ideal[k]) + penalty * miss * miss;
+    }
+    costs[off] = total;
+  }
 }
 
 // fg = filled cv.circle of radius r_i, bg = annulus(outer_r, inner_r), all centred on
@@ -124,8 +130,9 @@ extern "C" int mg_cluster1d_costs(const double* d_sorted_points, int n_points, i
                                   void* stream) {
   if (!d_sorted_points || !d_ideal || !d_costs || n_points < 0 || n_offsets < 0 || n_clusters <= 0) return MG_EINVAL;
   if (n_offsets == 0) return MG_OK;
-  hipLaunchKernelGGL(k_cluster1d, dim3((n_offsets + NT - 1) / NT), dim3(NT), 0, mg_stream(stream), d_sorted_points,
-                     n_points, n_offsets, n_clusters, cluster_length, d_ideal, penalty, d_costs);
+  if (n_clusters > 4096) return MG_EINVAL;  // (the per-cluster terms of an offset are staged in LDS)
+  hipLaunchKernelGGL(k_cluster1d, dim3(n_offsets), dim3(64), (size_t)n_clusters * 12 + 8, mg_stream(stream),
+                     d_sorted_points, n_points, n_offsets, n_clusters, cluster_length, d_ideal, penalty, d_costs);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

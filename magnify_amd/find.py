@@ -202,6 +202,27 @@ def chamber_seed(seed: int, chamber: int, k: int) -> int:
     return (seed + 0x51ED270B * (chamber + 1) + 0x2545F491 * (k + 1)) & 0xFFFFFFFFFFFFFFFF
 
 
+def chamber_seeds(seed: int, m: int, k: int) -> np.ndarray:
+    """``chamber_seed`` of chambers 0 .. m - 1 at once (uint64 arithmetic wraps like the mask above)."""
+    with np.errstate(over="ignore"):
+        return (np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + np.uint64(0x51ED270B) * (np.arange(m, dtype=np.uint64) + np.uint64(1))
+                + np.uint64((0x2545F491 * (k + 1)) & 0xFFFFFFFFFFFFFFFF))
+
+
+def _rounded_centres(y, x):
+    """(m, 2) int32 [row, col] = round-half-to-even of the float positions, as Python's ``round`` gives them
+    (find.py:316-317)."""
+    return np.stack([np.rint(np.asarray(y, dtype=np.float64).reshape(-1)), np.rint(np.asarray(x, dtype=np.float64).reshape(-1))],
+                    axis=1).astype(np.int32)
+
+
+def _window_origin(c, L, size):
+    """utils.bounding_box for many centres at once: the L-wide window about c, shifted into [0, size)."""
+    lo = c.astype(np.int64) - L // 2
+    lo = np.where(lo < 0, 0, lo)
+    return np.where(lo + L > size, size - L, lo)
+
+
 class ButtonFinder:
     def __init__(self, row_dist, col_dist, min_button_diameter, max_button_diameter, chamber_diameter, top_chamber,
                  left_chamber, low_edge_quantile, high_edge_quantile, num_iter, min_roundness, cluster_penalty,
@@ -266,8 +287,7 @@ class ButtonFinder:
         m, L = n_rows * n_cols, self.roi_length
         x, y = x.copy(), y.copy()
         radius = np.full((n_rows, n_cols), self.max_button_radius, dtype=np.int64)
-        centers = np.array([[round(float(y[i, j])), round(float(x[i, j]))] for i in range(n_rows) for j in range(n_cols)],
-                           dtype=np.int32)
+        centers = _rounded_centres(y, x)
         tiles = hotpath.roi_gather_reduce(image_t.view(1, n_c, 1, h, w), [centers], L, None, want_masks=False,
                                           want_sums=False)["roi"]  # (m, C, 1, L, L)
         per_iter = self.num_iter // m
@@ -277,19 +297,17 @@ class ButtonFinder:
             finder = _finder(m, L, L, self.min_button_radius, self.max_button_radius, per_iter, image_t.device)
             hi_q = 1 - np.pi * self.min_button_radius / L**2
             for k, ch in enumerate(search_idx):
-                seeds = [chamber_seed(seed, c, k) for c in range(m)]
-                res, _ = finder.find(tiles[:, ch, 0], None, self.low_edge_quantile, hi_q, self.min_roundness, 0, seeds)
-                for c in range(m):
-                    circles, scores = res[c]
-                    if len(circles) > 0 and scores[0] > best_score[c]:  # sorted by score: [0] is np.argmax
-                        best[c], best_score[c] = circles[0], scores[0]
+                # only every chamber's best circle is needed (the lists come out sorted by score: [0] is np.argmax):
+                # the first row of the device tables, not 784 host lists
+                counts, (d_out, d_scores, _) = finder.find(tiles[:, ch, 0], None, self.low_edge_quantile, hi_q,
+                                                           self.min_roundness, 0, chamber_seeds(seed, m, k),
+                                                           host_results=False)
+                top_circle = d_out[:, 0].cpu().numpy().astype(np.int64)
+                top_score = d_scores[:, 0].cpu().numpy().astype(np.float64)
+                better = (np.asarray(counts) > 0) & (top_score > best_score)
+                best[better], best_score[better] = top_circle[better], top_score[better]
         # window origins of all chambers at once (utils.bounding_box: shift the L x L window into the image)
-        def origin(c, size):
-            lo = c.astype(np.int64) - L // 2
-            lo = np.where(lo < 0, 0, lo)
-            return np.where(lo + L > size, size - L, lo)
-
-        top, left = origin(centers[:, 0], h), origin(centers[:, 1], w)
+        top, left = _window_origin(centers[:, 0], L, h), _window_origin(centers[:, 1], L, w)
         found = ((tag != "").reshape(-1)) & (best[:, 2] >= 0)
         ys, xs, rs = y.reshape(-1), x.reshape(-1), radius.reshape(-1)  # views of the (contiguous) copies
         ys[found], xs[found] = (best[:, 0] + top)[found], (best[:, 1] + left)[found]
@@ -322,16 +340,13 @@ class ButtonFinder:
             src = self.search_timesteps[0] if t < self.search_timesteps[0] else t - 1
             x[..., t], y[..., t], radius[..., t], valid[..., t] = x[..., src], y[..., src], radius[..., src], valid[..., src]
         # final windows, masks and sums for every (timestep, chamber)
-        centers = [np.array([[round(float(y[i, j, t])), round(float(x[i, j, t]))] for i in range(n_rows)
-                             for j in range(n_cols)], dtype=np.int32) for t in range(n_t)]
+        centers = [_rounded_centres(y[..., t], x[..., t]) for t in range(n_t)]
         out = hotpath.roi_gather_reduce(img_t.view(n_t, n_c, 1, h, w), centers, L, None, want_masks=False,
                                         want_sums=False)
         roi = out["roi"].view(n_t, m, n_c, L, L).permute(1, 2, 0, 3, 4).contiguous()  # (M, C, T, L, L)
-        rel = np.empty((n_t * m, 2), dtype=np.int32)
-        for t in range(n_t):
-            for c in range(m):
-                top, _, left, _ = utils.bounding_box(int(centers[t][c, 1]), int(centers[t][c, 0]), L, w, h)
-                rel[t * m + c] = (centers[t][c, 0] - top, centers[t][c, 1] - left)
+        every = np.concatenate(centers)  # (T * m, 2): position of every centre inside its own window
+        rel = np.stack([every[:, 0] - _window_origin(every[:, 0], L, h), every[:, 1] - _window_origin(every[:, 1], L, w)],
+                       axis=1).astype(np.int32)
         radii_tm = np.ascontiguousarray(radius.reshape(m, n_t).T).reshape(-1)
         fg, bg = hotpath.button_masks(rel, radii_tm, L, self.chamber_radius, self.max_button_radius, image.device)
         fg = fg.view(n_t, m, L, L).permute(1, 0, 2, 3).contiguous()  # (M, T, L, L)
