@@ -117,7 +117,8 @@ int mg_to_uint8_blur(const void* d_src, int dtype, int n_planes, int64_t plane_s
  * monotone function of m, so np.quantile's order statistics are recovered exactly).
  * mode 0 (combined, 12288 bins per plane): bins [0, 8192) count m exactly, bin 8192 + (m >> 13)
  *   counts the rest coarsely -- one pass suffices whenever both quantile ranks fall below 8192;
- * mode 1 (window, 8192 bins per plane): bin m - d_base[plane] for m in [base, base + 8192).
+ * mode 1 (window, 8192 bins per plane): bin m - d_base[plane] for m in [base, base + 8192); a plane whose base
+ *   is 0xFFFFFFFF is skipped.
  * d_hist must be pre-zeroed. */
 int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w, int mode, const uint32_t* d_base,
                    uint32_t* d_hist, uint32_t* d_scratch, int64_t scratch_words, void* stream);
@@ -131,10 +132,19 @@ int64_t mg_scharr_hist_scratch_words(int n_planes, int h, int w, int mode);
  * order-statistic indices of numpy's linear interpolation for the low and the high quantile, gamma_* its
  * float32 weights (magnify_amd.hotpath.quantile_indexes).  Outputs d_thresh[n_planes][2] (the integer
  * thresholds mg_canny_nms takes), d_quantiles[n_planes][2] (float32, what np.quantile returns) and
- * d_unresolved[n_planes]: 1 where a rank falls into a coarse bin (the caller then resolves it with mode-1
- * window passes of mg_scharr_hist; thresholds of such a plane are not valid). */
+ * d_unresolved[n_planes]: low byte = the number of WINDOW passes the plane still needs (0: thresholds valid) -- one
+ * per distinct coarse bin that one of its ranks fell into --, next byte = the number it needs in all.  With d_state (int32 [n_planes][16]) and d_win_base
+ * (uint32 [n_planes]) the passes stay on the device: d_win_base receives the base of pass 0 (0xFFFFFFFF: the plane
+ * needs none and mg_scharr_hist mode 1 skips it); then, for pass = 0, 1, ...: clear d_hist_win
+ * [n_planes][8192], mg_scharr_hist(mode 1, d_base = d_win_base, d_hist = d_hist_win),
+ * mg_edge_thresholds_window(pass) -- which resolves the ranks of that window, writes the next base and, after a
+ * plane's last window, its thresholds and d_unresolved = 0.  At most 4 passes.  Both NULL: detection only. */
 int mg_edge_thresholds(const uint32_t* d_hist, int n_planes, const int64_t* ranks4, float gamma_low, float gamma_high,
-                       int32_t* d_thresh, float* d_quantiles, int32_t* d_unresolved, void* stream);
+                       int32_t* d_thresh, float* d_quantiles, int32_t* d_unresolved, int32_t* d_state,
+                       uint32_t* d_win_base, void* stream);
+int mg_edge_thresholds_window(const uint32_t* d_hist_win, int n_planes, int pass, float gamma_low, float gamma_high,
+                              int32_t* d_state, uint32_t* d_win_base, int32_t* d_thresh, float* d_quantiles,
+                              int32_t* d_unresolved, void* stream);
 
 /* Bitmaps over pixels use the linear layout bit i of word k <-> pixel 32 k + i (i = y * w + x);
  * words_per_plane >= ceil(h w / 32) + 1. */
@@ -162,6 +172,12 @@ int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_
  * (pre-zeroed) receives this sweep's flags.  Pass d_flags_in = NULL for the first sweep. */
 int mg_canny_hysteresis(const uint32_t* d_weak, uint32_t* d_strong, int64_t words_per_plane, int n_planes, int h,
                         int w, uint32_t* d_changed, const uint8_t* d_flags_in, uint8_t* d_flags_out, void* stream);
+/* The same hysteresis carried to the global fixed point in ONE launch: a workgroup that grows edges up to a weak
+ * pixel of a neighbouring tile marks that tile in d_dirty (uint32 [n_planes][ceil(tiles / 32)], tiles from
+ * mg_hysteresis_tiles; cleared here), and every workgroup keeps claiming and working off marked tiles of its plane
+ * until none is left -- no workgroup ever waits for another.  dirty_words = capacity of d_dirty in words. */
+int mg_canny_hysteresis_full(const uint32_t* d_weak, uint32_t* d_strong, int64_t words_per_plane, int n_planes, int h,
+                             int w, uint32_t* d_dirty, int64_t dirty_words, void* stream);
 int mg_hysteresis_tiles(int h, int w, int* tiles_x, int* tiles_y);
 
 /* Inspection helper: bitmap -> {0,1} bytes, d_out[n_planes][n_bits]. */

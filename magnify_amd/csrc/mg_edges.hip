@@ -275,6 +275,7 @@ __device__ __forceinline__ void scharr_n(const Row12& a, const Row12& b, const R
 // m == 0 (flat background, by far the most frequent value) is counted in registers.
 constexpr int FINE = 8192;
 constexpr int COARSE = 4096;
+constexpr uint32_t MG_HIST_SKIP = 0xFFFFFFFFu;  // mode 1: d_base[plane] of a plane that takes no part in the pass
 
 // A workgroup accumulates HIST_TILES vertically adjacent tiles (3 x 16384 pixels: a 16-bit counter
 // cannot overflow) before it hands its histogram over: a plain coalesced store of the packed counters
@@ -362,6 +363,8 @@ __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ 
   uint32_t* slot = (DIRECT && d_partial) ? d_partial + ((int64_t)plane * gridDim.y * gridDim.x +
                                                         (int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (n_bins / 2)
                                          : nullptr;
+  const uint32_t base = (mode == 1 && d_base) ? d_base[plane] : 0u;
+  if (mode == 1 && base == MG_HIST_SKIP) return;  // this plane needs no window pass (k_hist_reduce skips it too)
   if (DIRECT && !interior) {  // the staged launch handles this group (and adds straight into d_hist)
     if (slot)
       for (int i = threadIdx.x; i < n_bins / 2; i += NT) slot[i] = 0u;
@@ -369,7 +372,6 @@ __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ 
   }
   if (!DIRECT && split && interior) return;
   for (int i = threadIdx.x; i < n_bins / 2; i += NT) hist[i] = 0;
-  const uint32_t base = (mode == 1 && d_base) ? d_base[plane] : 0u;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = 4 * lane, gx = tx0 + c0;
   uint32_t zeros = 0;
@@ -447,8 +449,9 @@ __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ 
 constexpr int HIST_SLOTS_PER_BLOCK = 32;
 
 __global__ __launch_bounds__(NT) void k_hist_reduce(const uint32_t* __restrict__ d_partial, int slots, int n_bins,
-                                                    uint32_t* __restrict__ d_hist) {
+                                                    uint32_t* __restrict__ d_hist, const uint32_t* __restrict__ d_skip_base) {
   const int plane = blockIdx.y;
+  if (d_skip_base && d_skip_base[plane] == MG_HIST_SKIP) return;
   const int i = blockIdx.x * NT + threadIdx.x;  // packed word = bins 2i, 2i + 1
   if (i >= n_bins / 2) return;
   const int s0 = blockIdx.z * HIST_SLOTS_PER_BLOCK, s1 = min(s0 + HIST_SLOTS_PER_BLOCK, slots);
@@ -478,14 +481,69 @@ __global__ __launch_bounds__(NT) void k_hist_reduce(const uint32_t* __restrict__
 // interpolation for the low and the high quantile) are the bins where the running sum of the histogram first
 // exceeds the rank; a fine bin IS the value m = dx^2 + dy^2.  Then, exactly as NumPy 2.x and OpenCV do it
 // (utils.py:120-134): g = sqrt(float32(m)) in float32, _lerp in float32 with the float32 weight gamma, the two
-// thresholds ordered, clamped to 32767, squared in float64 and floored.  A rank that falls into a COARSE bin
-// (strong gradients: noiseless images) cannot be resolved here: d_unresolved[plane] = 1 and the caller takes the
-// window-histogram path for that call.
+// thresholds ordered, clamped to 32767, squared in float64 and floored.
+// A rank that falls into a COARSE bin (strong gradients: noiseless images, the chip's per-chamber windows) is
+// resolved by WINDOW passes that stay on the device: the plane's state block records, per rank, the coarse bin and
+// the rank's position inside it; pass p re-histograms the plane's p-th distinct coarse bin exactly (mg_scharr_hist
+// mode 1 with the base this kernel / k_window_resolve wrote) and k_window_resolve turns the positions into order
+// statistics.  d_unresolved[plane] = passes still to run (low byte; 0: thresholds valid) | passes needed in all << 8.
+constexpr int TS_ORDER = 0, TS_COARSE = 4, TS_RESID = 8, TS_NWIN = 12, TS_WORDS = 16;  // int32 words of a state block
+
+__device__ __forceinline__ void finish_thresholds(const int32_t* order, float gamma_lo, float gamma_hi, int plane,
+                                                  int32_t* __restrict__ d_thresh, float* __restrict__ d_quantiles) {
+  float q[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float ga = (float)sqrt((double)order[2 * k]), gb = (float)sqrt((double)order[2 * k + 1]);  // == float32 sqrt
+    const float gamma = k == 0 ? gamma_lo : gamma_hi;
+    const float diff = gb - ga;
+    q[k] = gamma >= 0.5f ? gb - diff * (1.0f - gamma) : ga + diff * gamma;  // numpy's _lerp, float32 throughout
+  }
+  double lo = (double)fminf(q[0], q[1]), hi = (double)fmaxf(q[0], q[1]);
+  lo = fmin(lo, 32767.0);
+  hi = fmin(hi, 32767.0);
+  if (lo > 0.0) lo = lo * lo;
+  if (hi > 0.0) hi = hi * hi;
+  d_thresh[2 * plane] = (int32_t)floor(lo);
+  d_thresh[2 * plane + 1] = (int32_t)floor(hi);
+  d_quantiles[2 * plane] = q[0];
+  d_quantiles[2 * plane + 1] = q[1];
+}
+
+// The p-th smallest distinct coarse bin among the four ranks' (entries < 0: resolved), or -1.
+__device__ __forceinline__ int nth_window(const int32_t* coarse, int p) {
+  int last = -1;
+  for (int it = 0; it <= p; ++it) {
+    int best = 0x7FFFFFFF;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (coarse[k] > last && coarse[k] < best) best = coarse[k];
+    if (best == 0x7FFFFFFF) return -1;
+    last = best;
+  }
+  return last;
+}
+
+// Exclusive prefix of per-thread 64-bit sums over the workgroup (Hillis-Steele in LDS).
+__device__ __forceinline__ long long block_exscan_i64(long long mine, long long* s_pre) {
+  s_pre[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 1; off < NT; off <<= 1) {
+    const long long v = (int)threadIdx.x >= off ? s_pre[threadIdx.x - off] : 0;
+    __syncthreads();
+    s_pre[threadIdx.x] += v;
+    __syncthreads();
+  }
+  return s_pre[threadIdx.x] - mine;
+}
+
 __global__ __launch_bounds__(NT) void k_edge_thresholds(const uint32_t* __restrict__ d_hist, int n_fine, int n_bins,
                                                         long long r0, long long r1, long long r2, long long r3,
                                                         float gamma_lo, float gamma_hi, int32_t* __restrict__ d_thresh,
-                                                        float* __restrict__ d_quantiles, int32_t* __restrict__ d_unresolved) {
+                                                        float* __restrict__ d_quantiles, int32_t* __restrict__ d_unresolved,
+                                                        int32_t* __restrict__ d_state, uint32_t* __restrict__ d_win_base) {
   __shared__ int s_bin[4];
+  __shared__ long long s_below[4];
   __shared__ uint32_t s_hist[FINE + COARSE];  // the plane's histogram, staged by coalesced loads (n_bins <= FINE + COARSE)
   const int plane = blockIdx.x;
   const uint32_t* hist_g = d_hist + (int64_t)plane * n_bins;
@@ -496,48 +554,92 @@ __global__ __launch_bounds__(NT) void k_edge_thresholds(const uint32_t* __restri
   const int b0 = threadIdx.x * per, b1 = min(b0 + per, n_bins);
   long long mine = 0;
   for (int b = b0; b < b1; ++b) mine += hist[b];
-  // exclusive prefix of the chunk sums (64-bit: a plane holds up to 2^31 pixels): Hillis-Steele over the workgroup
+  // exclusive prefix of the chunk sums (64-bit: a plane holds up to 2^31 pixels)
   __shared__ long long s_pre[NT];
-  s_pre[threadIdx.x] = mine;
-  __syncthreads();
-  for (int off = 1; off < NT; off <<= 1) {
-    const long long v = (int)threadIdx.x >= off ? s_pre[threadIdx.x - off] : 0;
-    __syncthreads();
-    s_pre[threadIdx.x] += v;
-    __syncthreads();
-  }
-  if (threadIdx.x < 4) s_bin[threadIdx.x] = n_bins;  // rank beyond the data: unresolved
+  long long run = block_exscan_i64(mine, s_pre);
+  if (threadIdx.x < 4) s_bin[threadIdx.x] = n_bins, s_below[threadIdx.x] = 0;  // rank beyond the data
   __syncthreads();
   const long long ranks[4] = {r0, r1, r2, r3};
-  long long run = s_pre[threadIdx.x] - mine;
   for (int b = b0; b < b1; ++b) {
     const long long nxt = run + hist[b];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (run <= ranks[k] && ranks[k] < nxt) s_bin[k] = b;  // first bin whose running sum exceeds the rank
+      if (run <= ranks[k] && ranks[k] < nxt) s_bin[k] = b, s_below[k] = run;  // first bin whose running sum exceeds the rank
     run = nxt;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const bool ok = s_bin[0] < n_fine && s_bin[1] < n_fine && s_bin[2] < n_fine && s_bin[3] < n_fine;
-    d_unresolved[plane] = ok ? 0 : 1;
-    float q[2];
+    int32_t order[4], coarse[4];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const float ga = (float)sqrt((double)s_bin[2 * k]), gb = (float)sqrt((double)s_bin[2 * k + 1]);  // == float32 sqrt
-      const float gamma = k == 0 ? gamma_lo : gamma_hi;
-      const float diff = gb - ga;
-      q[k] = gamma >= 0.5f ? gb - diff * (1.0f - gamma) : ga + diff * gamma;  // numpy's _lerp, float32 throughout
+    for (int k = 0; k < 4; ++k) {
+      const bool fine = s_bin[k] < n_fine || s_bin[k] >= n_bins;  // (a rank beyond the data cannot occur: n = h w)
+      order[k] = fine ? s_bin[k] : 0;
+      coarse[k] = fine ? -1 : s_bin[k] - n_fine;
     }
-    double lo = (double)fminf(q[0], q[1]), hi = (double)fmaxf(q[0], q[1]);
-    lo = fmin(lo, 32767.0);
-    hi = fmin(hi, 32767.0);
-    if (lo > 0.0) lo = lo * lo;
-    if (hi > 0.0) hi = hi * hi;
-    d_thresh[2 * plane] = (int32_t)floor(lo);
-    d_thresh[2 * plane + 1] = (int32_t)floor(hi);
-    d_quantiles[2 * plane] = q[0];
-    d_quantiles[2 * plane + 1] = q[1];
+    int n_win = 0;
+    while (nth_window(coarse, n_win) >= 0) ++n_win;
+    d_unresolved[plane] = n_win | (n_win << 8);  // passes still to run | passes this plane needs in all
+    if (d_state) {
+      int32_t* st = d_state + (int64_t)plane * TS_WORDS;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        st[TS_ORDER + k] = order[k];
+        st[TS_COARSE + k] = coarse[k];
+        st[TS_RESID + k] = (int32_t)(ranks[k] - s_below[k]);  // position inside the coarse bin (< its count < 2^31)
+      }
+      st[TS_NWIN] = n_win;
+    }
+    if (d_win_base) d_win_base[plane] = n_win > 0 ? (uint32_t)nth_window(coarse, 0) << 13 : MG_HIST_SKIP;
+    finish_thresholds(order, gamma_lo, gamma_hi, plane, d_thresh, d_quantiles);  // (valid when n_win == 0)
+  }
+}
+
+// Window pass `pass`: d_hist_win[plane][0 .. FINE) counts m - base exactly for the plane's pass-th distinct coarse
+// bin.  Ranks that sit in that bin get their order statistic; after the plane's last window the thresholds are
+// computed and d_unresolved[plane] drops to 0.  Writes the base of the next pass.
+__global__ __launch_bounds__(NT) void k_window_resolve(const uint32_t* __restrict__ d_hist_win, int pass, float gamma_lo,
+                                                       float gamma_hi, int32_t* __restrict__ d_state,
+                                                       uint32_t* __restrict__ d_win_base, int32_t* __restrict__ d_thresh,
+                                                       float* __restrict__ d_quantiles, int32_t* __restrict__ d_unresolved) {
+  __shared__ int s_pos[4];
+  __shared__ long long s_pre[NT];
+  const int plane = blockIdx.x;
+  int32_t* st = d_state + (int64_t)plane * TS_WORDS;
+  const int n_win = st[TS_NWIN];
+  if (pass >= n_win) return;  // block-uniform (its base was MG_HIST_SKIP: nothing was counted)
+  int32_t coarse[4], resid[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) coarse[k] = st[TS_COARSE + k], resid[k] = st[TS_RESID + k];
+  const int cbin = nth_window(coarse, pass);
+  const uint32_t* hist = d_hist_win + (int64_t)plane * FINE;
+  constexpr int PER = FINE / NT;
+  uint32_t mine_v[PER];
+  long long mine = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) mine_v[j] = hist[threadIdx.x * PER + j], mine += mine_v[j];
+  long long run = block_exscan_i64(mine, s_pre);
+  if (threadIdx.x < 4) s_pos[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const long long nxt = run + mine_v[j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (coarse[k] == cbin && run <= (long long)resid[k] && (long long)resid[k] < nxt) s_pos[k] = threadIdx.x * PER + j;
+    run = nxt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t order[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      order[k] = st[TS_ORDER + k];
+      if (coarse[k] == cbin) order[k] = (cbin << 13) + s_pos[k], st[TS_ORDER + k] = order[k];
+    }
+    const int left = n_win - 1 - pass;
+    d_unresolved[plane] = left | (n_win << 8);
+    d_win_base[plane] = left > 0 ? (uint32_t)nth_window(coarse, pass + 1) << 13 : MG_HIST_SKIP;
+    if (left == 0) finish_thresholds(order, gamma_lo, gamma_hi, plane, d_thresh, d_quantiles);
   }
 }
 
@@ -841,6 +943,161 @@ __global__ __launch_bounds__(NT) void k_hysteresis(const uint32_t* __restrict__ 
   }
 }
 
+// ---- K4b: hysteresis to the global fixed point in ONE launch -------------------------------------------------
+// Same tiles and the same tile-local fixed point as k_hysteresis, but a workgroup does not stop after its own tile:
+// when growth inside a tile reaches a weak pixel of a NEIGHBOURING tile (a weak, not yet strong pixel of the halo
+// next to a newly set bit), that tile is marked in a per-plane dirty bitmap, and every workgroup, once its tile is
+// done, keeps claiming marked tiles of its plane (atomic fetch-and) and working them off until a scan finds none.
+// Nobody ever waits for another workgroup (no barrier across workgroups, no spinning): a workgroup that marks a tile
+// scans afterwards itself, so when the last one leaves no mark is left and the bitmap is the fixed point -- whatever
+// order the hardware runs the workgroups in.  Marks are release / claims acquire at agent scope: the claimer's loads
+// see the bits that caused the mark.  A mark made by a stale view (the neighbour promoted the pixel meanwhile)
+// only costs a re-check of that tile.
+// Replaces ~8 sweep launches (each of 16 384 workgroups at 64 planes, most of which only tested a flag) whose number
+// had to be guessed ahead by the host.
+__device__ __forceinline__ uint32_t lds_word(const uint32_t (*a)[HW + 2], int r, int k) {
+  return (r >= 1 && r <= HTH && k >= 1 && k <= HW) ? a[r][k] : 0u;  // interior words only (of the diff array)
+}
+
+__global__ __launch_bounds__(NT) void k_hysteresis_full(const uint32_t* __restrict__ d_weak, uint32_t* __restrict__ d_strong,
+                                                        int64_t words_per_plane, int h, int w,
+                                                        uint32_t* __restrict__ d_dirty, int dirty_words) {
+  __shared__ uint32_t st[HTH + 2][HW + 2];
+  __shared__ uint32_t wk[HTH + 2][HW + 2];  // weak map with halo; its interior is reused for the tile's new bits
+  __shared__ int s_next, s_claimed;
+  __shared__ uint32_t s_mark;
+  const int plane = blockIdx.z;
+  const int ntx = gridDim.x, nty = gridDim.y, n_tiles = ntx * nty;
+  const uint32_t* weak = d_weak + plane * words_per_plane;
+  uint32_t* strong = d_strong + plane * words_per_plane;
+  uint32_t* dirty = d_dirty + (int64_t)plane * dirty_words;
+  const int own = blockIdx.y * ntx + blockIdx.x;
+  int tile = own;
+  constexpr int WPT = HTH * HW / NT;  // words per thread
+  static_assert(WPT * NT == HTH * HW, "the tile's words must divide evenly over the threads");
+  const int k = (threadIdx.x & (HW - 1)) + 1, r0 = WPT * (threadIdx.x / HW) + 1;  // st coordinates of the thread's words
+  for (;;) {
+    const int bx = tile % ntx, by = tile / ntx;
+    const int tx0 = bx * TW, ty0 = by * HTH;
+    int pending = 0;
+    for (int i = threadIdx.x; i < (HTH + 2) * (HW + 2); i += NT) {
+      const int r = i / (HW + 2), kk = i - r * (HW + 2);
+      const uint32_t sv = row_word(strong, h, w, ty0 - 1 + r, tx0 - 32 + 32 * kk);
+      const uint32_t wv = row_word(weak, h, w, ty0 - 1 + r, tx0 - 32 + 32 * kk);
+      st[r][kk] = sv;
+      wk[r][kk] = wv;
+      if (r >= 1 && r <= HTH && kk >= 1 && kk <= HW) pending |= (wv & ~sv) != 0;
+    }
+    if (threadIdx.x == 0) s_mark = 0u;
+    if (__syncthreads_or(pending)) {  // (else: every weak pixel of the tile is an edge already)
+      uint32_t first[WPT];  // this thread's strong words before the growth
+#pragma unroll
+      for (int j = 0; j < WPT; ++j) first[j] = st[r0 + j][k];
+      int again;
+      do {  // as k_hysteresis: grow from the 3 x 3 neighbourhood, then along the word, rows seeing the rows above
+        int changed = 0;
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+          const int r = r0 + j;
+          uint32_t cur = st[r][k];
+          uint32_t cand = wk[r][k] & ~cur;
+          if (!cand) continue;
+          uint32_t dil = 0;
+#pragma unroll
+          for (int dr = -1; dr <= 1; ++dr) {
+            const uint32_t c = st[r + dr][k], l = st[r + dr][k - 1], rt = st[r + dr][k + 1];
+            dil |= c | (c << 1) | (c >> 1) | (l >> 31) | (rt << 31);
+          }
+          uint32_t nw = cand & dil;
+          if (!nw) continue;
+          cur |= nw;
+          cand &= ~nw;
+          for (uint32_t g = cand & ((cur << 1) | (cur >> 1)); g; g = cand & ((cur << 1) | (cur >> 1))) {
+            cur |= g;
+            cand &= ~g;
+          }
+          st[r][k] = cur;
+          changed = 1;
+        }
+        again = __syncthreads_or(changed);
+      } while (again);
+      // new bits -> global memory and -> the interior of wk (the weak interior is not needed any more)
+#pragma unroll
+      for (int j = 0; j < WPT; ++j) {
+        const uint32_t diff = st[r0 + j][k] & ~first[j];
+        wk[r0 + j][k] = diff;
+        if (diff) bits_or(strong, (int64_t)(ty0 + r0 + j - 1) * w + tx0 + 32 * (k - 1), diff);  // only in-image bits can be set
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this thread's bits before the marks below
+      __syncthreads();
+      // halo pixels that are weak, not strong (as far as this tile knows) and touch a NEW bit: their tile has work
+      for (int i = threadIdx.x; i < 2 * (HW + 2) + 2 * HTH; i += NT) {
+        int r, kk;
+        if (i < HW + 2) r = 0, kk = i;
+        else if (i < 2 * (HW + 2)) r = HTH + 1, kk = i - (HW + 2);
+        else if (i < 2 * (HW + 2) + HTH) r = i - 2 * (HW + 2) + 1, kk = 0;
+        else r = i - 2 * (HW + 2) - HTH + 1, kk = HW + 1;
+        const uint32_t cand = wk[r][kk] & ~st[r][kk];
+        if (!cand) continue;
+        uint32_t dil = 0;
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr) {
+          const uint32_t c = lds_word(wk, r + dr, kk), l = lds_word(wk, r + dr, kk - 1), rt = lds_word(wk, r + dr, kk + 1);
+          dil |= c | (c << 1) | (c >> 1) | (l >> 31) | (rt << 31);
+        }
+        if (cand & dil) {
+          const int dy = r == 0 ? -1 : (r == HTH + 1 ? 1 : 0), dx = kk == 0 ? -1 : (kk == HW + 1 ? 1 : 0);
+          atomicOr(&s_mark, 1u << ((dy + 1) * 3 + dx + 1));
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t m = s_mark;
+      for (int d = 0; d < 9; ++d) {
+        if (!((m >> d) & 1u)) continue;
+        const int nx = bx + d % 3 - 1, ny = by + d / 3 - 1;
+        if (nx < 0 || nx >= ntx || ny < 0 || ny >= nty) continue;
+        const int t = ny * ntx + nx;
+        __hip_atomic_fetch_or(&dirty[t >> 5], 1u << (t & 31), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // the next marked tile of this plane, looked for from this workgroup's own tile onwards (workgroups spread over
+    // the marks instead of all going for the first); claimed by clearing its bit
+    bool got = false;
+    for (;;) {
+      if (threadIdx.x == 0) s_next = 0x7FFFFFFF;
+      __syncthreads();
+      for (int wd = threadIdx.x; wd < dirty_words; wd += NT) {
+        uint32_t v = __hip_atomic_load(&dirty[wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (v) {
+          const int t = 32 * wd + __ffs(v) - 1;
+          v &= v - 1;
+          int key = t - own;
+          if (key < 0) key += n_tiles;
+          atomicMin(&s_next, key);
+        }
+      }
+      __syncthreads();
+      const int key = s_next;
+      if (key == 0x7FFFFFFF) break;  // nothing marked: done (block-uniform)
+      const int t = (own + key) % n_tiles;
+      if (threadIdx.x == 0) {
+        const uint32_t old = __hip_atomic_fetch_and(&dirty[t >> 5], ~(1u << (t & 31)), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_claimed = (old >> (t & 31)) & 1u;
+      }
+      __syncthreads();
+      if (s_claimed) {
+        tile = t;
+        got = true;
+        break;
+      }
+    }
+    if (!got) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the loads of the claimed tile see the bits behind its mark
+  }
+}
+
 // ---- inspection: bitmap -> {0,1} bytes ------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_unpack_bits(const uint32_t* __restrict__ d_bits, int64_t words_per_plane,
                                                     int64_t npix, uint8_t* __restrict__ d_out) {
@@ -1121,7 +1378,7 @@ extern "C" int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w,
   if (d_scratch) {
     const int slots = (int)(g.x * g.y);
     hipLaunchKernelGGL(k_hist_reduce, dim3((n_bins / 2 + NT - 1) / NT, n_planes, (slots + HIST_SLOTS_PER_BLOCK - 1) / HIST_SLOTS_PER_BLOCK),
-                       dim3(NT), 0, mg_stream(stream), d_scratch, slots, n_bins, d_hist);
+                       dim3(NT), 0, mg_stream(stream), d_scratch, slots, n_bins, d_hist, mode == 1 ? d_base : nullptr);
     MG_CHECK_LAUNCH();
   }
   return MG_OK;
@@ -1129,12 +1386,26 @@ extern "C" int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w,
 
 extern "C" int mg_edge_thresholds(const uint32_t* d_hist, int n_planes, const int64_t* ranks4, float gamma_low,
                                   float gamma_high, int32_t* d_thresh, float* d_quantiles, int32_t* d_unresolved,
-                                  void* stream) {
+                                  int32_t* d_state, uint32_t* d_win_base, void* stream) {
   if (!d_hist || !ranks4 || !d_thresh || !d_quantiles || !d_unresolved || n_planes < 0) return MG_EINVAL;
+  if ((d_state == nullptr) != (d_win_base == nullptr)) return MG_EINVAL;
   if (n_planes == 0) return MG_OK;
   hipLaunchKernelGGL(k_edge_thresholds, dim3(n_planes), dim3(NT), 0, mg_stream(stream), d_hist, FINE, FINE + COARSE,
                      (long long)ranks4[0], (long long)ranks4[1], (long long)ranks4[2], (long long)ranks4[3], gamma_low,
-                     gamma_high, d_thresh, d_quantiles, d_unresolved);
+                     gamma_high, d_thresh, d_quantiles, d_unresolved, d_state, d_win_base);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_edge_thresholds_window(const uint32_t* d_hist_win, int n_planes, int pass, float gamma_low,
+                                         float gamma_high, int32_t* d_state, uint32_t* d_win_base, int32_t* d_thresh,
+                                         float* d_quantiles, int32_t* d_unresolved, void* stream) {
+  if (!d_hist_win || !d_state || !d_win_base || !d_thresh || !d_quantiles || !d_unresolved || n_planes < 0 || pass < 0 ||
+      pass > 3)
+    return MG_EINVAL;
+  if (n_planes == 0) return MG_OK;
+  hipLaunchKernelGGL(k_window_resolve, dim3(n_planes), dim3(NT), 0, mg_stream(stream), d_hist_win, pass, gamma_low,
+                     gamma_high, d_state, d_win_base, d_thresh, d_quantiles, d_unresolved);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -1170,6 +1441,22 @@ extern "C" int mg_canny_hysteresis(const uint32_t* d_weak, uint32_t* d_strong, i
   if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
   hipLaunchKernelGGL(k_hysteresis, g, dim3(NT), 0, mg_stream(stream), d_weak, d_strong, words_per_plane, h, w,
                      d_changed, d_flags_in, d_flags_out);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_canny_hysteresis_full(const uint32_t* d_weak, uint32_t* d_strong, int64_t words_per_plane, int n_planes,
+                                       int h, int w, uint32_t* d_dirty, int64_t dirty_words, void* stream) {
+  if (!d_weak || !d_strong || !d_dirty || n_planes < 0 || h < 0 || w < 0) return MG_EINVAL;
+  if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
+  if (!words_ok(words_per_plane, h, w)) return MG_EINVAL;
+  const dim3 g((w + TW - 1) / TW, (h + HTH - 1) / HTH, n_planes);
+  if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
+  const int per_plane = (int)((g.x * g.y + 31) / 32);
+  if (dirty_words < (int64_t)per_plane * n_planes) return MG_EINVAL;
+  hipStream_t s = mg_stream(stream);
+  if (hipMemsetAsync(d_dirty, 0, (size_t)per_plane * n_planes * 4, s) != hipSuccess) return MG_ELAUNCH;
+  hipLaunchKernelGGL(k_hysteresis_full, g, dim3(NT), 0, s, d_weak, d_strong, words_per_plane, h, w, d_dirty, per_plane);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -152,7 +152,7 @@ __device__ __forceinline__ DiskMasks build_disk_masks(uint32_t* base, int len, i
   return m;
 }
 
-__device__ __forceinline__ int mask_words(int len) { return 3 * len * ((len + 31) >> 5); }
+inline __host__ __device__ int mask_words(int len) { return 3 * len * ((len + 31) >> 5); }
 inline size_t roi_lds_bytes(int len, bool disks) {
   const size_t fl = ((size_t)len * len + 3) & ~(size_t)3;
   return fl + (disks ? (size_t)3 * len * ((len + 31) >> 5) * 4 : 0);
@@ -267,9 +267,22 @@ __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64
 }
 
 // ---- fast path: uint16 image, even window length <= 126, even image width -------------------------
-// One wave per window row, one dword (2 pixels) per lane: aligned 4-byte loads (odd source offsets
-// are funnel-shifted from two neighbouring dwords), 4-byte roi stores, 2-byte mask stores.
-template <int U>
+// One wave per window row, one dword (2 pixels) per lane: aligned 4-byte loads (odd source offsets are funnel-shifted
+// from the neighbouring lane's dword, fetched by a whole-wave DPP shift), 4-byte roi stores, 2-byte mask stores.
+// The masks live in LDS as two BIT rows per window row (fg, bg); a lane turns its two bits into the 0/1 halves of a
+// packed-u16 multiplier once per row and applies it to CTB (channel, time) planes at a time: one v_dot2_u32_u16 per
+// dword and mask.  All sums fit 32 bits (126^2 pixels x 65535 < 2^32) up to the final conversion.
+// (Before: byte flags in LDS and four conditional 64-bit adds per dword -- 53 wave-instructions per row and plane,
+// the VALU 85 % busy at the HBM ceiling.)
+typedef unsigned short roi_us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t roi_dot2(uint32_t v, uint32_t m, uint32_t acc) {
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(roi_us2, v), __builtin_bit_cast(roi_us2, m), acc, false);
+}
+// bits 0, 1 of b -> the 0/1 halves of a packed pair
+__device__ __forceinline__ uint32_t roi_pair(uint32_t b) { return (b & 1u) | ((b & 2u) << 15); }
+
+template <int U, int CTB, bool PIPE>
 __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict__ d_image, int64_t assay_stride,
                                                      int n_c, int n_t, int h, int w,
                                                      const int32_t* __restrict__ d_beads,
@@ -281,9 +294,10 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
                                                      uint16_t* __restrict__ d_roi, uint8_t* __restrict__ d_fg,
                                                      uint8_t* __restrict__ d_bg, double* __restrict__ d_sums,
                                                      int32_t* __restrict__ d_counts) {
-  extern __shared__ __attribute__((aligned(4))) uint8_t flags[];  // [len][len]: bit 0 fg, bit 1 bg
-  __shared__ long long s_red[2][NT / 64];
-  __shared__ int s_cnt[2][NT / 64];
+  extern __shared__ __attribute__((aligned(4))) uint8_t smem[];  // three bit-row arrays of len x wpr words
+  constexpr int WV = NT / 64;
+  __shared__ uint32_t s_red[2][CTB][WV];
+  __shared__ int s_cnt[2][WV];
   // label mode: one block per marker of a flat list; disk mode: grid (local index, assay)
   int g = blockIdx.x, assay, first = 0, local;
   int64_t bead0 = 0, gb = g;  // the assay's first bead / this marker's bead in d_beads
@@ -307,28 +321,41 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = 2 * lane;
   const bool act = lane < half;
-  const int32_t* lab = d_labels ? d_labels + (int64_t)assay * h * w : nullptr;
-  DiskMasks dm{};
-  if (d_halfwidths)
-    dm = build_disk_masks(reinterpret_cast<uint32_t*>(flags + ((n + 3) & ~3)), len, top, left,
-                          d_beads + 3 * bead0, d_assay_offsets[assay + 1] - first, local, d_halfwidths, max_r);
+  const int wpr = (len + 31) >> 5, words = len * wpr;
+  uint32_t* base = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* fgw = base + 2 * words;  // (disk mode: `own`, narrowed in place)
+  uint32_t* bgw = base;              // (disk mode: `any`, complemented in place)
   int cf = 0, cb = 0;
-  for (int ry = wave; ry < len; ry += NT / 64) {
-    if (!act) continue;
-    uint32_t f0 = 0, f1 = 0, b0 = 0, b1 = 0;
-    if (d_halfwidths) {
-      dm.flags(ry, x, f0, b0);
-      dm.flags(ry, x + 1, f1, b1);
-    } else if (lab) {
-      const int32_t* lp = lab + (int64_t)(top + ry) * w + left + x;
-      const int v0 = lp[0], v1 = lp[1];
-      f0 = v0 == local, f1 = v1 == local, b0 = v0 == -1, b1 = v1 == -1;
+  if (d_halfwidths) {
+    const DiskMasks dm = build_disk_masks(base, len, top, left, d_beads + 3 * bead0, d_assay_offsets[assay + 1] - first,
+                                          local, d_halfwidths, max_r);
+    // fg = own and not contested, bg = covered by nobody (the bits of a row's last word beyond the window stay 0)
+    for (int i = threadIdx.x; i < words; i += NT) {
+      const int wd = i % wpr;
+      const uint32_t valid = (len - 32 * wd >= 32) ? 0xFFFFFFFFu : ((1u << (len - 32 * wd)) - 1u);
+      const uint32_t f = dm.own[i] & ~dm.multi[i], b = ~dm.any[i] & valid;
+      fgw[i] = f;
+      bgw[i] = b;
+      cf += __popc(f);
+      cb += __popc(b);
     }
-    *reinterpret_cast<uint16_t*>(&flags[ry * len + x]) = (uint16_t)((f0 | (b0 << 1)) | ((f1 | (b1 << 1)) << 8));
-    if (d_fg) *reinterpret_cast<uint16_t*>(&d_fg[(int64_t)g * n + ry * len + x]) = (uint16_t)(f0 | (f1 << 8));
-    if (d_bg) *reinterpret_cast<uint16_t*>(&d_bg[(int64_t)g * n + ry * len + x]) = (uint16_t)(b0 | (b1 << 8));
-    cf += f0 + f1;
-    cb += b0 + b1;
+  } else {
+    for (int i = threadIdx.x; i < 3 * words; i += NT) base[i] = 0u;
+    __syncthreads();
+    if (d_labels) {
+      const int32_t* lab = d_labels + (int64_t)assay * h * w;
+      for (int ry = wave; ry < len; ry += WV) {
+        if (!act) continue;
+        const int32_t* lp = lab + (int64_t)(top + ry) * w + left + x;
+        const int v0 = lp[0], v1 = lp[1];
+        const uint32_t f = (uint32_t)(v0 == local) | ((uint32_t)(v1 == local) << 1);
+        const uint32_t b = (uint32_t)(v0 == -1) | ((uint32_t)(v1 == -1) << 1);
+        if (f) atomicOr(&fgw[ry * wpr + (x >> 5)], f << (x & 31));
+        if (b) atomicOr(&bgw[ry * wpr + (x >> 5)], b << (x & 31));
+        cf += __popc(f);
+        cb += __popc(b);
+      }
+    }
   }
   cf = mg_wave_sum_i32(cf);
   cb = mg_wave_sum_i32(cb);
@@ -336,68 +363,108 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
     s_cnt[0][wave] = cf;
     s_cnt[1][wave] = cb;
   }
-  __syncthreads();
+  __syncthreads();  // bit rows complete, counts in place
   if (threadIdx.x == 0 && d_counts) {
     d_counts[2 * (int64_t)g] = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
     d_counts[2 * (int64_t)g + 1] = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
   }
+  const int mword = x >> 5, msh = x & 31;  // this lane's two bits inside a bit row
+  if (d_fg || d_bg) {
+    for (int ry = wave; ry < len; ry += WV) {
+      if (!act) continue;
+      const uint32_t f = (fgw[ry * wpr + mword] >> msh) & 3u, b = (bgw[ry * wpr + mword] >> msh) & 3u;
+      if (d_fg) *reinterpret_cast<uint16_t*>(&d_fg[(int64_t)g * n + ry * len + x]) = (uint16_t)((f & 1u) | ((f & 2u) << 7));
+      if (d_bg) *reinterpret_cast<uint16_t*>(&d_bg[(int64_t)g * n + ry * len + x]) = (uint16_t)((b & 1u) | ((b & 2u) << 7));
+    }
+  }
   const uint16_t* img = d_image + (int64_t)assay * assay_stride;
-  for (int ct = 0; ct < n_c * n_t; ++ct) {
-    const uint16_t* plane = img + (int64_t)(time_major ? (ct % n_t) * n_c + ct / n_t : ct) * h * w;
-    uint16_t* out = d_roi ? d_roi + ((int64_t)g * n_c * n_t + ct) * n : nullptr;
-    long long sf = 0, sb = 0;
-    // rows are handled U at a time per wave: all U row loads are in flight before the first is
-    // consumed (the gather is latency-bound otherwise: one 256-byte request per wave at a time)
-    constexpr int WV = NT / 64;
-    for (int r0 = wave; r0 < len; r0 += WV * U) {
-      uint32_t dd[U];
-      int oddv[U];
+  const int nct = n_c * n_t;
+  // w is even: every row of the window starts at the same parity.  An odd start is read from one element before
+  // (aligned dwords) and funnel-shifted; its last dword then ends one element behind the window -- inside the image
+  // row, because left + len == w would make left even.
+  const int odd = left & 1;
+  const uint32_t shift = odd ? 16u : 0u;
+  const uint32_t lidx = (uint32_t)min(lane, half - 1 + odd);  // idle lanes repeat the last dword: no branch around a load
+  const int64_t plane_elems = (int64_t)h * w;
+  for (int ct0 = 0; ct0 < nct; ct0 += CTB) {
+    // outputs are (channel, time)-ordered; the image block may be stored time-major (t, c, h, w)
+    const uint32_t* plane[CTB];
+    uint32_t* out[CTB];
+#pragma unroll
+    for (int c = 0; c < CTB; ++c) {
+      const int ct = min(ct0 + c, nct - 1);
+      plane[c] = reinterpret_cast<const uint32_t*>(img + (int64_t)(time_major ? (ct % n_t) * n_c + ct / n_t : ct) * plane_elems);
+      out[c] = d_roi ? reinterpret_cast<uint32_t*>(d_roi + ((int64_t)g * nct + ct) * n) : nullptr;
+    }
+    uint32_t sf[CTB], sb[CTB];
+#pragma unroll
+    for (int c = 0; c < CTB; ++c) sf[c] = 0u, sb[c] = 0u;
+    // U rows x CTB planes per trip and wave, software-pipelined: the loads of the NEXT trip are issued before this
+    // trip's dwords are shifted, stored and summed (the gather is latency-bound otherwise: a wave would sit out a
+    // full load round trip, and the write acknowledgements of its stores, between two batches of requests)
+    auto load_rows = [&](int r0, uint32_t (&dd)[U][CTB]) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int ry = r0 + u * WV;
-        dd[u] = 0;
-        oddv[u] = 0;
-        if (ry < len) {
-          const int64_t e0 = (int64_t)(top + ry) * w + left;  // element offset of the row start in the plane
-          const int odd = (int)(e0 & 1);
-          const uint32_t* src = reinterpret_cast<const uint32_t*>(plane + (e0 - odd));
-          if (lane < half) dd[u] = src[lane];
-          else if (lane == half && odd) dd[u] = plane[e0 + len - 1];  // last pixel of the row, no over-read
-          oddv[u] = odd;
-        }
+        const int ry = min(r0 + u * WV, len - 1);
+        const uint32_t di = (uint32_t)(((top + ry) * w + left - odd) >> 1) + lidx;  // dword index in the plane (h w < 2^31)
+#pragma unroll
+        for (int c = 0; c < CTB; ++c) dd[u][c] = plane[c][di];
+      }
+    };
+    uint32_t dd[U][CTB], dn[U][CTB];
+    load_rows(wave, dd);
+    for (int r0 = wave; r0 < len; r0 += WV * U) {
+      if (PIPE) {
+        load_rows(r0 + WV * U, dn);  // (rows beyond the window repeat its last row: no branch)
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int ry = r0 + u * WV;
         if (ry >= len) break;  // wave-uniform
-        const uint32_t d = dd[u];
-        const uint32_t nx = (uint32_t)__shfl_down((int)d, 1);
-        const uint32_t v = oddv[u] ? ((d >> 16) | (nx << 16)) : d;
-        if (act) {
-          if (out) *reinterpret_cast<uint32_t*>(&out[ry * len + x]) = v;
-          const uint32_t fl = *reinterpret_cast<const uint16_t*>(&flags[ry * len + x]);
-          const long long p0 = v & 0xFFFFu, p1 = v >> 16;
-          if (fl & 0x0001u) sf += p0;
-          if (fl & 0x0100u) sf += p1;
-          if (fl & 0x0002u) sb += p0;
-          if (fl & 0x0200u) sb += p1;
+        const uint32_t mf = roi_pair((fgw[ry * wpr + mword] >> msh) & 3u), mb = roi_pair((bgw[ry * wpr + mword] >> msh) & 3u);
+        const uint32_t oi = (uint32_t)(ry * half + lane);
+#pragma unroll
+        for (int c = 0; c < CTB; ++c) {
+          if (ct0 + c >= nct) break;  // uniform
+          const uint32_t d = dd[u][c];
+          const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x130, 0xF, 0xF, false);  // lane + 1
+          const uint32_t v = __builtin_amdgcn_alignbit(nx, d, shift);
+          if (act) {
+            if (out[c]) out[c][oi] = v;
+            sf[c] = roi_dot2(v, mf, sf[c]);
+            sb[c] = roi_dot2(v, mb, sb[c]);
+          }
         }
+      }
+      if (PIPE) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int c = 0; c < CTB; ++c) dd[u][c] = dn[u][c];
+      } else if (r0 + WV * U < len) {
+        load_rows(r0 + WV * U, dd);
       }
     }
     if (d_sums) {
-      sf = mg_wave_sum_i64(sf);
-      sb = mg_wave_sum_i64(sb);
-      __syncthreads();
-      if (lane == 0) {
-        s_red[0][wave] = sf;
-        s_red[1][wave] = sb;
+#pragma unroll
+      for (int c = 0; c < CTB; ++c) {
+        const uint32_t a = (uint32_t)mg_wave_scan_incl_i32((int)sf[c]), b = (uint32_t)mg_wave_scan_incl_i32((int)sb[c]);
+        if (lane == 63) {
+          s_red[0][c][wave] = a;
+          s_red[1][c][wave] = b;
+        }
       }
       __syncthreads();
-      if (threadIdx.x == 0) {
-        double* o = d_sums + ((int64_t)g * n_c * n_t + ct) * 2;
-        o[0] = (double)(s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3]);
-        o[1] = (double)(s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]);
+      if ((int)threadIdx.x < 2 * CTB) {
+        const int k = threadIdx.x & 1, c = threadIdx.x >> 1;
+        if (ct0 + c < nct) {
+          uint32_t tot = 0;
+#pragma unroll
+          for (int q = 0; q < WV; ++q) tot += s_red[k][c][q];
+          d_sums[((int64_t)g * nct + ct0 + c) * 2 + k] = (double)tot;
+        }
       }
+      __syncthreads();
     }
   }
 }
@@ -506,10 +573,12 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
   hipStream_t s = mg_stream(stream);
   const dim3 grid = d_assay_offsets ? dim3(max_per_assay, n_assays) : dim3(m);
   if (dtype == MG_U16 && (roi_len & 1) == 0 && roi_len <= 126 && (w & 1) == 0 && (assay_stride & 1) == 0 &&
+      (int64_t)h * w < (1LL << 31) &&
       (reinterpret_cast<uintptr_t>(d_image) & 3) == 0 && (!d_roi || (reinterpret_cast<uintptr_t>(d_roi) & 3) == 0) &&
       (!d_fg || (reinterpret_cast<uintptr_t>(d_fg) & 1) == 0) && (!d_bg || (reinterpret_cast<uintptr_t>(d_bg) & 1) == 0)) {
-    // 4 row loads in flight per wave (2..13 measured: 4-7 are equally fast, 2 is 30 % slower)
-    hipLaunchKernelGGL(k_roi_u16_even<4>, grid, dim3(NT), roi_lds_bytes(roi_len, d_halfwidths != nullptr), s,
+    // 2 rows x 4 planes per trip, next trip's loads in flight while this one is worked on (measured at 16 x 4 x 4096^2:
+    // 1.14 ms; without the pipelining 1.22, one row per trip 1.22, 4 rows x 2 planes 1.20, 4 x 4 unpipelined 1.24)
+    hipLaunchKernelGGL((k_roi_u16_even<2, 4, true>), grid, dim3(NT), (size_t)mask_words(roi_len) * 4, s,
                        (const uint16_t*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
                        roi_len, d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg,
                        d_sums, d_counts);

@@ -308,11 +308,20 @@ class CircleFinder:
          self.num_surv, self.num_circles) = (self.status[k] for k in range(8))
         self.changed, self.undecided = self.status[8: 8 + G], self.status[8 + G: 8 + 2 * G]
         self.status_host = torch.zeros((8 + 2 * G, P), dtype=i32).pin_memory()
-        self._thresh_on_host, self._quantiles = False, None
+        self._quantiles = None
+        # window passes of the threshold search (ranks inside coarse histogram bins), all on the device: per-plane state
+        # block, the base of the next pass, the window histogram (allocated when a shape first needs a pass)
+        self.win_state = torch.zeros((P, 16), dtype=i32, device=dev)
+        self.hist_win = None
+        self._recent_win = []
         tx, ty = nat.C.c_int(0), nat.C.c_int(0)
         nat.check(nat.lib().mg_hysteresis_tiles(h, w, nat.C.byref(tx), nat.C.byref(ty)), "mg_hysteresis_tiles")
         # active-tile flags of the hysteresis sweeps, one layer per sweep of a group (+ the last layer of the group before)
         self.tile_flags = torch.zeros((G + 1, P, ty.value, tx.value), dtype=u8, device=dev)
+        # one-launch hysteresis (mg_canny_hysteresis_full) with its per-plane bitmap of marked tiles; MG_HYST_SWEEPS=1
+        # keeps the sweep-per-launch kernel (A/B measurements, parity of the two)
+        self.hyst_full = not os.environ.get("MG_HYST_SWEEPS")
+        self.hyst_dirty = torch.zeros((P, (ty.value * tx.value + 31) // 32), dtype=i32, device=dev)
         self.scan_state = torch.zeros((max(1, int(nat.lib().mg_edge_grid_scan_words(P, h, w, self.grid))),),
                                       dtype=torch.int64, device=dev)
         # Optimistic chain (see find): sweeps / rounds / capacities taken from the calls before, everything checked
@@ -411,32 +420,35 @@ class CircleFinder:
               self.hist_scratch.numel(), s)
         n = h * w
         idx = [quantile_indexes(n, q) for q in (low_q, high_q)]  # (prev, next, gamma) per quantile
-        # Thresholds on the device (mg_edge_thresholds: no host round trip, no ATen kernels) unless the previous call
-        # showed that this kind of image needs the window passes (ranks inside coarse bins: noiseless images);
-        # whether they were needed THIS time rides on the hysteresis convergence check below.
-        on_device = not self._thresh_on_host
-        assert on_device or not optimistic
-        if on_device:
-            ranks4 = np.array([idx[0][0], idx[0][1], idx[1][0], idx[1][1]], dtype=np.int64)
-            _call("mg_edge_thresholds", self.hist.data_ptr(), P, ranks4.ctypes.data, float(idx[0][2]), float(idx[1][2]),
-                  self.thresh.data_ptr(), self.quant_d.data_ptr(), self.unresolved.data_ptr(), s)
-            self._quantiles = None
-            self.stats["hist_passes"] = 1
-        else:
-            self._thresholds_on_host(idx, n)
+        # Thresholds on the device (mg_edge_thresholds: no host round trip, no ATen kernels).  Ranks inside coarse bins
+        # (strong gradients: noiseless images, the chip's chamber windows) take window passes that stay on the device as
+        # well (_window_pass); as many are launched without looking as the calls before needed, and whether they
+        # sufficed THIS time rides on the hysteresis convergence check below (status row `unresolved`).
+        ranks4 = np.array([idx[0][0], idx[0][1], idx[1][0], idx[1][1]], dtype=np.int64)
+        self._gammas = (float(idx[0][2]), float(idx[1][2]))
+        _call("mg_edge_thresholds", self.hist.data_ptr(), P, ranks4.ctypes.data, self._gammas[0], self._gammas[1],
+              self.thresh.data_ptr(), self.quant_d.data_ptr(), self.unresolved.data_ptr(), self.win_state.data_ptr(),
+              self.hist_base.data_ptr(), s)
+        self._quantiles = None
+        n_win = max(self._recent_win) if self._recent_win else 0
+        for k in range(n_win):
+            self._window_pass(k)
+        self.stats["hist_passes"] = 1 + n_win
         if optimistic:
             self._canny()
-            self._sweeps(0, min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP))
+            self._sweeps(0, 1 if self.hyst_full else min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP))
             self._edge_grid(3)
             n_edges = None
         else:
-            n_edges, sweeps, needed, unresolved = self._edges_from_thresholds(on_device)
-            if on_device and unresolved:
-                self._thresh_on_host = True
-                self._thresholds_on_host(idx, n)
-                n_edges, sweeps, needed, _ = self._edges_from_thresholds(False)
-            elif not on_device and self.stats["hist_passes"] == 1:
-                self._thresh_on_host = False  # every rank sat in a fine bin: the device path serves the next call
+            n_edges, sweeps, needed, unresolved = self._edges_from_thresholds()
+            if unresolved:  # more window passes than launched: one at a time until every plane is resolved, then again
+                while unresolved:
+                    self._window_pass(n_win)
+                    n_win += 1
+                    unresolved = bool((self._fetch_status()[2] & 0xFF).any())
+                self.stats["hist_passes"] = 1 + n_win
+                n_edges, sweeps, needed, _ = self._edges_from_thresholds()
+            self._note(self._recent_win, int(self.status_host.numpy()[2].max()) >> 8)  # what the planes needed
             self.stats["hysteresis_sweeps"] = sweeps
             self._note(self._recent_sweeps, needed)
             need_cap = max(1, int(n_edges.max()))
@@ -462,6 +474,12 @@ class CircleFinder:
     def _sweeps(self, done, group):
         """Hysteresis sweeps done .. done + group - 1; sweep k of the group counts its changes in self.changed[k]
         (cleared by the caller) and writes the tile flags of layer k + 1 (layer 0: the flags of the sweep before)."""
+        if self.hyst_full:  # to the global fixed point in one launch: the sweep after it would change nothing
+            if done == 0:
+                _call("mg_canny_hysteresis_full", self.weak_bits.data_ptr(), self.edge_bits.data_ptr(), self.words, self.P, self.h,
+                      self.w, self.hyst_dirty.data_ptr(), self.hyst_dirty.numel(), _stream(), stage="mg_canny_hysteresis")
+            self._last_layer = group
+            return
         flags = self.tile_flags
         if done > 0:
             flags[0].copy_(flags[self._last_layer])
@@ -479,73 +497,31 @@ class CircleFinder:
               coords.shape[1] if coords is not None else 0, self.scan_state.data_ptr(), self.edge_totals.data_ptr(), phases,
               _stream())
 
-    def _thresholds_on_host(self, idx, n):
-        """The rank search with window passes for ranks in coarse bins (strong gradients), np.quantile's
-        interpolation and cv::Canny's threshold preparation; sets self.thresh."""
-        L, P, h, w, s = nat.lib(), self.P, self.h, self.w, _stream()
-        ranks = sorted({i for a, b, _ in idx for i in (a, b)})
-        # bin of every needed rank, per plane (searched on the device: only P x 4 integers come back);
-        # fine bins give the order statistic directly
-        ccum_d = torch.cumsum(self.hist.to(torch.int64), dim=1)
-        ranks_d = torch.tensor(ranks, dtype=torch.int64, device=self.dev).expand(P, -1).contiguous()
-        bins_d = torch.searchsorted(ccum_d, ranks_d, right=True)
-        bins = bins_d.cpu().numpy()
-        order_stat = np.where(bins < FINE_BINS, bins, -1).astype(np.int64)
-        n_pass = 0
-        if (bins >= FINE_BINS).any():
-            # Window pass(es): ranks that fell into a coarse bin (strong gradients) are resolved by a fine
-            # histogram of that bin's value window.  Per plane: its distinct coarse bins in ascending
-            # order, one per pass; the look-ups stay on the device (only P x 4 integers come back).
-            big = 1 << 30
-            c = np.where(bins >= FINE_BINS, bins - FINE_BINS, big)
-            c.sort(axis=1)
-            c[:, 1:][c[:, 1:] == c[:, :-1]] = big
-            c.sort(axis=1)
-            cnt = (c < big).sum(axis=1)
-            n_pass = int(cnt.max())
-            order_d = torch.where(bins_d < FINE_BINS, bins_d, torch.full_like(bins_d, -1))
-            rows = np.arange(P)
-            for k in range(n_pass):
-                base_bins = np.where(cnt > 0, c[rows, np.minimum(k, np.maximum(cnt - 1, 0))], 0).astype(np.int64)
-                base_d = torch.from_numpy(base_bins).to(self.dev)
-                self.hist_base.copy_((base_d << COARSE_SHIFT).to(torch.int32))
-                fine = self.hist.view(-1)[: P * FINE_BINS].view(P, FINE_BINS)
-                fine.zero_()
-                _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 1, self.hist_base.data_ptr(), fine.data_ptr(),
-                      self.hist_scratch.data_ptr(), self.hist_scratch.numel(), s)
-                fcum_d = torch.cumsum(fine.to(torch.int64), dim=1)
-                below_d = ccum_d.gather(1, (FINE_BINS + base_d - 1).clamp_(min=0)[:, None])  # values below the bin
-                pos_d = torch.searchsorted(fcum_d, (ranks_d - below_d).contiguous(), right=True)
-                hit = bins_d == (FINE_BINS + base_d)[:, None]
-                order_d = torch.where(hit, (base_d[:, None] << COARSE_SHIFT) + pos_d, order_d)
-            order_stat = order_d.cpu().numpy()
-        self.stats["hist_passes"] = 1 + n_pass
-        # np.quantile's interpolation and cv::Canny's threshold preparation, vectorised over the planes
-        # (same float32 / float64 operations as quantile_indexes / lerp_f32 / canny_int_thresholds)
-        vals = []
-        for a, b, gamma in idx:
-            ga = np.sqrt(order_stat[:, ranks.index(a)].astype(np.float32))  # _grad_of
-            gb = np.sqrt(order_stat[:, ranks.index(b)].astype(np.float32))
-            diff = (gb - ga).astype(np.float32)
-            vals.append((gb - diff * np.float32(1 - gamma)).astype(np.float32) if gamma >= 0.5
-                        else (ga + diff * gamma).astype(np.float32))
-        self._quantiles = np.stack(vals, axis=1).astype(np.float32)
-        lo = np.minimum(vals[0], vals[1]).astype(np.float64)
-        hi = np.maximum(vals[0], vals[1]).astype(np.float64)
-        lo, hi = np.minimum(lo, 32767.0), np.minimum(hi, 32767.0)
-        lo, hi = np.where(lo > 0, lo * lo, lo), np.where(hi > 0, hi * hi, hi)
-        thresh = np.stack([np.floor(lo), np.floor(hi)], axis=1).astype(np.int32)
-        self.thresh.copy_(torch.from_numpy(thresh))
+    def _window_pass(self, k):
+        """Window pass k of the threshold search: the planes whose k-th distinct coarse bin holds one of their ranks
+        re-histogram that bin exactly (base in self.hist_base, written by the kernel before; other planes are skipped)
+        and resolve the ranks in it; a plane's last pass writes its thresholds."""
+        if k > 3:
+            raise RuntimeError("edge thresholds: more than four window passes")  # four ranks = at most four bins
+        P = self.P
+        if self.hist_win is None:
+            self.hist_win = torch.zeros((P, FINE_BINS), dtype=torch.int32, device=self.dev)
+        else:
+            self.hist_win.zero_()
+        _call("mg_scharr_hist", self.blur.data_ptr(), P, self.h, self.w, 1, self.hist_base.data_ptr(), self.hist_win.data_ptr(),
+              self.hist_scratch.data_ptr(), self.hist_scratch.numel(), _stream())
+        _call("mg_edge_thresholds_window", self.hist_win.data_ptr(), P, k, self._gammas[0], self._gammas[1],
+              self.win_state.data_ptr(), self.hist_base.data_ptr(), self.thresh.data_ptr(), self.quant_d.data_ptr(),
+              self.unresolved.data_ptr(), _stream(), stage="mg_edge_thresholds")
 
-
-    def _edges_from_thresholds(self, fetch_unresolved):
+    def _edges_from_thresholds(self):
         """Canny NMS + hysteresis to convergence + the cell counts of the edge grid, from self.thresh.
-        Returns (n_edges per plane, sweeps run, sweeps needed, any plane whose device thresholds were unresolved)."""
+        Returns (n_edges per plane, sweeps run, sweeps needed, any plane whose thresholds still need window passes)."""
         self._canny()
         sweeps, unresolved, needed = 0, False, 0
         # sweeps per host check: first as many as the calls before needed (a sweep after convergence only
         # runs the tile-flag test), then two at a time -- one host round trip in the steady state
-        group = min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP)
+        group = 1 if self.hyst_full else min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP)
         while True:
             self.changed[:group].zero_()
             self._sweeps(sweeps, group)
@@ -555,7 +531,7 @@ class CircleFinder:
             self._edge_grid(1)
             st = self._fetch_status()
             per_sweep, n_edges = st[8: 8 + group].sum(axis=1), st[0].copy()
-            unresolved = bool(fetch_unresolved and st[2].any())
+            unresolved = bool((st[2] & 0xFF).any())
             if unresolved:  # these edges come from invalid thresholds: the caller redoes them
                 needed = sweeps
                 break
@@ -750,7 +726,7 @@ class CircleFinder:
         sweeps converged, the coordinate list and the output were large enough and the rounds converged.  Anything
         else is repaired from that point with the checked chain (the results are the same either way: every stage is
         a pure function of its inputs; a plane whose edges overflowed the list was skipped by the kernels after it)."""
-        opt = (self.optimistic and not self._thresh_on_host and self.coords is not None and self._out_cap > 0
+        opt = (self.optimistic and self.coords is not None and self._out_cap > 0
                and bool(self._recent_sweeps) and (min_dist <= 0 or bool(self._recent_rounds)))
         self.stats["optimistic"] = False
         if opt:
@@ -761,13 +737,14 @@ class CircleFinder:
             st = self._fetch_status()
             sweeps = self._last_layer
             per_sweep = st[8: 8 + sweeps].sum(axis=1)
-            edges_ok = (not st[2].any() and per_sweep[sweeps - 1] == 0
+            edges_ok = (not (st[2] & 0xFF).any() and per_sweep[sweeps - 1] == 0
                         and int(st[1].max()) <= self.coords.shape[1])
             if edges_ok:
                 n_edges = st[0].copy()
                 self.n_edges_host = n_edges
                 self.stats.update(hysteresis_sweeps=sweeps, optimistic=True)
                 self._note(self._recent_sweeps, int(np.argmax(per_sweep == 0)) + 1)
+                self._note(self._recent_win, int(st[2].max()) >> 8)
                 max_alive = int(st[3].max())
                 if max_alive > bufs[0].shape[1]:  # the ordered output did not fit: gather it again (the rounds hold)
                     bufs = self._out_buffers(max_alive)

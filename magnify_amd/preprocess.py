@@ -119,10 +119,11 @@ def _field(value):
                                       "(preprocess.py:66-73) is broken; pass a TIFF file or an array")
         if not path.exists():
             raise FileNotFoundError(str(path))
-        from . import reader
+        from . import tiff
 
-        pages, dims, _ = reader._open_tiff(str(path))
-        return np.asarray(pages[0]) if not dims else np.stack(pages)
+        with tiff.TiffFile(str(path)) as tif:  # (tifffile.imread in the reference: every page of the file)
+            pages = [tif.asarray(i) for i in range(len(tif))]
+        return pages[0] if len(pages) == 1 else np.stack(pages)
     if isinstance(value, (DataArray,)):
         value = value.values
     return value

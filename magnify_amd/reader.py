@@ -5,10 +5,14 @@ them) pass straight through (reader.py:31-35).  Path patterns follow the referen
 (reader.py:80-160): named groups ``(assay)``, ``(channel)``, ``(time)`` / ``(time|%Y%m%d)``,
 ``(row)``, ``(col)`` select the file's place in the tile array, ``(name_key|formatter|format)`` groups
 attach an alternative labelling ``name`` to dimension ``key``; ``*`` / ``?`` / ``**`` glob as usual.
-Files are TIFFs read with Pillow (tifffile / OME / MicroManager metadata are not available to this
-build): one 2-D page per file, or an ImageJ hyperstack whose description names ``channels`` /
-``frames``.  Reading is eager into one host array per assay -- SURVEY 8f N2's streaming half is the
-per-stream upload of ``StackProcessor`` (host-resident stack -> HBM, overlapped with compute).
+Files are TIFFs read with this build's own TIFF layer (``magnify_amd.tiff``: classic and BigTIFF, strips or tiles,
+the usual lossless codecs): one 2-D page per file, or a series whose axes the file itself names -- OME-XML
+(``DimensionOrder`` / ``SizeC`` / ``SizeT``, ``Plane DeltaT``), MicroManager's summary (``StartTime``, ``ChNames``) or
+an ImageJ hyperstack -- with the reference's rules (reader.py:194-258): a Z axis is refused, the position axis ``R``
+is ignored (tiles come from the path), X and Y must be there, a dimension named both in the path and in the file is
+an error.  ``read_tiffs`` fills one host array per assay page by page; SURVEY 8f N2's streaming half is
+``iter_time_chunks``: the series chunk by chunk of the time axis into page-locked blocks, one page decoded at a time
+(the reference maps every page to its own dask block, reader.py:265-292), feeding ``stack.process_stream``.
 """
 from __future__ import annotations
 
@@ -81,37 +85,58 @@ def extract_paths(pattern, **keys):
     return path_dict, meta_dict
 
 
-def _open_tiff(path):
-    """-> (pages as a list of 2-D arrays, dims of the page axis: [] / ['time'] / ['channel'] / both)."""
-    from PIL import Image
+_LETTER_TO_DIM = {"C": "channel", "T": "time", "Z": "depth", "Y": "tile_y", "X": "tile_x", "R": "tile_pos"}  # reader.py:196-203
 
-    with Image.open(path) as im:
-        n = getattr(im, "n_frames", 1)
-        desc = im.tag_v2.get(270, "") if hasattr(im, "tag_v2") else ""
-        pages = []
-        for i in range(n):
-            im.seek(i)
-            pages.append(np.array(im))
-    if n == 1:
-        return pages, [], ()
-    found = {k: int(v) for k, v in re.findall(r"(channels|frames|slices)=(\d+)", desc if isinstance(desc, str) else "")}
-    if found.get("slices", 1) > 1:
-        raise ValueError("tiff files with a Z dimension are not yet supported.")
-    n_c, n_t = found.get("channels", 1), found.get("frames", 1)
-    if n_c * n_t != n:
-        raise ValueError(f"{path}: {n} pages but no ImageJ hyperstack description that explains them "
-                         "(OME / MicroManager metadata are not readable in this build)")
-    dims, shape = [], ()
-    if n_t > 1:
-        dims, shape = dims + ["time"], shape + (n_t,)
-    if n_c > 1:
-        dims, shape = dims + ["channel"], shape + (n_c,)
-    return pages, dims, shape
+
+def series_layout(path, need_times=True, need_channels=True):
+    """What the reference learns from the first file of an assay (reader.py:189-258): the dimensions inside the file
+    (position axis dropped), the shape of the axes in front of a page, page size and dtype, and -- when the path does
+    not give them -- the timepoints (MicroManager ``StartTime`` + OME ``Plane DeltaT``) and channel names (``ChNames``).
+    -> dict(dims, inner, page, dtype, times, channels)."""
+    from . import tiff
+
+    with tiff.TiffFile(path) as tif:
+        axes, shape = tif.series()
+        unknown = [c for c in axes if c not in _LETTER_TO_DIM]
+        if unknown:
+            raise ValueError(f"{path}: {shape[0]} pages with no description of their axes (tifffile axes {axes!r}); "
+                             "name the dimension in the path or write OME / ImageJ metadata")
+        dims = [_LETTER_TO_DIM[c] for c in axes]
+        inner = tuple(shape)
+        times = channels = None
+        summary = tif.micromanager_metadata.get("Summary", {}) if tif.is_micromanager else {}
+        if need_times and "StartTime" in summary:
+            start = datetime.datetime.strptime(summary["StartTime"][:-6], "%Y-%m-%d %H:%M:%S.%f")  # without the time zone
+            if "time" in dims:
+                planes = tif.ome_planes or []
+                if not all(pl.get("DeltaTUnit") == "ms" for pl in planes):
+                    raise ValueError(f"{path}: OME Plane DeltaT in a unit other than ms")
+                times = [start + datetime.timedelta(milliseconds=float(pl.get("DeltaT"))) for pl in planes]
+                stride = inner[dims.index("channel")] if "channel" in dims else 1
+                if len(times) % stride:
+                    raise ValueError(f"{path}: {len(times)} OME planes for {stride} channels")
+                times = times[::stride]
+            else:
+                times = [start]
+        if need_channels and "ChNames" in summary:
+            channels = list(summary["ChNames"])
+        if "tile_pos" in dims:  # positions are separate files: the user names tiles in the search path (reader.py:249-254)
+            k = dims.index("tile_pos")
+            inner, dims = inner[:k] + inner[k + 1:], dims[:k] + dims[k + 1:]
+        if "depth" in dims:
+            raise ValueError("tiff files with a Z dimension are not yet supported.")
+        if "tile_y" not in dims or "tile_x" not in dims:
+            raise ValueError("tiff files must contain an X and Y dimension.")
+        page = tif.page(0)
+        return {"dims": dims[:-2], "inner": tuple(inner[:-2]), "page": page.shape, "dtype": tif.dtype, "times": times,
+                "channels": channels}
 
 
 def read_tiffs(xp_dict, name, meta_dict):
     """reader.py:163-324: one Dataset with ``tile`` over the dimensions found in the paths and inside
     the files, in the standard order (channel, time, tile_row, tile_col, tile_y, tile_x)."""
+    from . import tiff
+
     channel_idx, time_idx, row_idx, col_idx = (sorted(set(i)) for i in zip(*xp_dict.keys()))
     in_path, outer = [], ()
     for dim, values in (("channel", channel_idx), ("time", time_idx), ("tile_row", row_idx), ("tile_col", col_idx)):
@@ -119,28 +144,28 @@ def read_tiffs(xp_dict, name, meta_dict):
             in_path.append(dim)
             outer += (len(values),)
     files = [p for _, p in sorted(xp_dict.items())]
-    pages0, in_file, inner = _open_tiff(files[0])
+    lay = series_layout(files[0], need_times="time" not in in_path, need_channels="channel" not in in_path)
+    in_file, inner, (ty, tx) = lay["dims"], lay["inner"], lay["page"]
     if set(in_file) & set(in_path):
         raise ValueError("Dimensions specified in the path names and inside the tiff file overlap.")
-    ty, tx = pages0[0].shape[:2]
     if len(files) != int(np.prod(outer, dtype=np.int64)):
         raise ValueError(f"{name or 'assay'}: {len(files)} files do not fill the {outer} array the pattern describes")
-    tiles = np.empty(outer + inner + (ty, tx), dtype=pages0[0].dtype)
+    tiles = np.empty(outer + inner + (ty, tx), dtype=lay["dtype"])
     flat = tiles.reshape((-1,) + (ty, tx))
     per_file = int(np.prod(inner, dtype=np.int64)) if inner else 1
     for f, path in enumerate(files):
-        pages = pages0 if f == 0 else _open_tiff(path)[0]
-        if len(pages) != per_file or pages[0].shape[:2] != (ty, tx):
-            raise ValueError(f"{path}: page count / size differs from {files[0]}")
-        for k, page in enumerate(pages):
-            flat[f * per_file + k] = page
+        with tiff.TiffFile(path) as tif:
+            for k in range(per_file):  # pages run over the in-file axes in C order (reader.py:272-282)
+                tif.read_page_into(k, flat[f * per_file + k])
+    times = time_idx if "time" in in_path else lay["times"]
+    channels = channel_idx if "channel" in in_path else lay["channels"]
+    dims = tuple(in_path + in_file + ["tile_y", "tile_x"])
     coords = {}
-    if "channel" in in_path:
-        coords["channel"] = list(channel_idx)
-    if "time" in in_path:
-        coords["time"] = [int(t.timestamp()) if isinstance(t, datetime.datetime) else t for t in time_idx]
-    xp = xr_lite.Dataset({"tile": xr_lite.DataArray(tiles, tuple(in_path + in_file + ["tile_y", "tile_x"]))},
-                         coords=coords, attrs={"name": name})
+    if channels is not None and ("channel" not in dims or len(channels) == tiles.shape[dims.index("channel")]):
+        coords["channel"] = list(channels)
+    if times is not None and ("time" not in dims or len(times) == tiles.shape[dims.index("time")]):
+        coords["time"] = [int(t.timestamp()) if isinstance(t, datetime.datetime) else t for t in times]  # seconds
+    xp = xr_lite.Dataset({"tile": xr_lite.DataArray(tiles, dims)}, coords=coords, attrs={"name": name})
     order = [d for d in ("channel", "time", "tile_row", "tile_col", "tile_y", "tile_x") if d in xp.tile.dims]
     xp = xp.transpose(*order)
     for (meta_name, dim), table in meta_dict.items():
@@ -174,47 +199,13 @@ class Reader:
         return Reader()
 
 
-def _tiff_layout(path):
-    """(page dims, page shape, page dtype, n_frames) of a TIFF without decoding more than its first page."""
-    from PIL import Image
-
-    with Image.open(path) as im:
-        n = getattr(im, "n_frames", 1)
-        desc = im.tag_v2.get(270, "") if hasattr(im, "tag_v2") else ""
-        first = np.array(im)
-    if n == 1:
-        return [], (), first.shape[:2], first.dtype, 1
-    found = {k: int(v) for k, v in re.findall(r"(channels|frames|slices)=(\d+)", desc if isinstance(desc, str) else "")}
-    if found.get("slices", 1) > 1:
-        raise ValueError("tiff files with a Z dimension are not yet supported.")
-    n_c, n_t = found.get("channels", 1), found.get("frames", 1)
-    if n_c * n_t != n:
-        raise ValueError(f"{path}: {n} pages but no ImageJ hyperstack description that explains them")
-    dims, shape = [], ()
-    if n_t > 1:
-        dims, shape = dims + ["time"], shape + (n_t,)
-    if n_c > 1:
-        dims, shape = dims + ["channel"], shape + (n_c,)
-    return dims, shape, first.shape[:2], first.dtype, n
-
-
-def _read_page(path, index, out):
-    """Decode ONE page of a TIFF into ``out`` (the reference maps every page to its own dask block and reads it
-    on demand, reader.py:265-292)."""
-    from PIL import Image
-
-    with Image.open(path) as im:
-        if index:
-            im.seek(index)
-        out[...] = np.asarray(im)
-
-
 def iter_time_chunks(pattern, chunk: int, pinned: bool = False):
     """Streamed ingest of a time series too large to hold: the files behind
     ``pattern`` are read ``chunk`` timepoints at a time, in time order, page by page, never all at once.
     Groups as in ``extract_paths``: ``(channel)``, ``(time|format)``, and for tiled acquisitions ``(row)`` /
-    ``(col)``; a file holds one 2-D page or an ImageJ hyperstack whose pages run over time and / or channel
-    (a dimension is either in the path or in the file, reader.py:225-231).
+    ``(col)``; a file holds one 2-D page or a series (OME-TIFF / BigTIFF, MicroManager, ImageJ hyperstack) whose pages
+    run over time and / or channel (a dimension is either in the path or in the file, reader.py:260-262); timepoints
+    and channel names come from the path or, failing that, from the file's metadata (``series_layout``).
     Yields ``(time_values, channels, block)`` with ``block`` (T_chunk, C, H, W) -- tiled series:
     (T_chunk, C, rows, cols, tile_y, tile_x), stitched later on the device (``stack.process_stream(overlap=...)``)
     -- of the files' dtype: a NumPy array, or with ``pinned`` a page-locked torch tensor ready for an
@@ -224,8 +215,9 @@ def iter_time_chunks(pattern, chunk: int, pinned: bool = False):
         raise FileNotFoundError(f"The pattern {pattern} did not lead to any files.")
     if len({k[0] for k in path_dict}) > 1:
         raise ValueError("iter_time_chunks streams one assay per pattern")
-    in_file, inner, (h, w), dtype, _ = _tiff_layout(next(iter(path_dict.values())))
     path_dims = {"channel": any(k[1] is not None for k in path_dict), "time": any(k[2] is not None for k in path_dict)}
+    lay = series_layout(next(iter(path_dict.values())), need_times=not path_dims["time"], need_channels=not path_dims["channel"])
+    in_file, inner, (h, w), dtype = lay["dims"], lay["inner"], lay["page"], lay["dtype"]
     for d in in_file:
         if path_dims[d]:
             raise ValueError("Dimensions specified in the path names and inside the tiff file overlap.")
@@ -236,16 +228,31 @@ def iter_time_chunks(pattern, chunk: int, pinned: bool = False):
     cols = sorted({k[4] for k in path_dict}, key=lambda v: (v is None, v))
     n_t_file = inner[in_file.index("time")] if "time" in in_file else 1
     n_c_file = inner[in_file.index("channel")] if "channel" in in_file else 1
+    # page index inside a file: C order over the in-file axes, whichever of time / channel comes first
+    stride = {d: int(np.prod(inner[in_file.index(d) + 1:], dtype=np.int64)) for d in in_file}
     channels = sorted({k[1] for k in path_dict}, key=lambda c: (c is None, c)) if path_dims["channel"] else list(range(n_c_file))
     times = sorted({k[2] for k in path_dict}) if path_dims["time"] else list(range(n_t_file))
+    time_values = times if path_dims["time"] or lay["times"] is None or len(lay["times"]) != n_t_file else lay["times"]
+    channel_names = channels if path_dims["channel"] or lay["channels"] is None or len(lay["channels"]) != n_c_file else lay["channels"]
+    assay = next(iter(path_dict))[0]
+    open_files = {}  # path -> TiffFile, kept open across pages (a chunk touches each of its files many times)
 
-    def page_of(t, c, r, cc):  # -> (path, page index inside the file): pages run (time, channel), channel fastest
-        key = (next(iter(path_dict))[0], c if path_dims["channel"] else None, t if path_dims["time"] else None, r, cc)
+    def read_page(path, index, out):
+        from . import tiff
+
+        tif = open_files.get(path)
+        if tif is None:
+            if len(open_files) >= 64:
+                open_files.pop(next(iter(open_files))).close()
+            tif = open_files[path] = tiff.TiffFile(path)
+        tif.read_page_into(index, out)
+
+    def page_of(t, c, r, cc):  # -> (path, page index inside the file)
+        key = (assay, c if path_dims["channel"] else None, t if path_dims["time"] else None, r, cc)
         if key not in path_dict:
             raise FileNotFoundError(f"no file for channel {c!r}, time {t}, tile ({r}, {cc})")
-        ti = 0 if path_dims["time"] else t
-        ci = 0 if path_dims["channel"] else c
-        return path_dict[key], ti * n_c_file + ci
+        index = (0 if path_dims["time"] else t * stride.get("time", 0)) + (0 if path_dims["channel"] else c * stride.get("channel", 0))
+        return path_dict[key], index
 
     for lo in range(0, len(times), int(chunk)):
         part = times[lo: lo + int(chunk)]
@@ -263,6 +270,8 @@ def iter_time_chunks(pattern, chunk: int, pinned: bool = False):
                     for b, cc in enumerate(cols):
                         path, index = page_of(t, c, r, cc)
                         dst = block[i, j, a, b] if tiled else block[i, j]
-                        _read_page(path, index, dst)
-        stamps = [int(t.timestamp()) if isinstance(t, datetime.datetime) else t for t in part]
-        yield stamps, [c for c in channels], (block_t if pinned else block)
+                        read_page(path, index, dst)
+        stamps = [int(t.timestamp()) if isinstance(t, datetime.datetime) else t for t in time_values[lo: lo + int(chunk)]]
+        yield stamps, list(channel_names), (block_t if pinned else block)
+    for tif in open_files.values():
+        tif.close()

@@ -261,6 +261,103 @@ def test_edge_stage_empty_and_tiny(hp):
     assert n_edges[0] == 0
 
 
+@pytest.mark.parametrize("quantiles", [(0.1, 0.9), (0.45, 0.55), (0.999, 0.2)])
+def test_edge_thresholds_window_passes(hp, quantiles):
+    """Quantile ranks inside COARSE histogram bins (strong gradients everywhere: white noise over the full range, a
+    noiseless plane searched near its top quantile) are resolved by window passes that stay on the device; planes of
+    one batch need different numbers of them (0 .. 4).  Quantiles, thresholds and edges equal the oracle's, and the
+    second call on the finder runs the passes optimistically (one host round trip)."""
+    rng = np.random.default_rng(11)
+    shape = (200, 264)
+    planes = np.stack([rng.integers(0, 65536, shape).astype(np.uint16),                    # ranks in several coarse bins
+                       noisy_bead_image(21, shape, 5, r_lo=6, r_hi=12)[0],                 # fine bins only
+                       draw_beads(shape, [[50, 60], [120, 200], [160, 90]], 24),           # noiseless
+                       (rng.integers(0, 2, shape) * 40000 + 500).astype(np.uint16)])       # two-level noise
+    p, h, w = planes.shape
+    cf = hp.CircleFinder(p, h, w, 5, 13, 2000)
+    cf.keep_debug_maps = True
+    for call in range(2):
+        got, _ = cf.find(dev(planes), None, quantiles[0], quantiles[1], 0.3, 5, [3, 4, 5, 6])
+        assert cf.stats["optimistic"] == (call == 1)
+        for k in range(p):
+            _, _, _, want_edges, (lo, hi) = rp.edge_stage(rn.to_uint8(planes[k]), *quantiles)
+            assert (np.float32(lo), np.float32(hi)) == tuple(cf.quantiles[k]), (call, k)
+            assert tuple(cf.thresh[k].cpu().numpy()) == rcv.canny_thresholds(lo, hi), (call, k)
+            np.testing.assert_array_equal(cf.edges[k].cpu().numpy(), want_edges)
+    assert cf.stats["hist_passes"] > 1  # the white-noise plane cannot do without window passes
+
+
+def test_hysteresis_one_launch_reaches_the_fixed_point(hp):
+    """mg_canny_hysteresis_full against connected components (8-connected weak regions that hold a strong pixel,
+    scipy.ndimage.label) and against the sweep-per-launch kernel: a serpentine weak line with ONE strong seed that
+    crosses the 256 x 256 tile borders dozens of times in both directions (growth has to be handed from tile to tile
+    and back), random weak clutter with sparse seeds, a line along tile borders and corners, an empty plane."""
+    from scipy import ndimage
+
+    from magnify_amd import _native as nat
+
+    rng = np.random.default_rng(5)
+    h, w = 700, 900
+    weak = np.zeros((4, h, w), dtype=bool)
+    strong = np.zeros((4, h, w), dtype=bool)
+    # plane 0: serpentine, 12 px pitch, columns 5 .. w - 6, every row pair connected at alternating ends
+    for j, y in enumerate(range(4, h - 13, 12)):
+        weak[0, y, 5: w - 5] = True
+        weak[0, y: y + 13, (w - 6) if j % 2 == 0 else 5] = True
+    strong[0, 4, 5] = True
+    # plane 1: clutter
+    weak[1] = rng.random((h, w)) < 0.35
+    strong[1] = weak[1] & (rng.random((h, w)) < 0.002)
+    # plane 2: lines on the tile borders (rows 255 / 256, cols 255 / 256, 511 / 512), diagonal steps through the corners
+    weak[2, 255, :] = weak[2, :, 256] = weak[2, 512, :] = weak[2, :, 511] = True
+    for d in range(-20, 21):
+        weak[2, 256 + d, 256 - d] = True
+    strong[2, 255, 0] = True
+    strong[2, 699, 511] = True
+    # plane 3: nothing
+    want = np.zeros_like(weak)
+    for p in range(4):
+        lab, _ = ndimage.label(weak[p], structure=np.ones((3, 3), dtype=int))
+        keep = np.unique(lab[strong[p] & weak[p]])
+        want[p] = np.isin(lab, keep[keep > 0]) | strong[p]
+    words = 2 * ((h * w + 63) // 64) + 2
+
+    def pack(m):
+        out = np.zeros((4, words), dtype=np.uint32)
+        for p in range(4):
+            b = np.packbits(m[p].reshape(-1), bitorder="little")
+            out[p].view(np.uint8)[: len(b)] = b
+        return dev(out.view(np.int32))
+
+    def unpack(t):
+        a = t.cpu().numpy().view(np.uint32)
+        return np.stack([np.unpackbits(a[p].view(np.uint8), bitorder="little")[: h * w].reshape(h, w).astype(bool) for p in range(4)])
+
+    d_weak = pack(weak)
+    tx, ty = nat.C.c_int(0), nat.C.c_int(0)
+    nat.check(nat.lib().mg_hysteresis_tiles(h, w, nat.C.byref(tx), nat.C.byref(ty)), "mg_hysteresis_tiles")
+    dirty = torch.zeros((4, (tx.value * ty.value + 31) // 32), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    d_full = pack(strong)
+    nat.check(nat.lib().mg_canny_hysteresis_full(d_weak.data_ptr(), d_full.data_ptr(), words, 4, h, w, dirty.data_ptr(),
+                                                 dirty.numel(), stream), "mg_canny_hysteresis_full")
+    got = unpack(d_full)
+    for p in range(4):
+        np.testing.assert_array_equal(got[p], want[p], err_msg=f"plane {p}")
+    assert not dirty.cpu().numpy().any()  # every mark was claimed
+    # the sweep kernel, launched until nothing changes
+    d_sw = pack(strong)
+    changed = torch.zeros((4,), dtype=torch.int32, device="cuda")
+    for sweep in range(2000):
+        changed.zero_()
+        nat.check(nat.lib().mg_canny_hysteresis(d_weak.data_ptr(), d_sw.data_ptr(), words, 4, h, w, changed.data_ptr(), 0, 0,
+                                                stream), "mg_canny_hysteresis")
+        if not changed.cpu().numpy().any():
+            break
+    assert 20 < sweep < 1999  # the serpentine really needs many hand-overs
+    np.testing.assert_array_equal(unpack(d_sw), got)
+
+
 # ---------------------------------------------------------------------------------------------
 # A8-A11: candidates, unique circles, scores, suppression
 # ---------------------------------------------------------------------------------------------
