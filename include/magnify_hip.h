@@ -163,21 +163,15 @@ int mg_edge_thresholds_window(const uint32_t* d_hist_win, int n_planes, int pass
 int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, const int32_t* d_thresh, uint32_t* d_weak,
                  uint32_t* d_strong, uint32_t* d_class, int64_t words_per_plane, void* stream);
 
-/* One sweep of 8-connected hysteresis, bit-parallel on the bitmaps: every 256 x 64 tile grows its
- * strong set into its weak set to a fixed point in LDS (halo from global memory) and ORs the new
- * bits into d_strong.  d_changed[n_planes] becomes non-zero for planes that changed; call until a
- * sweep leaves it at zero: d_strong is then the edge map of utils.py:142.  Active-tile tracking:
- * d_flags_in / d_flags_out are uint8[n_planes][tiles_y][tiles_x] (mg_hysteresis_tiles); a tile is
- * skipped unless it or one of its 8 neighbours set its flag in the previous sweep; d_flags_out
- * (pre-zeroed) receives this sweep's flags.  Pass d_flags_in = NULL for the first sweep. */
+/* One sweep of 8-connected hysteresis, bit-parallel on the bitmaps: every 256 x 256 tile grows its strong set into
+ * its weak set to a fixed point in LDS (halo from global memory) and ORs the new bits into d_strong.  Where that
+ * growth reaches a weak, not yet strong pixel of a NEIGHBOURING tile, the neighbour's flag in d_flags_out
+ * (uint8[n_planes][tiles_y][tiles_x], mg_hysteresis_tiles; pre-zeroed) is set and d_changed[n_planes] becomes
+ * non-zero for the plane: another sweep is needed, in which only the flagged tiles (d_flags_in = that d_flags_out)
+ * are worked on.  Call until a sweep leaves d_changed at zero: d_strong is then the edge map of utils.py:142.
+ * d_flags_in = NULL (first sweep, or a caller without flags): every tile is worked on. */
 int mg_canny_hysteresis(const uint32_t* d_weak, uint32_t* d_strong, int64_t words_per_plane, int n_planes, int h,
                         int w, uint32_t* d_changed, const uint8_t* d_flags_in, uint8_t* d_flags_out, void* stream);
-/* The same hysteresis carried to the global fixed point in ONE launch: a workgroup that grows edges up to a weak
- * pixel of a neighbouring tile marks that tile in d_dirty (uint32 [n_planes][ceil(tiles / 32)], tiles from
- * mg_hysteresis_tiles; cleared here), and every workgroup keeps claiming and working off marked tiles of its plane
- * until none is left -- no workgroup ever waits for another.  dirty_words = capacity of d_dirty in words. */
-int mg_canny_hysteresis_full(const uint32_t* d_weak, uint32_t* d_strong, int64_t words_per_plane, int n_planes, int h,
-                             int w, uint32_t* d_dirty, int64_t dirty_words, void* stream);
 int mg_hysteresis_tiles(int h, int w, int* tiles_x, int* tiles_y);
 
 /* Inspection helper: bitmap -> {0,1} bytes, d_out[n_planes][n_bits]. */

@@ -42,7 +42,6 @@ PROTOTYPES = {
     "mg_edge_thresholds_window": [_p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p],
     "mg_canny_nms": [_p, _i, _i, _i, _p, _p, _p, _p, _l, _p],
     "mg_canny_hysteresis": [_p, _p, _l, _i, _i, _i, _p, _p, _p, _p],
-    "mg_canny_hysteresis_full": [_p, _p, _l, _i, _i, _i, _p, _l, _p],
     "mg_unpack_bits": [_p, _l, _i, _l, _p, _p],
     "mg_hysteresis_tiles": [_i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "mg_edge_grid_scan_words": [_i, _i, _i, _i],

@@ -850,43 +850,40 @@ constexpr int HW = TW / 32;  // interior words per tile row (8)
 constexpr int HTH = 256;     // tile rows: taller than the stencil tiles -- growth crosses a tile border only
                              // once per sweep, and a sweep is a launch plus a host check
 
+// A tile is worked on in sweep k + 1 only if a NEIGHBOUR asked for it in sweep k: growth in the neighbour reached a
+// weak, not yet strong pixel of this tile (the neighbour sees it in its halo, next to one of its new bits).  A tile's
+// own growth never asks for its own next turn -- it has reached its local fixed point, only new bits across a border
+// can move it again.  (Until round 3 a tile was active whenever it or any of its 8 neighbours had changed, which in the
+// sweeps after the first is nearly every tile: they cost 0.2 ms each at 64 planes where a few per cent of the tiles
+// had anything to do.)  A request made from a stale view (the pixel was promoted meanwhile) costs one re-check.
+__device__ __forceinline__ uint32_t lds_interior(const uint32_t (*a)[HW + 2], int r, int k) {
+  return (r >= 1 && r <= HTH && k >= 1 && k <= HW) ? a[r][k] : 0u;
+}
+
 __global__ __launch_bounds__(NT) void k_hysteresis(const uint32_t* __restrict__ d_weak, uint32_t* __restrict__ d_strong,
                                                    int64_t words_per_plane, int h, int w,
                                                    uint32_t* __restrict__ d_changed,
                                                    const uint8_t* __restrict__ d_flags_in,
                                                    uint8_t* __restrict__ d_flags_out) {
   __shared__ uint32_t st[HTH + 2][HW + 2];
-  __shared__ uint32_t wk[HTH][HW];
+  __shared__ uint32_t wk[HTH + 2][HW + 2];  // weak map with halo; its interior is reused for the tile's new bits
+  __shared__ uint32_t s_mark;
   const int plane = blockIdx.z;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * HTH;
   const int ntx = gridDim.x, nty = gridDim.y;
-  if (d_flags_in) {
-    // A tile can only gain edges if it or one of its 8 neighbours changed in the previous sweep.
-    const uint8_t* f = d_flags_in + (int64_t)plane * ntx * nty;
-    bool active = false;
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int bx = (int)blockIdx.x + dx, by = (int)blockIdx.y + dy;
-        if (bx >= 0 && bx < ntx && by >= 0 && by < nty) active |= f[by * ntx + bx] != 0;
-      }
-    if (!active) return;
-  }
+  if (d_flags_in && !d_flags_in[(int64_t)plane * ntx * nty + blockIdx.y * ntx + blockIdx.x]) return;  // nobody asked
   const uint32_t* weak = d_weak + plane * words_per_plane;
   uint32_t* strong = d_strong + plane * words_per_plane;
   int pending = 0;
   for (int i = threadIdx.x; i < (HTH + 2) * (HW + 2); i += NT) {
-    const int r = i / (HW + 2), k = i - r * (HW + 2);
-    st[r][k] = row_word(strong, h, w, ty0 - 1 + r, tx0 - 32 + 32 * k);
+    const int r = i / (HW + 2), kk = i - r * (HW + 2);
+    const uint32_t sv = row_word(strong, h, w, ty0 - 1 + r, tx0 - 32 + 32 * kk);
+    const uint32_t wv = row_word(weak, h, w, ty0 - 1 + r, tx0 - 32 + 32 * kk);
+    st[r][kk] = sv;
+    wk[r][kk] = wv;
+    if (r >= 1 && r <= HTH && kk >= 1 && kk <= HW) pending |= (wv & ~sv) != 0;
   }
-  for (int i = threadIdx.x; i < HTH * HW; i += NT) {
-    const int r = i / HW, k = i - r * HW;
-    wk[r][k] = row_word(weak, h, w, ty0 + r, tx0 + 32 * k);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < HTH * HW; i += NT) {
-    const int r = i / HW, k = i - r * HW;
-    pending |= (wk[r][k] & ~st[r + 1][k + 1]) != 0;
-  }
+  if (threadIdx.x == 0) s_mark = 0u;
   if (!__syncthreads_or(pending)) return;
   // A thread owns WPT vertically adjacent words (rows WPT g .. WPT g + WPT - 1 of word column k).  Per
   // iteration it grows each of them from the 3 x 3 neighbourhood and then along the word itself until
@@ -905,7 +902,7 @@ __global__ __launch_bounds__(NT) void k_hysteresis(const uint32_t* __restrict__ 
     for (int j = 0; j < WPT; ++j) {
       const int r = r0 + j;
       uint32_t cur = st[r][k];
-      uint32_t cand = wk[r - 1][k - 1] & ~cur;
+      uint32_t cand = wk[r][k] & ~cur;
       if (!cand) continue;
       uint32_t dil = 0;
 #pragma unroll
@@ -926,175 +923,48 @@ __global__ __launch_bounds__(NT) void k_hysteresis(const uint32_t* __restrict__ 
     }
     again = __syncthreads_or(changed);
   } while (again);
-  int wrote = 0;
+  // new bits -> global memory and -> the interior of wk (the weak interior is not needed any more)
 #pragma unroll
   for (int j = 0; j < WPT; ++j) {
     const uint32_t diff = st[r0 + j][k] & ~first[j];
-    if (diff) {
-      bits_or(strong, (int64_t)(ty0 + r0 + j - 1) * w + tx0 + 32 * (k - 1), diff);  // only in-image bits can be set
-      wrote = 1;
+    wk[r0 + j][k] = diff;
+    if (diff) bits_or(strong, (int64_t)(ty0 + r0 + j - 1) * w + tx0 + 32 * (k - 1), diff);  // only in-image bits can be set
+  }
+  __syncthreads();
+  // halo pixels that are weak, not strong (as far as this tile knows) and touch a NEW bit: their tile has work
+  for (int i = threadIdx.x; i < 2 * (HW + 2) + 2 * HTH; i += NT) {
+    int r, kk;
+    if (i < HW + 2) r = 0, kk = i;
+    else if (i < 2 * (HW + 2)) r = HTH + 1, kk = i - (HW + 2);
+    else if (i < 2 * (HW + 2) + HTH) r = i - 2 * (HW + 2) + 1, kk = 0;
+    else r = i - 2 * (HW + 2) - HTH + 1, kk = HW + 1;
+    const uint32_t cand = wk[r][kk] & ~st[r][kk];
+    if (!cand) continue;
+    uint32_t dil = 0;
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr) {
+      const uint32_t c = lds_interior(wk, r + dr, kk), l = lds_interior(wk, r + dr, kk - 1), rt = lds_interior(wk, r + dr, kk + 1);
+      dil |= c | (c << 1) | (c >> 1) | (l >> 31) | (rt << 31);
+    }
+    if (cand & dil) {
+      const int dy = r == 0 ? -1 : (r == HTH + 1 ? 1 : 0), dx = kk == 0 ? -1 : (kk == HW + 1 ? 1 : 0);
+      atomicOr(&s_mark, 1u << ((dy + 1) * 3 + dx + 1));
     }
   }
-  if (__syncthreads_or(wrote) && threadIdx.x == 0) {
-    // a flag, not a count: a thousand tiles of a plane change in the first sweep and their atomics would queue on
-    // the plane's one counter (the look goes to L2: a stale L1 line would only cost a redundant store)
-    if (__hip_atomic_load(&d_changed[plane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) d_changed[plane] = 1u;
-    if (d_flags_out) d_flags_out[(int64_t)plane * ntx * nty + blockIdx.y * ntx + blockIdx.x] = 1;
-  }
-}
-
-// ---- K4b: hysteresis to the global fixed point in ONE launch -------------------------------------------------
-// Same tiles and the same tile-local fixed point as k_hysteresis, but a workgroup does not stop after its own tile:
-// when growth inside a tile reaches a weak pixel of a NEIGHBOURING tile (a weak, not yet strong pixel of the halo
-// next to a newly set bit), that tile is marked in a per-plane dirty bitmap, and every workgroup, once its tile is
-// done, keeps claiming marked tiles of its plane (atomic fetch-and) and working them off until a scan finds none.
-// Nobody ever waits for another workgroup (no barrier across workgroups, no spinning): a workgroup that marks a tile
-// scans afterwards itself, so when the last one leaves no mark is left and the bitmap is the fixed point -- whatever
-// order the hardware runs the workgroups in.  Marks are release / claims acquire at agent scope: the claimer's loads
-// see the bits that caused the mark.  A mark made by a stale view (the neighbour promoted the pixel meanwhile)
-// only costs a re-check of that tile.
-// Replaces ~8 sweep launches (each of 16 384 workgroups at 64 planes, most of which only tested a flag) whose number
-// had to be guessed ahead by the host.
-__device__ __forceinline__ uint32_t lds_word(const uint32_t (*a)[HW + 2], int r, int k) {
-  return (r >= 1 && r <= HTH && k >= 1 && k <= HW) ? a[r][k] : 0u;  // interior words only (of the diff array)
-}
-
-__global__ __launch_bounds__(NT) void k_hysteresis_full(const uint32_t* __restrict__ d_weak, uint32_t* __restrict__ d_strong,
-                                                        int64_t words_per_plane, int h, int w,
-                                                        uint32_t* __restrict__ d_dirty, int dirty_words) {
-  __shared__ uint32_t st[HTH + 2][HW + 2];
-  __shared__ uint32_t wk[HTH + 2][HW + 2];  // weak map with halo; its interior is reused for the tile's new bits
-  __shared__ int s_next, s_claimed;
-  __shared__ uint32_t s_mark;
-  const int plane = blockIdx.z;
-  const int ntx = gridDim.x, nty = gridDim.y, n_tiles = ntx * nty;
-  const uint32_t* weak = d_weak + plane * words_per_plane;
-  uint32_t* strong = d_strong + plane * words_per_plane;
-  uint32_t* dirty = d_dirty + (int64_t)plane * dirty_words;
-  const int own = blockIdx.y * ntx + blockIdx.x;
-  int tile = own;
-  constexpr int WPT = HTH * HW / NT;  // words per thread
-  static_assert(WPT * NT == HTH * HW, "the tile's words must divide evenly over the threads");
-  const int k = (threadIdx.x & (HW - 1)) + 1, r0 = WPT * (threadIdx.x / HW) + 1;  // st coordinates of the thread's words
-  for (;;) {
-    const int bx = tile % ntx, by = tile / ntx;
-    const int tx0 = bx * TW, ty0 = by * HTH;
-    int pending = 0;
-    for (int i = threadIdx.x; i < (HTH + 2) * (HW + 2); i += NT) {
-      const int r = i / (HW + 2), kk = i - r * (HW + 2);
-      const uint32_t sv = row_word(strong, h, w, ty0 - 1 + r, tx0 - 32 + 32 * kk);
-      const uint32_t wv = row_word(weak, h, w, ty0 - 1 + r, tx0 - 32 + 32 * kk);
-      st[r][kk] = sv;
-      wk[r][kk] = wv;
-      if (r >= 1 && r <= HTH && kk >= 1 && kk <= HW) pending |= (wv & ~sv) != 0;
+  __syncthreads();
+  if (threadIdx.x == 0 && s_mark) {
+    const uint32_t m = s_mark;
+    bool any = false;
+    for (int d = 0; d < 9; ++d) {
+      if (!((m >> d) & 1u)) continue;
+      const int nx = (int)blockIdx.x + d % 3 - 1, ny = (int)blockIdx.y + d / 3 - 1;
+      if (nx < 0 || nx >= ntx || ny < 0 || ny >= nty) continue;
+      any = true;
+      if (d_flags_out) d_flags_out[(int64_t)plane * ntx * nty + ny * ntx + nx] = 1;
     }
-    if (threadIdx.x == 0) s_mark = 0u;
-    if (__syncthreads_or(pending)) {  // (else: every weak pixel of the tile is an edge already)
-      uint32_t first[WPT];  // this thread's strong words before the growth
-#pragma unroll
-      for (int j = 0; j < WPT; ++j) first[j] = st[r0 + j][k];
-      int again;
-      do {  // as k_hysteresis: grow from the 3 x 3 neighbourhood, then along the word, rows seeing the rows above
-        int changed = 0;
-#pragma unroll
-        for (int j = 0; j < WPT; ++j) {
-          const int r = r0 + j;
-          uint32_t cur = st[r][k];
-          uint32_t cand = wk[r][k] & ~cur;
-          if (!cand) continue;
-          uint32_t dil = 0;
-#pragma unroll
-          for (int dr = -1; dr <= 1; ++dr) {
-            const uint32_t c = st[r + dr][k], l = st[r + dr][k - 1], rt = st[r + dr][k + 1];
-            dil |= c | (c << 1) | (c >> 1) | (l >> 31) | (rt << 31);
-          }
-          uint32_t nw = cand & dil;
-          if (!nw) continue;
-          cur |= nw;
-          cand &= ~nw;
-          for (uint32_t g = cand & ((cur << 1) | (cur >> 1)); g; g = cand & ((cur << 1) | (cur >> 1))) {
-            cur |= g;
-            cand &= ~g;
-          }
-          st[r][k] = cur;
-          changed = 1;
-        }
-        again = __syncthreads_or(changed);
-      } while (again);
-      // new bits -> global memory and -> the interior of wk (the weak interior is not needed any more)
-#pragma unroll
-      for (int j = 0; j < WPT; ++j) {
-        const uint32_t diff = st[r0 + j][k] & ~first[j];
-        wk[r0 + j][k] = diff;
-        if (diff) bits_or(strong, (int64_t)(ty0 + r0 + j - 1) * w + tx0 + 32 * (k - 1), diff);  // only in-image bits can be set
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this thread's bits before the marks below
-      __syncthreads();
-      // halo pixels that are weak, not strong (as far as this tile knows) and touch a NEW bit: their tile has work
-      for (int i = threadIdx.x; i < 2 * (HW + 2) + 2 * HTH; i += NT) {
-        int r, kk;
-        if (i < HW + 2) r = 0, kk = i;
-        else if (i < 2 * (HW + 2)) r = HTH + 1, kk = i - (HW + 2);
-        else if (i < 2 * (HW + 2) + HTH) r = i - 2 * (HW + 2) + 1, kk = 0;
-        else r = i - 2 * (HW + 2) - HTH + 1, kk = HW + 1;
-        const uint32_t cand = wk[r][kk] & ~st[r][kk];
-        if (!cand) continue;
-        uint32_t dil = 0;
-#pragma unroll
-        for (int dr = -1; dr <= 1; ++dr) {
-          const uint32_t c = lds_word(wk, r + dr, kk), l = lds_word(wk, r + dr, kk - 1), rt = lds_word(wk, r + dr, kk + 1);
-          dil |= c | (c << 1) | (c >> 1) | (l >> 31) | (rt << 31);
-        }
-        if (cand & dil) {
-          const int dy = r == 0 ? -1 : (r == HTH + 1 ? 1 : 0), dx = kk == 0 ? -1 : (kk == HW + 1 ? 1 : 0);
-          atomicOr(&s_mark, 1u << ((dy + 1) * 3 + dx + 1));
-        }
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint32_t m = s_mark;
-      for (int d = 0; d < 9; ++d) {
-        if (!((m >> d) & 1u)) continue;
-        const int nx = bx + d % 3 - 1, ny = by + d / 3 - 1;
-        if (nx < 0 || nx >= ntx || ny < 0 || ny >= nty) continue;
-        const int t = ny * ntx + nx;
-        __hip_atomic_fetch_or(&dirty[t >> 5], 1u << (t & 31), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    // the next marked tile of this plane, looked for from this workgroup's own tile onwards (workgroups spread over
-    // the marks instead of all going for the first); claimed by clearing its bit
-    bool got = false;
-    for (;;) {
-      if (threadIdx.x == 0) s_next = 0x7FFFFFFF;
-      __syncthreads();
-      for (int wd = threadIdx.x; wd < dirty_words; wd += NT) {
-        uint32_t v = __hip_atomic_load(&dirty[wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (v) {
-          const int t = 32 * wd + __ffs(v) - 1;
-          v &= v - 1;
-          int key = t - own;
-          if (key < 0) key += n_tiles;
-          atomicMin(&s_next, key);
-        }
-      }
-      __syncthreads();
-      const int key = s_next;
-      if (key == 0x7FFFFFFF) break;  // nothing marked: done (block-uniform)
-      const int t = (own + key) % n_tiles;
-      if (threadIdx.x == 0) {
-        const uint32_t old = __hip_atomic_fetch_and(&dirty[t >> 5], ~(1u << (t & 31)), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_claimed = (old >> (t & 31)) & 1u;
-      }
-      __syncthreads();
-      if (s_claimed) {
-        tile = t;
-        got = true;
-        break;
-      }
-    }
-    if (!got) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the loads of the claimed tile see the bits behind its mark
+    // a flag, not a count: a thousand tiles of a plane ask in the first sweep and their atomics would queue on the
+    // plane's one counter (the look goes to L2: a stale L1 line would only cost a redundant store)
+    if (any && __hip_atomic_load(&d_changed[plane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) d_changed[plane] = 1u;
   }
 }
 
@@ -1441,22 +1311,6 @@ extern "C" int mg_canny_hysteresis(const uint32_t* d_weak, uint32_t* d_strong, i
   if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
   hipLaunchKernelGGL(k_hysteresis, g, dim3(NT), 0, mg_stream(stream), d_weak, d_strong, words_per_plane, h, w,
                      d_changed, d_flags_in, d_flags_out);
-  MG_CHECK_LAUNCH();
-  return MG_OK;
-}
-
-extern "C" int mg_canny_hysteresis_full(const uint32_t* d_weak, uint32_t* d_strong, int64_t words_per_plane, int n_planes,
-                                       int h, int w, uint32_t* d_dirty, int64_t dirty_words, void* stream) {
-  if (!d_weak || !d_strong || !d_dirty || n_planes < 0 || h < 0 || w < 0) return MG_EINVAL;
-  if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
-  if (!words_ok(words_per_plane, h, w)) return MG_EINVAL;
-  const dim3 g((w + TW - 1) / TW, (h + HTH - 1) / HTH, n_planes);
-  if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
-  const int per_plane = (int)((g.x * g.y + 31) / 32);
-  if (dirty_words < (int64_t)per_plane * n_planes) return MG_EINVAL;
-  hipStream_t s = mg_stream(stream);
-  if (hipMemsetAsync(d_dirty, 0, (size_t)per_plane * n_planes * 4, s) != hipSuccess) return MG_ELAUNCH;
-  hipLaunchKernelGGL(k_hysteresis_full, g, dim3(NT), 0, s, d_weak, d_strong, words_per_plane, h, w, d_dirty, per_plane);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

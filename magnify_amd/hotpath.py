@@ -318,10 +318,6 @@ class CircleFinder:
         nat.check(nat.lib().mg_hysteresis_tiles(h, w, nat.C.byref(tx), nat.C.byref(ty)), "mg_hysteresis_tiles")
         # active-tile flags of the hysteresis sweeps, one layer per sweep of a group (+ the last layer of the group before)
         self.tile_flags = torch.zeros((G + 1, P, ty.value, tx.value), dtype=u8, device=dev)
-        # one-launch hysteresis (mg_canny_hysteresis_full) with its per-plane bitmap of marked tiles; MG_HYST_SWEEPS=1
-        # keeps the sweep-per-launch kernel (A/B measurements, parity of the two)
-        self.hyst_full = not os.environ.get("MG_HYST_SWEEPS")
-        self.hyst_dirty = torch.zeros((P, (ty.value * tx.value + 31) // 32), dtype=i32, device=dev)
         self.scan_state = torch.zeros((max(1, int(nat.lib().mg_edge_grid_scan_words(P, h, w, self.grid))),),
                                       dtype=torch.int64, device=dev)
         # Optimistic chain (see find): sweeps / rounds / capacities taken from the calls before, everything checked
@@ -436,7 +432,7 @@ class CircleFinder:
         self.stats["hist_passes"] = 1 + n_win
         if optimistic:
             self._canny()
-            self._sweeps(0, 1 if self.hyst_full else min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP))
+            self._sweeps(0, min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP))
             self._edge_grid(3)
             n_edges = None
         else:
@@ -474,12 +470,6 @@ class CircleFinder:
     def _sweeps(self, done, group):
         """Hysteresis sweeps done .. done + group - 1; sweep k of the group counts its changes in self.changed[k]
         (cleared by the caller) and writes the tile flags of layer k + 1 (layer 0: the flags of the sweep before)."""
-        if self.hyst_full:  # to the global fixed point in one launch: the sweep after it would change nothing
-            if done == 0:
-                _call("mg_canny_hysteresis_full", self.weak_bits.data_ptr(), self.edge_bits.data_ptr(), self.words, self.P, self.h,
-                      self.w, self.hyst_dirty.data_ptr(), self.hyst_dirty.numel(), _stream(), stage="mg_canny_hysteresis")
-            self._last_layer = group
-            return
         flags = self.tile_flags
         if done > 0:
             flags[0].copy_(flags[self._last_layer])
@@ -521,7 +511,7 @@ class CircleFinder:
         sweeps, unresolved, needed = 0, False, 0
         # sweeps per host check: first as many as the calls before needed (a sweep after convergence only
         # runs the tile-flag test), then two at a time -- one host round trip in the steady state
-        group = 1 if self.hyst_full else min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP)
+        group = min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP)
         while True:
             self.changed[:group].zero_()
             self._sweeps(sweeps, group)

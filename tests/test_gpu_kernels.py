@@ -287,11 +287,13 @@ def test_edge_thresholds_window_passes(hp, quantiles):
     assert cf.stats["hist_passes"] > 1  # the white-noise plane cannot do without window passes
 
 
-def test_hysteresis_one_launch_reaches_the_fixed_point(hp):
-    """mg_canny_hysteresis_full against connected components (8-connected weak regions that hold a strong pixel,
-    scipy.ndimage.label) and against the sweep-per-launch kernel: a serpentine weak line with ONE strong seed that
-    crosses the 256 x 256 tile borders dozens of times in both directions (growth has to be handed from tile to tile
-    and back), random weak clutter with sparse seeds, a line along tile borders and corners, an empty plane."""
+def test_hysteresis_reaches_the_fixed_point(hp):
+    """mg_canny_hysteresis, swept until no tile asks for another turn, against connected components (8-connected weak
+    regions that hold a strong pixel, scipy.ndimage.label): a serpentine weak line with ONE strong seed that crosses
+    the 256 x 256 tile borders dozens of times in both directions (growth is handed from tile to tile and back through
+    the neighbour flags), random weak clutter with sparse seeds, lines along tile borders and through tile corners, an
+    empty plane.  With the tile flags (only tiles a neighbour asked for are worked on) and without (every tile, every
+    sweep): same bitmaps, same number of sweeps."""
     from scipy import ndimage
 
     from magnify_amd import _native as nat
@@ -336,26 +338,26 @@ def test_hysteresis_one_launch_reaches_the_fixed_point(hp):
     d_weak = pack(weak)
     tx, ty = nat.C.c_int(0), nat.C.c_int(0)
     nat.check(nat.lib().mg_hysteresis_tiles(h, w, nat.C.byref(tx), nat.C.byref(ty)), "mg_hysteresis_tiles")
-    dirty = torch.zeros((4, (tx.value * ty.value + 31) // 32), dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    d_full = pack(strong)
-    nat.check(nat.lib().mg_canny_hysteresis_full(d_weak.data_ptr(), d_full.data_ptr(), words, 4, h, w, dirty.data_ptr(),
-                                                 dirty.numel(), stream), "mg_canny_hysteresis_full")
-    got = unpack(d_full)
-    for p in range(4):
-        np.testing.assert_array_equal(got[p], want[p], err_msg=f"plane {p}")
-    assert not dirty.cpu().numpy().any()  # every mark was claimed
-    # the sweep kernel, launched until nothing changes
-    d_sw = pack(strong)
     changed = torch.zeros((4,), dtype=torch.int32, device="cuda")
-    for sweep in range(2000):
-        changed.zero_()
-        nat.check(nat.lib().mg_canny_hysteresis(d_weak.data_ptr(), d_sw.data_ptr(), words, 4, h, w, changed.data_ptr(), 0, 0,
-                                                stream), "mg_canny_hysteresis")
-        if not changed.cpu().numpy().any():
-            break
-    assert 20 < sweep < 1999  # the serpentine really needs many hand-overs
-    np.testing.assert_array_equal(unpack(d_sw), got)
+    sweeps = {}
+    for use_flags in (False, True):
+        d_strong = pack(strong)
+        flags = [torch.zeros((4, ty.value, tx.value), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        for sweep in range(2000):
+            changed.zero_()
+            flags[(sweep + 1) % 2].zero_()
+            nat.check(nat.lib().mg_canny_hysteresis(d_weak.data_ptr(), d_strong.data_ptr(), words, 4, h, w, changed.data_ptr(),
+                                                    flags[sweep % 2].data_ptr() if (use_flags and sweep) else 0,
+                                                    flags[(sweep + 1) % 2].data_ptr() if use_flags else 0, stream),
+                      "mg_canny_hysteresis")
+            if not changed.cpu().numpy().any():
+                break
+        sweeps[use_flags] = sweep
+        got = unpack(d_strong)
+        for p in range(4):
+            np.testing.assert_array_equal(got[p], want[p], err_msg=f"plane {p}, flags {use_flags}")
+    assert 20 < sweeps[True] < 1999 and sweeps[True] == sweeps[False]  # the serpentine really needs many hand-overs
 
 
 # ---------------------------------------------------------------------------------------------
