@@ -184,8 +184,9 @@ int mg_unpack_bits(const uint32_t* d_bits, int64_t words_per_plane, int n_planes
  * the edge count runs phase 1, reads d_num_edges and sizes the list; one with a capacity from an earlier call runs
  * both at once (phases = 3): a plane with more edges than coord_cap then gets d_num_edges = 0 -- nothing downstream
  * indexes beyond the list -- and its true count in d_edge_totals[n_planes] (optional), for the caller to check when it
- * next synchronises.  d_scan_state (optional): mg_edge_grid_scan_words(...) zero-initialised 64-bit words owned by
- * this caller; with it the prefix sum over the cells runs on many workgroups per plane instead of one. */
+ * next synchronises.  d_scan_state (optional): mg_edge_grid_scan_words(...) 64-bit words owned by the caller
+ * (cleared by the call itself): the prefix sum over the cells then runs on many workgroups per plane, chunk totals
+ * handed on through these words, chunks taken by ticket (no assumption about the order workgroups are dispatched in). */
 int64_t mg_edge_grid_scan_words(int n_planes, int h, int w, int grid);
 int mg_edge_grid(const uint32_t* d_edge_bits, int64_t words_per_plane, int n_planes, int h, int w, int grid,
                  int32_t* d_cell_counts, int32_t* d_cell_starts, int32_t* d_num_edges, int32_t* d_coords,
@@ -394,13 +395,19 @@ int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int64_t assay_s
                                  void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts,
                                  void* stream);
 
+/* d_offsets[0 .. n] = exclusive prefix sums of min(d_counts[i], cap) (int32, on the device): the d_assay_offsets of
+ * mg_roi_segment_reduce from the per-assay bead counts mg_collect_circles left in device memory -- the ROI pass can
+ * then be queued (with an upper bound for m) before the host has fetched the counts. */
+int mg_counts_to_offsets(const int32_t* d_counts, int n, int cap, int32_t* d_offsets, void* stream);
+
 /* fg/bg segmentation + ROI gather + reductions WITHOUT a label map (find.py:561-602 with
  * utils.py:380-395 folded in): the masks come straight from the bead table.  A window pixel is
  * foreground iff it lies in the marker's own disk and in no other disk of its assay (labels == i),
  * background iff it lies in no disk (labels == -1).  d_beads (m, 3) = [row, col, r] of all markers,
  * assay-major; d_assay_offsets int32[n_assays + 1] delimits every assay's markers (marker g of assay
- * a has label value g - d_assay_offsets[a]); max_per_assay >= the largest per-assay marker count
- * (launch grid = max_per_assay x n_assays); d_halfwidths / max_r as for mg_circle_labels (disks with
+ * a has label value g - d_assay_offsets[a]).  One workgroup per marker, launched for m of them: m may be an upper
+ * bound of d_assay_offsets[n_assays] (workgroups beyond it leave at once; markers beyond m are not worked on, the
+ * outputs must hold m).  d_halfwidths / max_r as for mg_circle_labels (disks with
  * r < 2 or r > max_r cover nothing, as there).  bead_stride = 0: d_beads is that compact list;
  * bead_stride > 0: d_beads holds one padded row of bead_stride triples per assay (the layout
  * mg_collect_circles writes: the ROI pass can start from the device-resident tables while the host
@@ -410,8 +417,7 @@ int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int64_t assay_s
  * Outputs as mg_roi_gather_reduce. */
 int mg_roi_segment_reduce(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h, int w,
                           int time_major, const int32_t* d_beads, int64_t bead_stride, const int32_t* d_assay_offsets,
-                          int n_assays,
-                          int max_per_assay, int m, int roi_len, const int32_t* d_halfwidths, int max_r, void* d_roi,
+                          int n_assays, int m, int roi_len, const int32_t* d_halfwidths, int max_r, void* d_roi,
                           uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream);
 
 /* Masked median (numpy nanmedian semantics: mean of the two middle values) of an already

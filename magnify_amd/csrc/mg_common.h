@@ -27,6 +27,21 @@
 
 static inline hipStream_t mg_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Clearing small counters / bitmaps: a kernel, not hipMemsetAsync.  The calls of this library are captured into
+// hipGraphs by the host side (hotpath.CircleFinder), and memset nodes of one captured graph were found to be replayed
+// with another graph's parameters once a second graph had been captured (ROCm 7.2: a counter came back as 0x10101034);
+// kernel nodes carry their own arguments.
+static __global__ void mg_k_zero_words(uint32_t* __restrict__ p, int64_t n_words) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t mg_zero_async(void* p, size_t bytes, hipStream_t s) {  // bytes: a multiple of 4
+  const int64_t n = (int64_t)(bytes / 4);
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)(n < 256 * 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(mg_k_zero_words, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), n);
+  return hipGetLastError();
+}
+
 __host__ __device__ static inline int mg_elem_size(int dtype) {
   return dtype == MG_U8 ? 1 : dtype == MG_U16 ? 2 : dtype == MG_F32 ? 4 : 8;
 }

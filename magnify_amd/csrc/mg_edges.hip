@@ -11,8 +11,6 @@
 // bit-exact against the oracle.  Roofline: HBM.
 #include <math.h>
 
-#include <atomic>
-
 #include "mg_common.h"
 
 namespace {
@@ -980,9 +978,12 @@ __global__ __launch_bounds__(NT) void k_unpack_bits(const uint32_t* __restrict__
 // ---- K5: grid_array from the bitmap: per-cell counts, scan, ordered coordinate fill -------------
 __global__ __launch_bounds__(NT) void k_cell_count(const uint32_t* __restrict__ d_bits, int64_t words_per_plane, int h,
                                                    int w, int grid, int gc, int n_cells,
-                                                   int32_t* __restrict__ d_counts) {
+                                                   int32_t* __restrict__ d_counts, unsigned long long* __restrict__ d_state,
+                                                   int state_words) {
   const int plane = blockIdx.y;
   const int cell = blockIdx.x * NT + threadIdx.x;
+  // the chunk states and the ticket of the scan kernel that follows on the stream start at zero
+  if (d_state && cell < state_words) d_state[(int64_t)plane * state_words + cell] = 0ull;
   if (cell >= n_cells) return;
   const uint32_t* bits = d_bits + plane * words_per_plane;
   const int cr = cell / gc, cc = cell - cr * gc;
@@ -1023,20 +1024,27 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const int32_t* __restrict__ 
 }
 
 // The same scan with SCAN_CHUNK cells per workgroup (one 16-byte load per thread) and the chunk totals handed from
-// workgroup to workgroup through d_state: a workgroup publishes (epoch << 32 | total) as soon as it has summed its
-// chunk and then adds up the totals of the chunks before it.  Workgroups are dispatched in blockIdx order and a
-// publication depends on nothing, so the wait always ends; `epoch` (unique per launch) tells a fresh total from the
-// previous launch's without clearing d_state.  One plane: 59 us -> ~8 us; 64 planes use 4096 workgroups instead of 64.
+// workgroup to workgroup through d_state: a workgroup publishes (1 << 63 | total) as soon as it has summed its
+// chunk and then adds up the totals of the chunks before it.  The chunk a workgroup takes is a TICKET drawn when it
+// starts (not its blockIdx: HIP does not promise a dispatch order), so every total it waits for belongs to a workgroup
+// that is already running and whose publication depends on nothing: the wait always ends.  The states and the ticket
+// word (d_state[n_chunks] of the plane) are cleared by k_cell_count, the kernel in front of this one -- no launch
+// counter in the arguments, so a captured graph can replay the launch.
+// One plane: 59 us -> ~8 us; 64 planes use 4096 workgroups instead of 64.
 constexpr int SCAN_CHUNK = 4096;
 
 __global__ __launch_bounds__(1024) void k_cell_scan_chunks(const int32_t* __restrict__ d_counts, int n_cells,
                                                            int32_t* __restrict__ d_starts, int32_t* __restrict__ d_num_edges,
                                                            int32_t* __restrict__ d_totals, int64_t limit,
-                                                           unsigned long long* __restrict__ d_state, uint32_t epoch) {
-  const int plane = blockIdx.y, chunk = blockIdx.x, n_chunks = gridDim.x;
+                                                           unsigned long long* __restrict__ d_state) {
+  const int plane = blockIdx.y, n_chunks = gridDim.x;
   const int32_t* cnt = d_counts + (int64_t)plane * n_cells;
   int32_t* st = d_starts + (int64_t)plane * n_cells;
-  unsigned long long* state = d_state + (int64_t)plane * n_chunks;
+  unsigned long long* state = d_state + (int64_t)plane * (n_chunks + 1);
+  __shared__ int s_chunk;
+  if (threadIdx.x == 0) s_chunk = (int)atomicAdd(&state[n_chunks], 1ull);
+  __syncthreads();
+  const int chunk = s_chunk;
   const int i0 = chunk * SCAN_CHUNK + 4 * (int)threadIdx.x;
   int c[4] = {0, 0, 0, 0};
   const bool vec = (n_cells & 3) == 0 && i0 + 4 <= n_cells;  // n_cells % 4 == 0 keeps every plane 16-byte aligned
@@ -1052,15 +1060,14 @@ __global__ __launch_bounds__(1024) void k_cell_scan_chunks(const int32_t* __rest
   int run = mg_block_exscan(c[0] + c[1] + c[2] + c[3], &total);
   __shared__ int s_base;
   if (threadIdx.x == 0)
-    __hip_atomic_store(&state[chunk], ((unsigned long long)epoch << 32) | (uint32_t)total, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&state[chunk], (1ull << 63) | (uint32_t)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x < 64) {  // wave 0: totals of the chunks before this one
     int base = 0;
     for (int j = threadIdx.x; j < chunk; j += 64) {
       unsigned long long v;
       do {
         v = __hip_atomic_load(&state[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-      } while ((uint32_t)(v >> 32) != epoch);
+      } while (!(v >> 63));
       base += (int)(uint32_t)v;
     }
 #pragma unroll
@@ -1292,8 +1299,8 @@ extern "C" int mg_canny_nms(const uint8_t* d_blur, int n_planes, int h, int w, c
   // w % 32 == 0: every bitmap word inside the image belongs to one lane group, which stores it whole -- nothing to
   // clear (the spare words behind the image are never written: the caller zeroes the buffers once, when it makes them)
   const size_t bytes = (size_t)n_planes * words_per_plane * 4;
-  if ((w & 31) && (hipMemsetAsync(d_weak, 0, bytes, s) != hipSuccess || hipMemsetAsync(d_strong, 0, bytes, s) != hipSuccess ||
-                   (d_class && hipMemsetAsync(d_class, 0, 3 * bytes, s) != hipSuccess)))
+  if ((w & 31) && (mg_zero_async(d_weak, bytes, s) != hipSuccess || mg_zero_async(d_strong, bytes, s) != hipSuccess ||
+                   (d_class && mg_zero_async(d_class, 3 * bytes, s) != hipSuccess)))
     return MG_ELAUNCH;
   hipLaunchKernelGGL(k_canny_nms, g, dim3(NT), 0, s, d_blur, h, w, d_thresh, words_per_plane, d_weak, d_strong,
                      d_class);
@@ -1337,7 +1344,7 @@ extern "C" int mg_unpack_bits(const uint32_t* d_bits, int64_t words_per_plane, i
 extern "C" int64_t mg_edge_grid_scan_words(int n_planes, int h, int w, int grid) {
   if (n_planes < 0 || h < 0 || w < 0 || grid <= 0) return -1;
   const int64_t n_cells = (int64_t)((h + grid - 1) / grid) * ((w + grid - 1) / grid);
-  return (int64_t)n_planes * ((n_cells + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  return (int64_t)n_planes * ((n_cells + SCAN_CHUNK - 1) / SCAN_CHUNK + 1);  // chunk states + the ticket word
 }
 
 extern "C" int mg_edge_grid(const uint32_t* d_edge_bits, int64_t words_per_plane, int n_planes, int h, int w, int grid,
@@ -1351,20 +1358,18 @@ extern "C" int mg_edge_grid(const uint32_t* d_edge_bits, int64_t words_per_plane
   const int gr = (h + grid - 1) / grid, gc = (w + grid - 1) / grid, n_cells = gr * gc;
   hipStream_t s = mg_stream(stream);
   if (phases & 1) {  // counts + scan (a caller without a capacity estimate sizes the coordinate list from d_num_edges)
+    const int n_chunks = (n_cells + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    const bool chunked = d_scan_state && n_chunks > 1 && n_chunks <= 65535 && n_chunks + 1 <= n_cells;
     if (n_cells > 0) {
       hipLaunchKernelGGL(k_cell_count, dim3((n_cells + NT - 1) / NT, n_planes), dim3(NT), 0, s, d_edge_bits,
-                         words_per_plane, h, w, grid, gc, n_cells, d_cell_counts);
+                         words_per_plane, h, w, grid, gc, n_cells, d_cell_counts,
+                         chunked ? reinterpret_cast<unsigned long long*>(d_scan_state) : nullptr, n_chunks + 1);
       MG_CHECK_LAUNCH();
     }
-    const int n_chunks = (n_cells + SCAN_CHUNK - 1) / SCAN_CHUNK;
     const int64_t limit = (phases & 2) ? coord_cap : -1;  // fill follows at once: the list's capacity bounds the count
-    if (d_scan_state && n_chunks > 1 && n_chunks <= 65535) {
-      static std::atomic<uint32_t> launches{0};
-      uint32_t epoch = ++launches;
-      if (epoch == 0) epoch = ++launches;  // 0 is what a fresh (zeroed) state holds
+    if (chunked) {
       hipLaunchKernelGGL(k_cell_scan_chunks, dim3(n_chunks, n_planes), dim3(1024), 0, s, d_cell_counts, n_cells,
-                         d_cell_starts, d_num_edges, d_edge_totals, limit, reinterpret_cast<unsigned long long*>(d_scan_state),
-                         epoch);
+                         d_cell_starts, d_num_edges, d_edge_totals, limit, reinterpret_cast<unsigned long long*>(d_scan_state));
     } else {
       hipLaunchKernelGGL(k_cell_scan, dim3(n_planes), dim3(1024), 0, s, d_cell_counts, n_cells, d_cell_starts, d_num_edges,
                          d_edge_totals, limit);

@@ -164,22 +164,30 @@ __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64
                                             const int32_t* __restrict__ d_marker_assay,
                                             const int32_t* __restrict__ d_marker_local, int len,
                                             const int32_t* __restrict__ d_labels,
-                                            const int32_t* __restrict__ d_assay_offsets, int64_t bead_stride, int time_major,
+                                            const int32_t* __restrict__ d_assay_offsets, int n_assays, int64_t bead_stride, int time_major,
                                             const int32_t* __restrict__ d_halfwidths, int max_r, T* __restrict__ d_roi,
                                             uint8_t* __restrict__ d_fg, uint8_t* __restrict__ d_bg,
                                             double* __restrict__ d_sums, int32_t* __restrict__ d_counts) {
   extern __shared__ __attribute__((aligned(4))) uint8_t flags[];
   __shared__ ACC s_red[2][NT / 64];
   __shared__ int s_cnt[2][NT / 64];
-  // label mode: one block per marker of a flat list; disk mode: grid (local index, assay)
+  // one block per marker: of a flat list with per-marker assay / local index (label mode), or of the assays'
+  // concatenated bead tables (disk mode)
   int g = blockIdx.x, assay, first = 0, local;
   int64_t bead0 = 0, gb = g;  // the assay's first bead / this marker's bead in d_beads
   if (d_assay_offsets) {
-    assay = blockIdx.y;
+    // flat grid over the markers of all assays (the launch may be sized by an upper bound: the rest leaves at once);
+    // the marker's assay = the last one that starts at or before it
+    if (g >= d_assay_offsets[n_assays]) return;
+    int lo = 0, hi = n_assays;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (d_assay_offsets[mid] <= g) lo = mid;
+      else hi = mid;
+    }
+    assay = lo;
     first = d_assay_offsets[assay];
-    local = blockIdx.x;
-    if (local >= d_assay_offsets[assay + 1] - first) return;
-    g = first + local;
+    local = g - first;
     // bead table: compact (markers and beads share the index) or one padded row per assay
     bead0 = bead_stride ? (int64_t)assay * bead_stride : first;
     gb = bead0 + local;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
                                                      const int32_t* __restrict__ d_marker_assay,
                                                      const int32_t* __restrict__ d_marker_local, int len,
                                                      const int32_t* __restrict__ d_labels,
-                                                     const int32_t* __restrict__ d_assay_offsets, int64_t bead_stride, int time_major,
+                                                     const int32_t* __restrict__ d_assay_offsets, int n_assays, int64_t bead_stride, int time_major,
                                                      const int32_t* __restrict__ d_halfwidths, int max_r,
                                                      uint16_t* __restrict__ d_roi, uint8_t* __restrict__ d_fg,
                                                      uint8_t* __restrict__ d_bg, double* __restrict__ d_sums,
@@ -298,15 +306,23 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
   constexpr int WV = NT / 64;
   __shared__ uint32_t s_red[2][CTB][WV];
   __shared__ int s_cnt[2][WV];
-  // label mode: one block per marker of a flat list; disk mode: grid (local index, assay)
+  // one block per marker: of a flat list with per-marker assay / local index (label mode), or of the assays'
+  // concatenated bead tables (disk mode)
   int g = blockIdx.x, assay, first = 0, local;
   int64_t bead0 = 0, gb = g;  // the assay's first bead / this marker's bead in d_beads
   if (d_assay_offsets) {
-    assay = blockIdx.y;
+    // flat grid over the markers of all assays (the launch may be sized by an upper bound: the rest leaves at once);
+    // the marker's assay = the last one that starts at or before it
+    if (g >= d_assay_offsets[n_assays]) return;
+    int lo = 0, hi = n_assays;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (d_assay_offsets[mid] <= g) lo = mid;
+      else hi = mid;
+    }
+    assay = lo;
     first = d_assay_offsets[assay];
-    local = blockIdx.x;
-    if (local >= d_assay_offsets[assay + 1] - first) return;
-    g = first + local;
+    local = g - first;
     // bead table: compact (markers and beads share the index) or one padded row per assay
     bead0 = bead_stride ? (int64_t)assay * bead_stride : first;
     gb = bead0 + local;
@@ -536,12 +552,12 @@ __global__ __launch_bounds__(NT) void k_masked_median_u16(const uint16_t* __rest
 template <typename T, typename ACC>
 int launch_roi(const void* d_image, int64_t assay_stride, int n_c, int n_t, int h, int w, const int32_t* d_beads,
                const int32_t* d_marker_assay, const int32_t* d_marker_local, dim3 grid, int len,
-               const int32_t* d_labels, const int32_t* d_assay_offsets, int64_t bead_stride, int time_major,
+               const int32_t* d_labels, const int32_t* d_assay_offsets, int n_assays, int64_t bead_stride, int time_major,
                const int32_t* d_halfwidths,
                int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, hipStream_t s) {
   hipLaunchKernelGGL((k_roi<T, ACC>), grid, dim3(NT), roi_lds_bytes(len, d_halfwidths != nullptr), s,
                      (const T*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, len,
-                     d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r, (T*)d_roi, d_fg, d_bg, d_sums, d_counts);
+                     d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_halfwidths, max_r, (T*)d_roi, d_fg, d_bg, d_sums, d_counts);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -565,13 +581,13 @@ namespace {
 int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h, int w,
                  const int32_t* d_beads, const int32_t* d_marker_assay, const int32_t* d_marker_local, int m, int roi_len,
                  const int32_t* d_labels, const int32_t* d_assay_offsets, int64_t bead_stride, int time_major, int n_assays,
-                 int max_per_assay, const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
+                 const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
                  double* d_sums, int32_t* d_counts, void* stream) {
   if (!d_image || !d_beads || m < 0 || roi_len <= 0 || n_c <= 0 || n_t <= 0) return MG_EINVAL;
   if (roi_len > h || roi_len > w || roi_lds_bytes(roi_len, d_halfwidths != nullptr) > 60000) return MG_EINVAL;
   if (m == 0) return MG_OK;
   hipStream_t s = mg_stream(stream);
-  const dim3 grid = d_assay_offsets ? dim3(max_per_assay, n_assays) : dim3(m);
+  const dim3 grid(m);
   if (dtype == MG_U16 && (roi_len & 1) == 0 && roi_len <= 126 && (w & 1) == 0 && (assay_stride & 1) == 0 &&
       (int64_t)h * w < (1LL << 31) &&
       (reinterpret_cast<uintptr_t>(d_image) & 3) == 0 && (!d_roi || (reinterpret_cast<uintptr_t>(d_roi) & 3) == 0) &&
@@ -580,7 +596,7 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
     // 1.14 ms; without the pipelining 1.22, one row per trip 1.22, 4 rows x 2 planes 1.20, 4 x 4 unpipelined 1.24)
     hipLaunchKernelGGL((k_roi_u16_even<2, 4, true>), grid, dim3(NT), (size_t)mask_words(roi_len) * 4, s,
                        (const uint16_t*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                       roi_len, d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg,
+                       roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg,
                        d_sums, d_counts);
     MG_CHECK_LAUNCH();
     return MG_OK;
@@ -588,24 +604,49 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
   switch (dtype) {
     case MG_U8:
       return launch_roi<uint8_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
-                                            d_marker_local, grid, roi_len, d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r,
+                                            d_marker_local, grid, roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_halfwidths, max_r,
                                             d_roi, d_fg, d_bg, d_sums, d_counts, s);
     case MG_U16:
       return launch_roi<uint16_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
-                                             d_marker_local, grid, roi_len, d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r,
+                                             d_marker_local, grid, roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_halfwidths, max_r,
                                              d_roi, d_fg, d_bg, d_sums, d_counts, s);
     case MG_F32:
       return launch_roi<float, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                                       grid, roi_len, d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                                       grid, roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_halfwidths, max_r, d_roi, d_fg, d_bg,
                                        d_sums, d_counts, s);
     case MG_F64:
       return launch_roi<double, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                                        grid, roi_len, d_labels, d_assay_offsets, bead_stride, time_major, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                                        grid, roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_halfwidths, max_r, d_roi, d_fg, d_bg,
                                         d_sums, d_counts, s);
   }
   return MG_EINVAL;
 }
 }  // namespace
+
+namespace {
+// d_offsets[0 .. n] = exclusive prefix of min(d_counts[i], cap): where every assay's markers start in the compact
+// outputs of mg_roi_segment_reduce -- on the device, so that the pass can be queued before the host has seen the counts.
+__global__ __launch_bounds__(1024) void k_counts_to_offsets(const int32_t* __restrict__ d_counts, int n, int cap,
+                                                            int32_t* __restrict__ d_offsets) {
+  int carry = 0;
+  for (int i0 = 0; i0 < n; i0 += 1024) {  // block-uniform trip count
+    const int i = i0 + (int)threadIdx.x;
+    const int v = i < n ? min(max(d_counts[i], 0), cap) : 0;
+    int total;
+    const int ex = mg_block_exscan(v, &total);
+    if (i < n) d_offsets[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) d_offsets[n] = carry;
+}
+}  // namespace
+
+extern "C" int mg_counts_to_offsets(const int32_t* d_counts, int n, int cap, int32_t* d_offsets, void* stream) {
+  if (!d_counts || !d_offsets || n < 0 || cap < 0) return MG_EINVAL;
+  hipLaunchKernelGGL(k_counts_to_offsets, dim3(1), dim3(1024), 0, mg_stream(stream), d_counts, n, cap, d_offsets);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
 
 extern "C" int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t,
                                             int h, int w, const int32_t* d_beads, const int32_t* d_marker_assay,
@@ -613,20 +654,18 @@ extern "C" int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int6
                                             const int32_t* d_labels, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
                                             double* d_sums, int32_t* d_counts, void* stream) {
   return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, m, roi_len,
-                      d_labels, nullptr, 0, 0, 0, 0, nullptr, 0, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
+                      d_labels, nullptr, 0, 0, 0, nullptr, 0, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
 }
 
 extern "C" int mg_roi_segment_reduce(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h,
                                      int w, int time_major, const int32_t* d_beads, int64_t bead_stride,
-                                     const int32_t* d_assay_offsets, int n_assays, int max_per_assay, int m, int roi_len,
+                                     const int32_t* d_assay_offsets, int n_assays, int m, int roi_len,
                                      const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
                                      double* d_sums, int32_t* d_counts, void* stream) {
-  if (!d_assay_offsets || !d_halfwidths || n_assays <= 0 || n_assays > 65535 || max_per_assay < 0 || max_r < 0 ||
-      bead_stride < 0 || (bead_stride > 0 && bead_stride < max_per_assay))
+  if (!d_assay_offsets || !d_halfwidths || n_assays <= 0 || n_assays > 65535 || max_r < 0 || bead_stride < 0)
     return MG_EINVAL;
-  if (max_per_assay == 0) return MG_OK;
   return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, nullptr, nullptr, m, roi_len, nullptr,
-                      d_assay_offsets, bead_stride, time_major, n_assays, max_per_assay, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                      d_assay_offsets, bead_stride, time_major, n_assays, d_halfwidths, max_r, d_roi, d_fg, d_bg,
                       d_sums, d_counts, stream);
 }
 

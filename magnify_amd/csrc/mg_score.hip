@@ -511,7 +511,7 @@ extern "C" int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angl
   if ((int64_t)ntr * ntc >= 32768) return MG_EINVAL;  // the 32-bit key
   if ((size_t)per_total * 12 > 48 * 1024 || NSUB * (nr + 1) > NP) return MG_EINVAL;
   hipStream_t s = mg_stream(stream);
-  if (hipMemsetAsync(d_num_surv, 0, (size_t)std::max(n_planes, 1) * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
+  if (mg_zero_async(d_num_surv, (size_t)std::max(n_planes, 1) * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
   const size_t lds_bytes = (size_t)WBASE + (size_t)(STY + 2 * max_r) * WSTR;
   const int nsr = (ntr + SUBY - 1) / SUBY, nsc = (ntc + SUBX - 1) / SUBX, n_st = nsr * nsc;

@@ -12,23 +12,38 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); no-op for 1 rank."""
+def _share_gpu(world_local: int) -> bool:
+    """Fewer GPUs than ranks on this node (the one-GPU test box): every rank works on cuda:0 and the ranks talk gloo
+    (a rehearsal of the multi-rank path, not a measurement).  Decided by every rank for itself -- the launcher's parent
+    process does not look at the GPUs at all (magnify_amd/launch.py) -- from the same two numbers, so all ranks agree."""
+    if os.environ.get("MG_SHARE_GPU") in ("0", "1"):
+        return os.environ["MG_SHARE_GPU"] == "1"
+    share = torch.cuda.is_available() and 0 < torch.cuda.device_count() < world_local
+    if share:
+        os.environ["MG_SHARE_GPU"] = "1"
+        os.environ.setdefault("MG_DIST_BACKEND", "gloo")
+    return share
+
+
+def init_from_env(backend=None, single_rank_group=False):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); no-op for 1 rank unless
+    ``single_rank_group`` (a process group of one: the collectives below then run through the backend -- RCCL for
+    "nccl" -- instead of returning at once)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    share = _share_gpu(int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = os.environ.get("MG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
-            # MG_SHARE_GPU=1: rehearsal of the multi-rank path on a single-GPU box (all ranks on cuda:0, gloo)
-            local = 0 if os.environ.get("MG_SHARE_GPU") == "1" else local
+            local = 0 if share else local
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
-        local = 0 if os.environ.get("MG_SHARE_GPU") == "1" else local
+        local = 0 if share else local
         torch.cuda.set_device(local)
     return rank, world, local
 
@@ -42,8 +57,13 @@ def shard_range(n_units: int, rank: int, world: int):
 
 def allreduce_max_(t: torch.Tensor):
     """In-place max all-reduce (flat-field maxima in single-assay mode, preprocess.py:84,86)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if dist.is_initialized():
+        if dist.get_backend() == "gloo" and t.is_cuda:
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
 
 
@@ -51,7 +71,7 @@ def gather_marker_table(table: torch.Tensor) -> torch.Tensor:
     """All-gather of per-rank marker tables (M_rank, F) -> (sum M_rank, F), rank order.
 
     Variable length: counts are gathered first, then one padded all-gather."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return table
     world = dist.get_world_size()
     out_device = table.device
@@ -95,7 +115,7 @@ def broadcast_beads(beads, src: int = 0, device="cpu"):
     other ranks.  Returns a numpy (M, 3) int32 array on every rank."""
     import numpy as np
 
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return np.asarray(beads, dtype=np.int32).reshape(-1, 3)
     dev = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device(device)
     me = dist.get_rank()
@@ -127,14 +147,7 @@ def run_mode_r(proc, stack_local: torch.Tensor, flatfield=1.0, darkfield=0.0, se
         raise ValueError("run_mode_r needs a StackProcessor(mode='R')")
     t, c, h, w = stack_local.shape
     tiles = stack_local.view(t * c, 1, 1, 1, h, w)
-    max2 = hp.flatfield_max(tiles, flatfield, darkfield, 1)
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        if dist.get_backend() == "gloo":
-            host = max2.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.MAX)
-            max2.copy_(host)
-        else:
-            dist.all_reduce(max2, op=dist.ReduceOp.MAX)
+    max2 = allreduce_max_(hp.flatfield_max(tiles, flatfield, darkfield, 1))
     proc.flatfield(stack_local, flatfield, darkfield, max2=max2)
     owner = 0
     me = dist.get_rank() if dist.is_initialized() else 0

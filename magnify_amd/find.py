@@ -83,11 +83,13 @@ class BeadFinder:
             # one search channel (nothing to de-duplicate across channels, find.py:490-500): the ROI pass reads the
             # bead table where the suppression left it on the device; the host copy of the table runs beside it
             ch = _channel_index(assay, self.search_channels[0])
+            roi_pass = lambda d_tab, d_num, cap: hotpath.roi_gather_reduce(  # noqa: E731  (queued before the counts come back)
+                image[None], None, L, None, disks=True, device_tables=(d_tab, None, self.max_bead_radius),
+                device_counts=(d_num, cap, None))
             counts, (d_out, d_scores, _) = finder.find(
                 image[ch, 0:1], _plane_minmax(assay, image, (ch, 0)), self.low_edge_quantile, self.high_edge_quantile,
-                self.min_roundness, self.min_bead_radius, [utils.next_seed()], host_results=False)
-            out = hotpath.roi_gather_reduce(image[None], None, L, None, disks=True,
-                                            device_tables=(d_out, counts, self.max_bead_radius))
+                self.min_roundness, self.min_bead_radius, [utils.next_seed()], host_results=False, follow=roi_pass)
+            out = hotpath.finish_roi(finder.follow_result, counts)  # (launched for the full capacity: never None)
             beads = finder.fetch_results(counts, d_out, d_scores, overlap=True)[0][0]
         else:
             for channel in self.search_channels:

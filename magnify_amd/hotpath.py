@@ -33,8 +33,11 @@ class StageTimer:
     """Per-stage HIP-event timing on the stream the kernels are launched on (torch's current
     stream): ``with timer.stage("name"):`` around C-ABI calls; ``timer.summary()`` after a sync."""
 
-    def __init__(self):
+    def __init__(self, allow_graphs=False):
+        """``allow_graphs``: the finder may replay its optimistic chain as one hipGraph launch -- the stages inside it
+        are then not timed (no events inside a graph), everything launched around it (flat-field, ROI pass) still is."""
         self.events = []
+        self.allow_graphs = allow_graphs
 
     class _Ctx:
         def __init__(self, timer, name):
@@ -87,9 +90,12 @@ def set_timer(timer):
 _NO_TIMER = TIMER
 
 
+_CAPTURING = False  # inside a stream capture (CircleFinder._capture_chain): no timing events
+
+
 def _call(name, *args, stage=None):
     """One C-ABI call: timed (if a StageTimer is installed) and status-checked."""
-    if TIMER is _NO_TIMER:
+    if TIMER is _NO_TIMER or _CAPTURING:
         rc = getattr(nat.lib(), name)(*args)
         if rc:
             nat.check(rc, name)
@@ -278,6 +284,7 @@ class CircleFinder:
     """
 
     MAX_GROUP = 64  # most hysteresis sweeps / suppression rounds launched between two host checks
+    MAX_CAPTURES = 12  # hipGraph captures per finder (a capture costs ~9 ms: callers whose launch sequences never repeat stop)
 
     def __init__(self, n_planes, h, w, min_radius, max_radius, num_iter, device="cuda", grid_length=GRID_LENGTH):
         require_gpu()
@@ -326,6 +333,11 @@ class CircleFinder:
         self._recent_sweeps, self._recent_rounds = [], []
         self.calls = {"optimistic": 0, "repaired": 0, "checked": 0}  # how the calls of this finder went (find)
         self._out_sets, self._out_turn, self._out_cap = [None, None], 0, 0
+        self._n_collects, self.follow_result = 0, None
+        # hipGraphs of the optimistic chain (_optimistic_chain), by launch-sequence key
+        self._graphs = None if os.environ.get("MG_NO_GRAPH") else {}
+        self._graph_bufs, self.graph_replays, self.graph_captures = None, 0, 0
+        self._mm = torch.empty((P, 2), dtype=torch.float64, device=dev)
         self.words = 2 * ((h * w + 63) // 64) + 2  # bitmap words per plane (even, one spare)
         self.edge_bits = torch.zeros((P, self.words), dtype=i32, device=dev)  # strong bits = edges
         self.weak_bits = torch.zeros((P, self.words), dtype=i32, device=dev)
@@ -374,10 +386,20 @@ class CircleFinder:
         self.stats = {}
 
     # -- host <-> device bookkeeping ---------------------------------------------------------------
-    def _fetch_status(self):
-        """The status block on the host (one pinned copy + a stream sync): rows as laid out in __init__."""
-        self.status_host.copy_(self.status, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+    def _fetch_status(self, after=None):
+        """The status block on the host (one pinned copy + a stream sync): rows as laid out in __init__.
+        ``after`` (an event): the copy runs on a side stream that only waits for that event -- not for what the caller
+        has queued behind it (the ROI pass of `follow`)."""
+        if after is None:
+            self.status_host.copy_(self.status, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return self.status_host.numpy()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        self._side.wait_event(after)
+        with torch.cuda.stream(self._side):
+            self.status_host.copy_(self.status, non_blocking=True)
+        self._side.synchronize()
         return self.status_host.numpy()
 
     @staticmethod
@@ -613,10 +635,15 @@ class CircleFinder:
         return self._out_sets[self._out_turn]
 
     def _collect(self, bufs, min_dist):
+        self._n_collects += 1
         out, out_scores, scratch = bufs
         _call("mg_collect_circles", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
               self.num_alive.data_ptr(), self.state.data_ptr(), int(min_dist <= 0), self.P, out.data_ptr(),
               out_scores.data_ptr(), out.shape[1], self.num_out.data_ptr(), scratch.data_ptr(), _ptr(self._tie_keys), _stream())
+        # what fetch_results' side stream waits for: the tables, not whatever the caller queues behind them
+        if not torch.cuda.is_current_stream_capturing():  # (a graph replay records its own, _optimistic_chain)
+            self._results_ready = torch.cuda.Event()
+            self._results_ready.record()
 
     def _nms_prepare(self, min_dist):
         pad = 2 * min_dist + 1
@@ -650,12 +677,13 @@ class CircleFinder:
               self._nms_ring.shape[0], self.nms_grid.data_ptr(), self.nms_grid.shape[1], self.state.data_ptr(),
               out_cap, _stream())
 
-    def nms_stage(self, min_dist: int, optimistic=False):
+    def nms_stage(self, min_dist: int, optimistic=False, bufs=None):
         """Checked chain: the alive counts come to the host first (they size the output), the rounds are checked for
         convergence afterwards.  ``optimistic``: output capacity and rounds from the calls before; the caller's (find's)
         single status fetch follows -- returns (buffers, rounds launched) and leaves the checks to ``_nms_finish``."""
         if optimistic:
-            bufs = self._out_buffers(self._out_cap)
+            if bufs is None:
+                bufs = self._out_buffers(self._out_cap)
             rounds = 0
             if min_dist > 0:
                 self._nms_prepare(min_dist)
@@ -700,14 +728,127 @@ class CircleFinder:
         self._out_counts = counts.astype(np.int64)
         return bufs[0], bufs[1], self.num_out
 
+    # -- the optimistic chain, eager or as a hipGraph -----------------------------------------------------------
+    def _launch_chain(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw, keep_u8, passthrough_u8,
+                      bufs=None):
+        """Everything between the inputs and the status fetch, launched without looking: returns (output buffers,
+        suppression rounds launched).  ``bufs``: the ordered output goes there instead of into the next public set."""
+        self.status.zero_()
+        self.edge_stage(planes, minmax, low_q, high_q, keep_u8=keep_u8, passthrough_u8=passthrough_u8, optimistic=True)
+        self.circle_stage(seeds, min_roundness, keep_raw=keep_raw, dedup_centres=min_dist > 0, counters_clear=True)
+        return self.nms_stage(min_dist, optimistic=True, bufs=bufs)
+
+    def _optimistic_chain(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw, keep_u8,
+                          passthrough_u8):
+        """The chain as ONE hipGraph launch: the ~40 kernel launches / clears of a call are a fixed sequence as long as
+        the inputs sit at the same addresses and the hints (window passes, sweeps, rounds, list and output capacities)
+        have not moved -- all of that is the graph's key; a sequence is captured when it first shows and replayed from
+        then on (up to 8 graphs are kept).  What changes from call to call travels through fixed buffers: the per-plane
+        min / max (copied into the finder's own block before the launch), the seeds (the pinned block the captured
+        upload reads) and the ordered output (the graph's own set, copied to the caller's).  Per-stage timing (a
+        StageTimer without allow_graphs), debug maps and the raw / uint8 side outputs need the eager launches.
+        MG_NO_GRAPH=1 turns the graphs off."""
+        usable = (self._graphs is not None and (TIMER is _NO_TIMER or getattr(TIMER, "allow_graphs", False))
+                  and not (keep_raw or keep_u8 or self.keep_debug_maps)
+                  and not self.need_angle_map() and planes.stride(2) == 1)
+        if not usable:
+            return self._launch_chain(planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw, keep_u8,
+                                      passthrough_u8)
+        if minmax is None and not passthrough_u8:
+            minmax = plane_minmax(planes)
+        if minmax is not None:
+            self._mm.copy_(minmax.reshape(self.P, 2))  # (stream-ordered: the values are read by the launch behind it)
+            minmax = self._mm
+        win = max(self._recent_win) if self._recent_win else 0
+        sweeps = min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP)
+        rounds = min(self._hint(self._recent_rounds, 2, spare=0), self.MAX_GROUP) if min_dist > 0 else 0
+        # the graph writes its ordered output into a set of its own (the public sets alternate from call to call --
+        # a graph per set would double the captures); two small copies hand it to the caller's set after the replay
+        if self._graph_bufs is None or self._graph_bufs[0].shape[1] != self._out_cap:
+            cap = self._out_cap
+            self._graph_bufs = (torch.empty((self.P, cap, 3), dtype=torch.int32, device=self.dev),
+                                torch.empty((self.P, cap), dtype=torch.float32, device=self.dev),
+                                torch.empty((self.P, 3 * cap), dtype=torch.int32, device=self.dev))
+        ready = ((self.nms_grid is not None or min_dist <= 0) and (self.hist_win is not None or win == 0)
+                 and (min_dist <= 0 or getattr(self, "_nms_dist", None) == min_dist))  # nothing left to allocate / upload
+        key = (planes.data_ptr(), planes.stride(0), planes.stride(1), planes.dtype, passthrough_u8, float(low_q), float(high_q),
+               float(min_roundness), int(min_dist), win, sweeps, rounds, self.coords.data_ptr(), self.coords.shape[1],
+               self._graph_bufs[0].data_ptr(), self.nms_grid.data_ptr() if self.nms_grid is not None else 0)
+        entry = self._graphs.get(key)
+        if entry is None and ready and self.graph_captures < self.MAX_CAPTURES:
+            # captured when a launch sequence first shows (a steady caller shows one; hints that drift -- one sweep more
+            # or less -- add a few; a caller whose sequences never repeat stops capturing after MAX_CAPTURES)
+            entry = self._capture_chain(key, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, passthrough_u8)
+            if self._graphs is None:
+                entry = None
+        if entry is None:
+            return self._launch_chain(planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw, keep_u8,
+                                      passthrough_u8)
+        self.seeds_host.numpy()[:] = np.asarray(seeds, dtype=np.uint64).reshape(self.P).view(np.int64)
+        entry["graph"].replay()
+        # the host-side state the eager launches would have left behind
+        for name, value in entry["state"].items():
+            setattr(self, name, value)
+        self.stats.update(entry["stats"])
+        self._n_collects += 1
+        bufs = self._out_buffers(self._out_cap)
+        bufs[0].copy_(self._graph_bufs[0])
+        bufs[1].copy_(self._graph_bufs[1])
+        self._results_ready = torch.cuda.Event()
+        self._results_ready.record()
+        self.graph_replays += 1
+        return bufs, entry["rounds"]
+
+    def _capture_chain(self, key, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, passthrough_u8):
+        """Stream capture of _launch_chain (on a side stream; nothing runs); None if the capture fails -- the graphs
+        of this finder are then off for good and the caller launches eagerly."""
+        global _CAPTURING
+        if len(self._graphs) >= 8:
+            self._graphs.clear()
+        self.graph_captures += 1
+        main = torch.cuda.current_stream()
+        if getattr(self, "_cap_stream", None) is None:
+            self._cap_stream = torch.cuda.Stream(device=self.dev)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            self._cap_stream.wait_stream(main)
+            _CAPTURING = True
+            # (thread-local: what other host threads do on their streams meanwhile does not concern this capture)
+            with torch.cuda.graph(graph, stream=self._cap_stream, capture_error_mode="thread_local"):
+                _, rounds = self._launch_chain(planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, False, False,
+                                               passthrough_u8, bufs=self._graph_bufs)
+            main.wait_stream(self._cap_stream)
+        except Exception as exc:  # noqa: BLE001  (whatever the runtime refuses: fall back in-process)
+            self._graphs = None
+            self.stats["graph_error"] = f"{type(exc).__name__}: {exc}"
+            try:  # a failed capture leaves its error behind for the next runtime call: take it here
+                torch.cuda.synchronize(self.dev)
+            except Exception:  # noqa: BLE001
+                pass
+            return None
+        finally:
+            _CAPTURING = False
+        entry = {"graph": graph, "rounds": rounds,
+                 "state": {k: getattr(self, k) for k in ("_last_layer", "coord_cap", "u8", "raw", "_tie_keys", "_quantiles",
+                                                          "_gammas")},
+                 "stats": {k: self.stats[k] for k in ("hist_passes",) if k in self.stats}}
+        self._graphs[key] = entry
+        return entry
+
     def find(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw=False, keep_u8=False,
-             passthrough_u8=False, host_results=True):
+             passthrough_u8=False, host_results=True, follow=None):
         """Returns per-plane lists (circles int32 (M,3) [row, col, r], scores float32 (M,)) on the
         host plus the device tensors (out, out_scores, num_out).  ``host_results=False``: only the
         counts come back -- (counts, (out, out_scores, num_out)); ``fetch_results`` copies the lists
         later (e.g. after the ROI pass, which reads the tables on the device, has been launched).
         ``out`` / ``out_scores`` stay valid until the next-but-one ``find`` of this finder (two buffer sets used in
         turn); ``num_out`` is a row of the status block and is cleared by the next ``find``.
+
+        ``follow(out, num_out, out_cap)``: device work that consumes the ordered tables (the ROI pass), queued BEFORE
+        the host waits for the status block -- the GPU goes straight on instead of idling through the round trip and the
+        launch after it.  It reads the tables and the per-plane counts where they are, on the device; if the optimistic
+        chain has to be repaired (or the output gathered again) it is simply called again on the final tables.  Its last
+        return value is ``self.follow_result``.
 
         Host round trips: the checked chain has three (hysteresis convergence + edge counts, alive counts,
         suppression convergence + output counts).  Once a call has gone through it, the next ones run OPTIMISTICALLY:
@@ -720,11 +861,17 @@ class CircleFinder:
                and bool(self._recent_sweeps) and (min_dist <= 0 or bool(self._recent_rounds)))
         self.stats["optimistic"] = False
         if opt:
-            self.status.zero_()
-            self.edge_stage(planes, minmax, low_q, high_q, keep_u8=keep_u8, passthrough_u8=passthrough_u8, optimistic=True)
-            self.circle_stage(seeds, min_roundness, keep_raw=keep_raw, dedup_centres=min_dist > 0, counters_clear=True)
-            bufs, rounds = self.nms_stage(min_dist, optimistic=True)
-            st = self._fetch_status()
+            bufs, rounds = self._optimistic_chain(planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw,
+                                                  keep_u8, passthrough_u8)
+            followed = None
+            if follow is not None:
+                chain_done = torch.cuda.Event()
+                chain_done.record()
+                self.follow_result = follow(bufs[0], self.num_out, bufs[0].shape[1])
+                followed = (self._n_collects, bufs[0].data_ptr())
+                st = self._fetch_status(after=chain_done)  # the host looks at the counters while the ROI pass runs
+            else:
+                st = self._fetch_status()
             sweeps = self._last_layer
             per_sweep = st[8: 8 + sweeps].sum(axis=1)
             edges_ok = (not (st[2] & 0xFF).any() and per_sweep[sweeps - 1] == 0
@@ -757,9 +904,9 @@ class CircleFinder:
             out, out_scores, num_out = self.nms_stage(min_dist)
         counts = self._out_counts  # came back with the suppression's convergence check
         self.stats["n_edges"] = n_edges
+        if follow is not None and (not opt or followed != (self._n_collects, out.data_ptr())):
+            self.follow_result = follow(out, num_out, out.shape[1])  # (the tables it read before were not the final ones)
         if not host_results:
-            self._results_ready = torch.cuda.Event()
-            self._results_ready.record()
             return counts, (out, out_scores, num_out)
         return self.fetch_results(counts, out, out_scores), (out, out_scores, num_out)
 
@@ -878,7 +1025,7 @@ def _upload_i32(values, device):
 
 def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, labels: torch.Tensor | None,
                       want_roi=True, want_masks=True, want_sums=True, reuse_buffers=False, disks=False,
-                      device_tables=None, time_major=False):
+                      device_tables=None, time_major=False, device_counts=None):
     """images (A, C, T, h, w) -- or, with ``time_major`` (and ``disks``), (A, T, C, h, w): the outputs
     are (channel, time)-ordered either way; centers_per_assay: list of (M_a, >=2) int arrays [row, col, ...].
 
@@ -888,6 +1035,12 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
     ``device_tables=(d_beads (A, cap, 3) int32, counts, max_r)`` (with ``disks``): the bead tables
     are still on the device, one padded row per assay as mg_collect_circles writes them; only the
     per-assay counts (host) are needed to size the outputs, ``centers_per_assay`` is ignored.
+
+    ``device_counts=(d_counts (A,) int32 on the device, cap, bound)`` (with ``device_tables=(d_beads, None, max_r)``):
+    the per-assay counts have not reached the host yet -- the pass is queued all the same, for at most ``bound``
+    markers in all (None: A x cap) with the assays' offsets computed on the device (mg_counts_to_offsets, counts cut to
+    ``cap``); ``finish_roi(res, counts)`` cuts the outputs to size once the counts are known and tells whether the
+    bound held.
 
     Returns dict: roi (M, C, T, L, L), fg/bg (M, L, L) uint8, sums (M, C, T, 2) float64
     [fg sum, bg sum], counts (M, 2) int32, offsets (A+1,) numpy.  ``reuse_buffers`` returns views of
@@ -901,10 +1054,15 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         a, c, t, h, w = images.shape
     images = images.contiguous()
     dev = images.device
-    sizes = [int(n) for n in device_tables[1]] if device_tables is not None else [len(b) for b in centers_per_assay]
-    m = int(sum(sizes))
-    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-    res = {"offsets": offsets}
+    if device_counts is not None:
+        d_counts, cap, bound = device_counts
+        assert device_tables is not None and disks and d_counts.dtype == torch.int32 and d_counts.numel() == a
+        sizes, m, offsets = None, (a * int(cap) if bound is None else max(1, min(int(bound), a * int(cap)))), None
+    else:
+        sizes = [int(n) for n in device_tables[1]] if device_tables is not None else [len(b) for b in centers_per_assay]
+        m = int(sum(sizes))
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    res = {"offsets": offsets, "bound": m}
     L = int(roi_len)
     alloc = pooled if reuse_buffers else (lambda name, n, tail, dt, d: torch.empty((n,) + tuple(tail), dtype=dt, device=d))
     res["roi"] = alloc("roi", m, (c, t, L, L), images.dtype, dev) if want_roi else None
@@ -919,9 +1077,13 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         assert disks and d_tab.dtype == torch.int32 and d_tab.is_contiguous() and d_tab.shape[0] == a
         max_r = max(int(max_r), 2)
         tab = _halfwidth_table(max_r, dev)
-        d_off = _upload_i32(offsets, dev)
+        if device_counts is not None:
+            d_off = pooled("roi_offsets", a + 1, (), torch.int32, dev)
+            _call("mg_counts_to_offsets", d_counts.data_ptr(), a, min(int(cap), d_tab.shape[1]), d_off.data_ptr(), _stream())
+        else:
+            d_off = _upload_i32(offsets, dev)
         _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
-              int(time_major), d_tab.data_ptr(), d_tab.shape[1], d_off.data_ptr(), a, int(max(sizes)), m, L, tab.data_ptr(), max_r,
+              int(time_major), d_tab.data_ptr(), d_tab.shape[1], d_off.data_ptr(), a, m, L, tab.data_ptr(), max_r,
               _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
         return res
     beads = np.zeros((m, 3), dtype=np.int32)
@@ -940,7 +1102,7 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         tab = _halfwidth_table(max_r, dev)
         d_off = torch.from_numpy(offsets.astype(np.int32)).to(dev)
         _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
-              int(time_major), d_beads.data_ptr(), 0, d_off.data_ptr(), a, int(max(sizes)), m, L, tab.data_ptr(), max_r,
+              int(time_major), d_beads.data_ptr(), 0, d_off.data_ptr(), a, m, L, tab.data_ptr(), max_r,
               _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
         return res
     d_assay = torch.from_numpy(assay).to(dev)
@@ -950,6 +1112,19 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         d_assay.data_ptr(), d_local.data_ptr(), m, L, _ptr(labels), _ptr(res["roi"]), _ptr(res["fg"]),
         _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
     return res
+
+
+def finish_roi(res, counts):
+    """The outputs of a ``roi_gather_reduce(device_counts=...)`` call cut to the markers there are, now that the
+    per-assay counts are on the host (the kernel placed them compactly, assay after assay).  None if there are more
+    markers than the pass was launched for (the caller runs it again with the counts it now has)."""
+    counts = np.asarray(counts, dtype=np.int64)
+    m = int(counts.sum())
+    if m > res["bound"]:
+        return None
+    out = {k: (v[:m] if isinstance(v, torch.Tensor) else v) for k, v in res.items()}
+    out["offsets"] = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return out
 
 
 def masked_median_u16(roi: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:

@@ -1,5 +1,7 @@
 """Self-starting multi-rank runs: one child process per GPU, started by a parent that never touches
-the GPU (a process that has initialised HIP must not be replaced or forked on this pool).
+the GPU (a process that has initialised HIP must not be replaced or forked on this pool) -- it does not even count
+the GPUs: whether the ranks have a GPU each or share one is decided by every rank for itself
+(``magnify_amd.distributed._share_gpu``), the only GPU count this file can give comes from sysfs.
 
 ``spawn_ranks(argv, n)`` runs ``python argv...`` n times with RANK / LOCAL_RANK / WORLD_SIZE /
 MASTER_ADDR / MASTER_PORT in the environment (what ``torch.distributed.run`` would set; the children
@@ -22,13 +24,26 @@ def free_port() -> int:
 
 
 def visible_gpus() -> int:
-    """Number of GPUs without initialising any (``torch.cuda.device_count`` reads sysfs on this image)."""
+    """GPUs of this node as the kernel driver lists them (KFD topology in sysfs: nodes with SIMDs), narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES; -1 if sysfs has no answer.  No HIP, no torch: nothing is initialised."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
     try:
-        import torch
-
-        return int(torch.cuda.device_count())
-    except Exception:
-        return 0
+        nodes = os.listdir(root)
+    except OSError:
+        return -1
+    n = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(root, node, "properties")) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            n = min(n, len([x for x in os.environ[var].split(",") if x.strip()]))
+    return n
 
 
 def launched_by_torchrun(env=None) -> bool:
@@ -36,15 +51,16 @@ def launched_by_torchrun(env=None) -> bool:
     return "RANK" in env and "WORLD_SIZE" in env
 
 
-def rank_env(rank: int, world: int, port: int, share_gpu: bool, base=None) -> dict:
+def rank_env(rank: int, world: int, port: int, share_gpu: bool | None, base=None) -> dict:
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MG_LAUNCHED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
-    if share_gpu:
-        # fewer GPUs than ranks (the one-GPU test box): every rank on cuda:0, gloo between them
-        env["MG_SHARE_GPU"] = "1"
-        env.setdefault("MG_DIST_BACKEND", "gloo")
+    if share_gpu is not None:  # (None: every rank finds out for itself, distributed._share_gpu)
+        env["MG_SHARE_GPU"] = "1" if share_gpu else "0"
+        if share_gpu:
+            # fewer GPUs than ranks (the one-GPU test box): every rank on cuda:0, gloo between them
+            env.setdefault("MG_DIST_BACKEND", "gloo")
     return env
 
 
@@ -53,13 +69,10 @@ def spawn_ranks(argv, n: int, share_gpu: bool | None = None, timeout: float | No
     ``out`` (default ``sys.stdout``), the other ranks' stdout goes to stderr.  If a rank fails the
     others are terminated (their own PIDs only).  Returns 0 or the first non-zero exit code."""
     out = sys.stdout if out is None else out
-    if share_gpu is None:
-        have = visible_gpus()
-        share_gpu = 0 < have < n
     port = free_port()
     procs = []
     for rank in range(n):
-        env = rank_env(rank, n, port, bool(share_gpu))
+        env = rank_env(rank, n, port, share_gpu)
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, stdout=subprocess.PIPE,
                                       stderr=None, text=True, bufsize=1))
 

@@ -52,6 +52,7 @@ class StackProcessor:
         self.n_assays = n_t if mode == "P" else 1
         self.n_streams = n_streams if (self.n_assays >= 2 * n_streams and not plane_batch) else 1
         self.step_stats = []  # per sub-batch (device counters, host counters) of the last call
+        self._roi_bound = None  # markers the ROI pass is launched for before the counts are known (None: capacity)
         self.stage = None  # device staging buffer of the host-ingest path
         if self.n_streams > 1:
             # The stack is cut into contiguous sub-batches of assays; HIP stream / host thread k works
@@ -67,6 +68,8 @@ class StackProcessor:
             self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n_streams)]
             self.finders = [hp.CircleFinder(per, h, w, self.min_r, self.max_r, num_iter, device=device)
                             for _ in range(self.n_streams)]
+            for f in self.finders:  # several host threads launching side by side: no stream captures among them
+                f._graphs = None
             self.finder = self.finders[0]
             self.batch = per
         else:
@@ -198,11 +201,20 @@ class StackProcessor:
         T, C, h, w = self.T, self.C, self.h, self.w
         ch = self.search_channels[0]
         seeds = [(seed + 1000003 * a) & 0xFFFFFFFFFFFFFFFF for a in range(self.n_assays)]
+        # the ROI pass is queued behind the suppression before the host has seen the bead counts (find's `follow`)
+        roi_pass = lambda d_out, d_num, cap: hp.roi_gather_reduce(  # noqa: E731
+            self.image.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi, reuse_buffers=True, disks=True,
+            device_tables=(d_out, None, self.max_r), device_counts=(d_num, cap, self._roi_bound))
         counts, (d_beads, d_scores, _) = self.finder.find(self.image[:, ch], self.minmax[:, ch].contiguous(), self.low_q,
                                                            self.high_q, self.min_roundness, self.min_r, seeds,
-                                                           host_results=False)
-        out = hp.roi_gather_reduce(self.image.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi,
-                                   reuse_buffers=True, disks=True, device_tables=(d_beads, counts, self.max_r))
+                                                           host_results=False, follow=roi_pass)
+        out = hp.finish_roi(self.finder.follow_result, counts)
+        if out is None:  # more markers than the pass was launched for: once more, with the counts
+            out = hp.roi_gather_reduce(self.image.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi,
+                                       reuse_buffers=True, disks=True, device_tables=(d_beads, counts, self.max_r))
+        # the next call's launch bound: 10 % above this call's markers (its workgroups beyond the real count only cost
+        # their start; the per-plane capacity x planes would be ~30 % above)
+        self._roi_bound = int(1.1 * int(np.sum(counts))) + 16 * self.n_assays
         out["beads"] = [r[0] for r in self.finder.fetch_results(counts, d_beads, d_scores, overlap=True)]
         return out
 

@@ -70,6 +70,27 @@ def test_mode_r_time_sharded_matches_single_process():
         np.testing.assert_array_equal(sums, want["sums"][:, :, lo:hi].cpu().numpy())
 
 
+def test_rccl_collectives_on_one_rank():
+    """Backend "nccl" IS RCCL on ROCm.  The one-GPU box cannot hold two RCCL ranks, but a process group of ONE rank is
+    legal: the collectives of the multi-GPU path (marker-table all-gather, flat-field max all-reduce, bead broadcast,
+    and mode R on top of them) run through RCCL on device tensors here, in a child process that initialises the
+    group before anything else touches the GPU."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MG_SHARE_GPU", "MG_DIST_BACKEND")}
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_child.py")], env=env, capture_output=True, text=True,
+                          timeout=600)
+    assert done.returncode == 0, done.stderr[-3000:]
+    rec = json.loads([ln for ln in done.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["backend"] == "nccl" and rec["world"] == 1
+    assert rec["table_on_device"] and rec["table_equal"]
+    assert rec["max"] == [3.5, -1.0] and rec["shared"] == [[1, 2, 3], [4, 5, 6]] and rec["empty_shape"] == [0, 3]
+    assert rec["mode_r_beads"] >= 5 and rec["mode_r_equal"]
+
+
 def _bench(*flags):
     import json
     import subprocess

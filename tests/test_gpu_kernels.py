@@ -607,6 +607,26 @@ def test_roi_segment_reduce_from_disks(hp, dtype, L):
             np.testing.assert_array_equal(sums[..., 0], win.astype(np.float64)[:, :, sub == i].sum(-1))
             np.testing.assert_array_equal(sums[..., 1], win.astype(np.float64)[:, :, sub == -1].sum(-1))
             assert tuple(res["counts"][g].cpu().numpy()) == (int((sub == i).sum()), int((sub == -1).sum()))
+    # the same pass queued before the host knows the counts: padded device tables + device counts + a capacity, the
+    # assays' offsets computed on the device (mg_counts_to_offsets); a count above the capacity is cut to it
+    if dtype == np.uint16:
+        cap = 160
+        tab = np.zeros((3, cap + 5, 3), dtype=np.int32)
+        for a, beads in enumerate(assays):
+            tab[a, : len(beads)] = beads
+        d_counts = dev(np.array([len(b) for b in assays], dtype=np.int32))
+        late = hp.roi_gather_reduce(dev(images), None, L, None, disks=True, device_tables=(dev(tab), None, 25),
+                                    device_counts=(d_counts, cap, None))
+        late = hp.finish_roi(late, [len(b) for b in assays])
+        np.testing.assert_array_equal(late["offsets"], off)
+        for key in ("roi", "fg", "bg", "sums", "counts"):
+            np.testing.assert_array_equal(late[key].cpu().numpy(), res[key].cpu().numpy(), err_msg=key)
+        cut = hp.roi_gather_reduce(dev(images), None, L, None, disks=True, device_tables=(dev(tab), None, 25),
+                                   device_counts=(d_counts, 100, 120))
+        cut = hp.finish_roi(cut, [11, 100, 0])
+        np.testing.assert_array_equal(cut["roi"][:11].cpu().numpy(), res["roi"][:11].cpu().numpy())
+        assert cut["roi"].shape[0] == 111
+        assert hp.finish_roi(dict(cut, bound=110), [11, 100, 0]) is None  # more markers than the launch was sized for
 
 
 # ---------------------------------------------------------------------------------------------
@@ -676,6 +696,47 @@ def test_optimistic_chain_equals_checked_chain(hp):
     assert len(want[1][0]) >= 4  # the scenes do hold beads
 
 
+def test_graph_replay_equals_eager_launches(hp):
+    """The optimistic chain replayed as one hipGraph launch (same input buffer, same hints: captured at the second
+    coming of a launch sequence) against a finder that launches every kernel eagerly: same tables call after call,
+    with new images and seeds travelling through the fixed buffers, through a call whose image breaks the hints (many
+    more beads: the chain is repaired eagerly) and back, and with the ROI pass queued behind the replay (`follow`)."""
+    shape = (320, 384)
+    images = [np.stack([noisy_bead_image(300 + 10 * n + j, shape, 6)[0] for j in range(2)]) for n in range(14)]
+    images[6] = np.stack([noisy_bead_image(400 + k, shape, 40, r_lo=6, r_hi=10, poisson=200.0)[0] for k in range(2)])
+    # two input buffers used in turn: two launch sequences, two graphs -- each is replayed after the OTHER has been
+    # captured (memset nodes of the first graph were once seen to run with the second graph's parameters)
+    bufs = [torch.empty((2,) + shape, dtype=torch.uint16, device="cuda") for _ in range(2)]
+    cf = hp.CircleFinder(2, shape[0], shape[1], 5, 21, 60000)
+    ref = hp.CircleFinder(2, shape[0], shape[1], 5, 21, 60000)
+    ref._graphs = None
+    assert cf._graphs is not None
+    followed = []
+    for n, planes in enumerate(images):
+        buf = bufs[n % 2]
+        buf.copy_(dev(planes))
+        if n > 0:  # generous, steady hints (these small scenes need 2 .. 10 sweeps / rounds): one launch sequence
+            cf._recent_sweeps[:], cf._recent_rounds[:] = [12], [12]
+            if cf.coords.shape[1] < 80000:
+                cf.coords = torch.empty((2, 80000, 2), dtype=torch.int32, device="cuda")
+        seeds = [7000 + 2 * n, 7001 + 2 * n]
+        got, (d_out, _, d_num) = cf.find(buf, None, 0.1, 0.9, 0.3, 5, seeds,
+                                         follow=lambda out, num, cap: (out.clone(), num.clone()))
+        followed.append(cf.follow_result)
+        want, _ = ref.find(buf, None, 0.1, 0.9, 0.3, 5, seeds)
+        for p in range(2):
+            np.testing.assert_array_equal(got[p][0], want[p][0], err_msg=f"call {n} plane {p}")
+            np.testing.assert_array_equal(got[p][1], want[p][1], err_msg=f"call {n} plane {p}")
+            # what the follow-up saw on the device = the final tables
+            k = len(got[p][0])
+            assert int(followed[-1][1][p].item()) == k
+            np.testing.assert_array_equal(followed[-1][0][p, :k].cpu().numpy(), got[p][0])
+        np.testing.assert_array_equal(cf.n_edges_host, ref.n_edges_host)
+    assert "graph_error" not in cf.stats, cf.stats.get("graph_error")
+    assert cf.graph_replays >= 8 and 2 <= cf.graph_captures <= 6, (cf.graph_replays, cf.graph_captures, cf.calls)
+    assert ref.graph_replays == 0
+
+
 def test_edge_grid_chunked_scan(hp):
     """The many-workgroup prefix sum over the cells (d_scan_state) against the one-workgroup one, and the capacity
     guard of the one-call form (phases = 3): a plane with more edges than the list holds reports 0 edges and its
@@ -710,7 +771,7 @@ def test_edge_grid_chunked_scan(hp):
     counts, starts, num = out["one"]
     np.testing.assert_array_equal(starts, np.cumsum(counts, axis=1) - counts)
     np.testing.assert_array_equal(num, counts.sum(axis=1))
-    assert state.numel() == P * ((n_cells + 4095) // 4096) and state.numel() > P
+    assert state.numel() == P * ((n_cells + 4095) // 4096 + 1) and state.numel() > 2 * P  # chunk states + a ticket per plane
     # one call, capacity between the two densities
     cap = int(num[0]) + 10
     coords = torch.full((P, cap, 2), -7, dtype=torch.int32, device="cuda")
