@@ -74,11 +74,15 @@ int mg_perimeter_table(int min_r, int max_r, int32_t* out_rc, double* out_expect
  * reference's single-assay semantics, the maxima span the whole array; n_groups = number of
  * assays when every time slice is its own assay).  d_max2 is double[n_groups][2], pre-initialised
  * by the caller to -inf.  dark/flat: scalar when d_dark / d_flat is NULL, else a (ty, tx) image
- * of type dark_dtype / flat_dtype (MG_F32 or MG_F64) broadcast over tiles. */
+ * of type dark_dtype / flat_dtype (MG_F32 or MG_F64) broadcast over tiles.
+ * d_scratch (optional): mg_flatfield_max_scratch_floats(dtype, ty, tx) floats owned by the caller; with it the
+ * integer-pixel / float32-flat path reads the flat image through a per-chunk bound an eighth (a sixteenth) of its
+ * size and touches the image itself only where a pixel can still raise M2 (same result, less traffic). */
+int64_t mg_flatfield_max_scratch_floats(int dtype, int ty, int tx);
 int mg_flatfield_max(const void* d_tiles, int dtype, int64_t n_tiles, int n_groups, int ty, int tx,
                      double dark, const void* d_dark, int dark_dtype,
                      double flat, const void* d_flat, int flat_dtype,
-                     double* d_max2, void* stream);
+                     double* d_max2, float* d_scratch, int64_t scratch_floats, void* stream);
 
 /* 1 when the correction is the identity for this pixel type: integer pixels, scalar dark 0 and scalar flat 1 (the
  * defaults of the reference's flatfield_correct, preprocess.py:62).  mg_flatfield_apply_stitch then only crops and

@@ -31,7 +31,8 @@ PROTOTYPES = {
     "mg_disk_halfwidths": [_i, _p],
     "mg_cv_disk_halfwidths": [_i, _p],
     "mg_perimeter_table": [_i, _i, _p, _p, _p, _i],
-    "mg_flatfield_max": [_p, _i, _l, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p],
+    "mg_flatfield_max": [_p, _i, _l, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p, _l, _p],
+    "mg_flatfield_max_scratch_floats": [_i, _i, _i],
     "mg_flatfield_is_identity": [_i, _d, _p, _d, _p],
     "mg_flatfield_apply_stitch": [_p, _i, _l, _i, _i, _i, _i, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p, _p, _p],
     "mg_plane_minmax": [_p, _i, _i, _l, _i, _i, _l, _p, _p],
@@ -73,7 +74,7 @@ PROTOTYPES = {
     "mg_masked_sums": [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p],
 }
 
-RETURNS_INT64 = {"mg_scharr_hist_scratch_words", "mg_edge_grid_scan_words"}
+RETURNS_INT64 = {"mg_scharr_hist_scratch_words", "mg_edge_grid_scan_words", "mg_flatfield_max_scratch_floats"}
 
 _lib = None
 

@@ -274,10 +274,21 @@ __global__ __launch_bounds__(256) void k_flatfield_max_fast(const T* __restrict_
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (g0 + q >= tiles_per_group) break;
+        // the float32 test for all N pixels first, one branch for the chunk: after the first few chunks a pixel that
+        // can beat the running maximum is rare, and a branch per pixel cost more than the arithmetic
+        bool cand = false;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
           const uint32_t xi = (uint32_t)x4[q][j];
           xmax = max(xmax, xi);
+          const float t_f = fmaxf((float)xi - dk_f, 0.0f);
+          const bool in_range = fl[j] > 1e-30f && fl[j] < 1e30f;
+          cand |= !(in_range && t_f * rc[j] <= thr);
+        }
+        if (!cand) continue;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const uint32_t xi = (uint32_t)x4[q][j];
           const float t_f = fmaxf((float)xi - dk_f, 0.0f);
           const bool in_range = fl[j] > 1e-30f && fl[j] < 1e30f;
           if (in_range && t_f * rc[j] <= thr) continue;  // provably below the running maximum
@@ -285,6 +296,104 @@ __global__ __launch_bounds__(256) void k_flatfield_max_fast(const T* __restrict_
           t = t < 0.0 ? 0.0 : t;
           m2 = mg_nanmax(m2, t / (double)fl[j]);
           thr = (m2 == m2 && m2 < 1e30) ? (float)m2 * (1.0f - 1e-5f) : -INFINITY;
+        }
+      }
+    }
+  }
+  double m1 = -INFINITY;
+  if (any) {
+    m1 = (double)xmax - dark;
+    m1 = m1 < 0.0 ? 0.0 : m1;
+  }
+  block_atomic_max2(m1, m2, out);
+}
+
+// The same pass with the flat image read at an eighth of its size: d_rcmax[v] = the largest float32 reciprocal of the
+// N flat values of chunk v (-1 if one of them is outside the range the float32 test is valid in).  A chunk whose
+// largest pixel, times that, cannot beat the running maximum is done after a few integer maxima -- its flat values are
+// not even loaded; after the first chunks that is all but a handful.  (Before: 64 MB of flat image re-read for every
+// assay, 2 GB of the pass's 10.7 GB of traffic at 64 assays, and a float32 multiply / compare per pixel.)
+template <int N>
+__global__ __launch_bounds__(256) void k_flat_rcmax(const float* __restrict__ d_flat, int64_t nvec, float* __restrict__ d_rcmax) {
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    float m = 0.0f;
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+      const float4 f = reinterpret_cast<const float4*>(d_flat + v * N)[q];
+      const float fl[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ok = ok && fl[j] > 1e-30f && fl[j] < 1e30f;
+        m = fmaxf(m, __builtin_amdgcn_rcpf(fl[j]));
+      }
+    }
+    d_rcmax[v] = ok ? m : -1.0f;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_flatfield_max_lean(const T* __restrict__ tiles, int64_t tiles_per_group,
+                                                             int64_t tile_elems, double dark,
+                                                             const float* __restrict__ d_flat,
+                                                             const float* __restrict__ d_rcmax,
+                                                             double* __restrict__ out) {
+  constexpr int N = VecOf<T>::N;
+  constexpr int UV = 2;  // chunk positions per trip: UV x 4 sixteen-byte loads in flight per lane
+  const int group = blockIdx.y;
+  tiles += (int64_t)group * tiles_per_group * tile_elems;
+  out += 2 * group;
+  const float dk_f = (float)dark;
+  uint32_t xmax = 0;
+  bool any = false;
+  double m2 = -INFINITY;
+  float thr = -INFINITY;
+  const int64_t nvec = tile_elems / N;  // the launcher guarantees tile_elems % N == 0
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v0 < nvec; v0 += UV * stride) {
+    float rcm[UV];
+#pragma unroll
+    for (int u = 0; u < UV; ++u) rcm[u] = d_rcmax[min(v0 + u * stride, nvec - 1)];
+    any = true;
+    for (int64_t g0 = 0; g0 < tiles_per_group; g0 += 4) {  // four tiles (channels) of the group per trip, loads together
+      T x4[UV][4][N];
+#pragma unroll
+      for (int u = 0; u < UV; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          load_vec<T, N>(tiles + min(g0 + q, tiles_per_group - 1) * tile_elems + min(v0 + u * stride, nvec - 1) * N, x4[u][q]);
+#pragma unroll
+      for (int u = 0; u < UV; ++u) {
+        const int64_t v = v0 + u * stride;
+        if (v >= nvec) break;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (g0 + q >= tiles_per_group) break;
+          uint32_t cm = 0;
+#pragma unroll
+          for (int j = 0; j < N; ++j) cm = max(cm, (uint32_t)x4[u][q][j]);
+          xmax = max(xmax, cm);
+          // t -> float(x) - dark -> max(., 0) and the product with a non-negative reciprocal are monotone: if the chunk's
+          // largest pixel with the chunk's largest reciprocal stays at or below the threshold, every pixel does
+          const float tf = fmaxf((float)cm - dk_f, 0.0f);
+          if (rcm[u] >= 0.0f && tf * rcm[u] <= thr) continue;
+          float fl[N];
+#pragma unroll
+          for (int k4 = 0; k4 < N / 4; ++k4) {
+            const float4 f = reinterpret_cast<const float4*>(d_flat + v * N)[k4];
+            fl[4 * k4] = f.x, fl[4 * k4 + 1] = f.y, fl[4 * k4 + 2] = f.z, fl[4 * k4 + 3] = f.w;
+          }
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const uint32_t xi = (uint32_t)x4[u][q][j];
+            const float t_f = fmaxf((float)xi - dk_f, 0.0f);
+            const bool in_range = fl[j] > 1e-30f && fl[j] < 1e30f;
+            if (in_range && t_f * __builtin_amdgcn_rcpf(fl[j]) <= thr) continue;  // provably below the running maximum
+            double t = (double)xi - dark;
+            t = t < 0.0 ? 0.0 : t;
+            m2 = mg_nanmax(m2, t / (double)fl[j]);
+            thr = (m2 == m2 && m2 < 1e30) ? (float)m2 * (1.0f - 1e-5f) : -INFINITY;
+          }
         }
       }
     }
@@ -331,6 +440,38 @@ __device__ __forceinline__ T correct_pixel(double t, double fl, double r, double
   e = e * m1;
   e = e / m2;
   return cast_trunc<T>(e);
+}
+
+// N pixels at once for an integer output type: the fast products of all N first (straight-line code), ONE test whether
+// any of them sits too close to an integer (or the operands are out of the fast path's range), and only then -- a few
+// chunks in a million -- the exact two-division path for the chunk.  (A branch per pixel made the pass VALU / branch
+// bound: ~25 vector and ~6 scalar instructions per pixel; the data path itself is a dozen.)
+template <typename T, int N>
+__device__ __forceinline__ void correct_chunk(const T (&x)[N], const double (&dk)[N], const double (&fl)[N],
+                                              const double (&r)[N], double m1, double m2, double k, bool fast_ok, T (&o)[N]) {
+  double t[N];
+  bool unsure = !fast_ok || !IsIntegral<T>::value;  // (other output types: always the reference's own operations)
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    t[j] = (double)x[j] - dk[j];
+    t[j] = t[j] < 0.0 ? 0.0 : t[j];
+    if (!IsIntegral<T>::value) continue;
+    const double v = t[j] * r[j] * k;
+    const double fv = floor(v);
+    const double fr = v - fv;
+    o[j] = (T)(unsigned int)fv;
+    // t == 0 gives exactly 0 (m1, m2 finite and positive under fast_ok); r == 0 marks a flat value outside the range
+    unsure |= !((fr > 1e-6 && fr < 1.0 - 1e-6 && v < 4.0e9) || t[j] == 0.0) || r[j] == 0.0;
+  }
+  if (unsure) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double e = t[j] / fl[j];
+      e = e * m1;
+      e = e / m2;
+      o[j] = cast_trunc<T>(e);
+    }
+  }
 }
 
 constexpr int PLANES_PER_BLOCK = 8;
@@ -525,12 +666,7 @@ __global__ __launch_bounds__(256) void k_apply_stitch_aligned(const T* __restric
           const double m1 = d_max2[2 * group], m2 = d_max2[2 * group + 1];
           const double kk = m1 / m2;
           const bool ok = kk > 0.0 && kk < 1e30 && m1 > 0.0 && m1 < 1e300 && m2 > 0.0 && m2 < 1e300;
-#pragma unroll
-          for (int j = 0; j < N; ++j) {
-            double t = (double)x[j] - dk[j];
-            t = t < 0.0 ? 0.0 : t;
-            o[j] = correct_pixel<T>(t, fl[j], rr[j], m1, m2, kk, ok);
-          }
+          correct_chunk<T, N>(x, dk, fl, rr, m1, m2, kk, ok, o);
         } else {
 #pragma unroll
           for (int j = 0; j < N; ++j) o[j] = x[j];
@@ -625,7 +761,7 @@ __global__ __launch_bounds__(256) void k_plane_minmax(const T* __restrict__ src,
 template <typename T>
 int launch_max(const void* d_tiles, int64_t tiles_per_group, int n_groups, int64_t tile_elems, double dark,
                const void* d_dark, int dark_dt, double flat, const void* d_flat, int flat_dt, double* d_max2,
-               hipStream_t s) {
+               float* d_scratch, int64_t scratch_floats, hipStream_t s) {
   if (tiles_per_group == 0 || n_groups == 0 || tile_elems == 0) return MG_OK;
   const int64_t nvec = tile_elems / VecOf<T>::N + 1;
   const int per_group = std::min(512, std::max(1, 4096 / n_groups));
@@ -644,6 +780,20 @@ int launch_max(const void* d_tiles, int64_t tiles_per_group, int n_groups, int64
   if (IsIntegral<T>::value && !d_dark && d_flat && flat_dt == MG_F32 && tile_elems % VecOf<T>::N == 0 &&
       (reinterpret_cast<uintptr_t>(d_flat) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_tiles) & 15) == 0 &&
       fabs(dark) < 16777216.0 && (double)(float)dark == dark) {
+    constexpr int N = VecOf<T>::N;
+    if (d_scratch && scratch_floats >= tile_elems / N && (reinterpret_cast<uintptr_t>(d_scratch) & 3) == 0) {
+      const int64_t cvec = tile_elems / N;
+      hipLaunchKernelGGL((k_flat_rcmax<N>), dim3((unsigned)std::min<int64_t>((cvec + 255) / 256, 2048)), dim3(256), 0, s,
+                         (const float*)d_flat, cvec, d_scratch);
+      MG_CHECK_LAUNCH();
+      // one resident round of workgroups in all (74 VGPRs: 6 per CU), however many groups share them: every workgroup
+      // ends with two compare-and-swap maxima on its group's cache line
+      const int per = (int)std::max<int64_t>(1, std::min<int64_t>((cvec + 255) / 256, std::max(1, 1536 / n_groups)));
+      hipLaunchKernelGGL((k_flatfield_max_lean<T>), dim3(per, n_groups), dim3(256), 0, s, (const T*)d_tiles, tiles_per_group,
+                         tile_elems, dark, (const float*)d_flat, d_scratch, d_max2);
+      MG_CHECK_LAUNCH();
+      return MG_OK;
+    }
     hipLaunchKernelGGL((k_flatfield_max_fast<T>), dim3(blocks, n_groups), dim3(256), 0, s, (const T*)d_tiles,
                        tiles_per_group, tile_elems, dark, (const float*)d_flat, d_max2);
     MG_CHECK_LAUNCH();
@@ -722,16 +872,23 @@ bool df_dtype_ok(const void* p, int dt) { return p == nullptr || dt == MG_F32 ||
 
 extern "C" int mg_version(void) { return 1; }
 
+extern "C" int64_t mg_flatfield_max_scratch_floats(int dtype, int ty, int tx) {
+  if (ty <= 0 || tx <= 0) return -1;
+  const int n = dtype == MG_U8 ? 16 : dtype == MG_U16 ? 8 : 0;  // (only the integer fast path uses the scratch)
+  return n ? ((int64_t)ty * tx + n - 1) / n : 0;
+}
+
 extern "C" int mg_flatfield_max(const void* d_tiles, int dtype, int64_t n_tiles, int n_groups, int ty, int tx,
                                 double dark, const void* d_dark, int dark_dtype, double flat, const void* d_flat,
-                                int flat_dtype, double* d_max2, void* stream) {
+                                int flat_dtype, double* d_max2, float* d_scratch, int64_t scratch_floats, void* stream) {
   if (!d_tiles || !d_max2 || n_tiles < 0 || ty <= 0 || tx <= 0 || n_groups <= 0 || n_groups > 65535) return MG_EINVAL;
   if (n_tiles % n_groups) return MG_EINVAL;
   if (!df_dtype_ok(d_dark, dark_dtype) || !df_dtype_ok(d_flat, flat_dtype)) return MG_EINVAL;
   const int64_t tile_elems = (int64_t)ty * tx, tpg = n_tiles / n_groups;
   hipStream_t s = mg_stream(stream);
 #define MG_MAX(T) \
-  return launch_max<T>(d_tiles, tpg, n_groups, tile_elems, dark, d_dark, dark_dtype, flat, d_flat, flat_dtype, d_max2, s)
+  return launch_max<T>(d_tiles, tpg, n_groups, tile_elems, dark, d_dark, dark_dtype, flat, d_flat, flat_dtype, d_max2, \
+                       d_scratch, scratch_floats, s)
   switch (dtype) {
     case MG_U8: MG_MAX(uint8_t);
     case MG_U16: MG_MAX(uint16_t);

@@ -151,8 +151,12 @@ def flatfield_max(tiles: torch.Tensor, flatfield=1.0, darkfield=0.0, n_groups=1)
     fl, flt, flc = _df_operand(flatfield, ty, tx, tiles.device)
     max2 = torch.full((n_groups, 2), -math.inf, dtype=torch.float64, device=tiles.device)
     n_tiles = tiles.numel() // (ty * tx)
-    _call("mg_flatfield_max", tiles.data_ptr(), nat.dtype_code(tiles.dtype), n_tiles, n_groups, ty, tx, dk, _ptr(dkt),
-                                         dkc, fl, _ptr(flt), flc, max2.data_ptr(), _stream())
+    code = nat.dtype_code(tiles.dtype)
+    words = int(nat.lib().mg_flatfield_max_scratch_floats(code, ty, tx)) if flt is not None else 0
+    # (one block per stream: the sub-batch threads of a multi-stream StackProcessor fill it side by side)
+    scratch = pooled(f"flatfield_max_scratch@{_stream()}", words, (), torch.float32, tiles.device) if words > 0 else None
+    _call("mg_flatfield_max", tiles.data_ptr(), code, n_tiles, n_groups, ty, tx, dk, _ptr(dkt),
+                                         dkc, fl, _ptr(flt), flc, max2.data_ptr(), _ptr(scratch), words, _stream())
     return max2
 
 
