@@ -25,6 +25,8 @@ from .pipeline import Pipeline  # noqa: F401
 from . import reader, preprocess, stitch, find, identify, postprocess, reduce, utils, filter  # noqa: F401,E402  (register components)
 from .utils import seed  # noqa: F401
 from .file import load, save  # noqa: F401
+from . import sink  # noqa: F401,E402
+from .sink import HostSink, SaveSink  # noqa: F401,E402
 
 __all__ = ["component", "microfluidic_chip", "microfluidic_chip_pipe", "mrbles", "mrbles_pipe", "beads", "beads_pipe",
            "image", "image_pipe", "save", "load", "Pipeline", "DataArray", "Dataset", "seed", "find", "identify", "postprocess",

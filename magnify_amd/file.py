@@ -76,8 +76,9 @@ _SHARD = 1 << 31  # default size of the largest variable of a part
 
 
 def _nbytes(v):
-    a = v.values if not isinstance(v, np.ndarray) else v
-    return int(np.prod(a.shape, dtype=np.int64)) * (1 if a.dtype == np.bool_ else a.dtype.itemsize)
+    """Bytes of a variable as it will be stored -- from its shape and dtype (a device-resident array stays where it is)."""
+    dtype = np.dtype(v.dtype)
+    return int(np.prod(v.shape, dtype=np.int64)) * (1 if dtype == np.bool_ else dtype.itemsize)
 
 
 def _take_block(ds: Dataset, dim, lo, hi, first):
@@ -89,7 +90,8 @@ def _take_block(ds: Dataset, dim, lo, hi, first):
             return v if first else None
         idx = [slice(None)] * len(v.dims)
         idx[v.dims.index(dim)] = slice(lo, hi)
-        return DataArray(np.asarray(v.values)[tuple(idx)], v.dims, None, v.name, dict(v.attrs or {}))
+        # (sliced where the array lives: a device-resident variable comes to the host part by part, when it is written)
+        return DataArray(v.data[tuple(idx)], v.dims, None, v.name, dict(v.attrs or {}))
 
     for k, c in ds.coords.items():
         piece = cut(c)
@@ -108,6 +110,7 @@ def save(file, xp, shard_bytes=None):
     ds = xp.unstack() if isinstance(xp, Dataset) else Dataset({xp.name or "data": xp})
     sizes = {k: _nbytes(v) for k, v in list(ds.data_vars.items()) + list(ds.coords.items())}
     biggest = max(sizes.values(), default=0)
+    _remove_stale(file)  # what an earlier save left under this name (the whole file, or parts -- possibly more of them)
     if shard_bytes is None and biggest <= _LIMIT:
         return _write(file, ds)
     limit = int(shard_bytes or _SHARD)
@@ -118,6 +121,11 @@ def save(file, xp, shard_bytes=None):
     per_row = max((sizes[k] // max(ds.sizes[dim], 1) for k, v in list(ds.data_vars.items()) + list(ds.coords.items())
                    if dim in v.dims), default=1)
     rows = max(1, limit // max(per_row, 1))
+    # parts end at chunk boundaries of the variables' chunk policy (find.py:506-531), when that leaves at least a chunk
+    policy = [v.attrs["__mg_chunks__"][dim] for v in list(ds.data_vars.values()) + list(ds.coords.values())
+              if dim in v.attrs.get("__mg_chunks__", {})]
+    if policy and rows >= max(policy) > 0:
+        rows -= rows % max(policy)
     n = ds.sizes[dim]
     bounds = list(range(0, n, rows)) + [n]
     for k, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
@@ -126,7 +134,29 @@ def save(file, xp, shard_bytes=None):
         _write(f"{file}.part{k:03d}", part)
 
 
+def _remove_stale(file):
+    import glob
+    import os
+
+    for old in [str(file)] + glob.glob(glob.escape(str(file)) + ".part[0-9][0-9][0-9]"):
+        if os.path.isfile(old):
+            os.remove(old)
+
+
 def _write(file, ds):
+    """One NetCDF-3 file, written under a temporary name and renamed: a crash leaves no half-written file behind."""
+    import os
+
+    tmp = f"{file}.tmp{os.getpid()}"
+    try:
+        _write_nc(tmp, ds)
+        os.replace(tmp, str(file))
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
+def _write_nc(file, ds):
     from scipy.io import netcdf_file
 
     coord_names = [k for k, c in ds.coords.items() if not (c.dims == (k,))]
@@ -172,8 +202,10 @@ def load(file):
     import glob
     import os
 
-    if not os.path.exists(str(file)):
-        parts = sorted(glob.glob(glob.escape(str(file)) + ".part[0-9][0-9][0-9]"))
+    parts = sorted(glob.glob(glob.escape(str(file)) + ".part[0-9][0-9][0-9]"))
+    if parts and os.path.exists(str(file)):
+        raise ValueError(f"{file}: both the file and parts of it exist (two different saves); remove one")
+    if parts or not os.path.exists(str(file)):
         if not parts:
             raise FileNotFoundError(str(file))
         pieces = [_read(p, restack=False) for p in parts]

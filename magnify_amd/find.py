@@ -106,11 +106,14 @@ class BeadFinder:
         # the kernel writes 0 / 1 bytes: reinterpreted as bool, not converted (two passes over M L^2 bytes less)
         fg = out["fg"].view(torch.bool)[:, None].expand(m, n_t, L, L)  # geometry replicated over time (find.py:585-586)
         bg = out["bg"].view(torch.bool)[:, None].expand(m, n_t, L, L)
-        assay["roi"] = DataArray(out["roi"], ("mark", "channel", "time", "roi_y", "roi_x"))
+        # the reference's chunk policy (find.py:506-531): every channel / timepoint of a marker together, markers per
+        # chunk for >= 1 MB; recorded on the variables (xr_lite.DataArray.chunk: what to_xarray / mg.save go by)
+        per = {"mark": utils.roi_mark_chunk(m, n_c, n_t, L)}
+        assay["roi"] = DataArray(out["roi"], ("mark", "channel", "time", "roi_y", "roi_x")).chunk(per)
         xy = beads.astype(np.float64)
         assay = assay.assign_coords(
-            fg=(("mark", "time", "roi_y", "roi_x"), fg),
-            bg=(("mark", "time", "roi_y", "roi_x"), bg),
+            fg=DataArray(fg, ("mark", "time", "roi_y", "roi_x")).chunk(per),
+            bg=DataArray(bg, ("mark", "time", "roi_y", "roi_x")).chunk(per),
             x=(("mark", "time"), np.repeat(xy[:, None, 1], n_t, axis=1)),
             y=(("mark", "time"), np.repeat(xy[:, None, 0], n_t, axis=1)),
             valid=(("mark", "time"), np.ones((m, n_t), dtype=bool)),
@@ -363,7 +366,13 @@ class ButtonFinder:
             valid=(("mark_row", "mark_col", "time"), valid),
         )
         assay._cache["radius"] = radius
-        return assay.stack_mark()
+        assay = assay.stack_mark()
+        # rechunked along the markers after stacking, as the reference does (find.py:182-201; bounded by the ROW count)
+        per = {"mark": utils.roi_mark_chunk(n_rows, n_c, n_t, L)}
+        assay["roi"] = assay.data_vars["roi"].chunk(per)
+        for k in ("fg", "bg"):
+            assay.coords[k] = assay.coords[k].chunk(per)
+        return assay
 
     @registry.components.register("find_buttons")
     def make(row_dist, col_dist, min_button_diameter, max_button_diameter, chamber_diameter, top_chamber, left_chamber,

@@ -1029,7 +1029,7 @@ def _upload_i32(values, device):
 
 def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, labels: torch.Tensor | None,
                       want_roi=True, want_masks=True, want_sums=True, reuse_buffers=False, disks=False,
-                      device_tables=None, time_major=False, device_counts=None):
+                      device_tables=None, time_major=False, device_counts=None, pool_tag=""):
     """images (A, C, T, h, w) -- or, with ``time_major`` (and ``disks``), (A, T, C, h, w): the outputs
     are (channel, time)-ordered either way; centers_per_assay: list of (M_a, >=2) int arrays [row, col, ...].
 
@@ -1048,7 +1048,8 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
 
     Returns dict: roi (M, C, T, L, L), fg/bg (M, L, L) uint8, sums (M, C, T, 2) float64
     [fg sum, bg sum], counts (M, 2) int32, offsets (A+1,) numpy.  ``reuse_buffers`` returns views of
-    pooled buffers that the next call overwrites (steady-state streaming use)."""
+    pooled buffers that the next call overwrites (steady-state streaming use); ``pool_tag`` names a separate set of them
+    (a streaming caller alternates two: the host copy of one chunk's outputs runs beside the next chunk's pass)."""
     require_gpu()
     if time_major:
         if not disks:
@@ -1068,7 +1069,8 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     res = {"offsets": offsets, "bound": m}
     L = int(roi_len)
-    alloc = pooled if reuse_buffers else (lambda name, n, tail, dt, d: torch.empty((n,) + tuple(tail), dtype=dt, device=d))
+    alloc = ((lambda name, n, tail, dt, d: pooled(name + pool_tag, n, tail, dt, d)) if reuse_buffers
+             else (lambda name, n, tail, dt, d: torch.empty((n,) + tuple(tail), dtype=dt, device=d)))
     res["roi"] = alloc("roi", m, (c, t, L, L), images.dtype, dev) if want_roi else None
     res["fg"] = alloc("fg", m, (L, L), torch.uint8, dev) if want_masks else None
     res["bg"] = alloc("bg", m, (L, L), torch.uint8, dev) if want_masks else None

@@ -1,0 +1,134 @@
+"""Where the results of a streamed run go.
+
+``stack.process_stream`` hands out, chunk by chunk, views of pooled device buffers that the chunk after next
+overwrites; the reference keeps every assay's ``roi / fg / bg`` by spilling them to a zarr store
+(``Dataset.mg.cache``, accessor.py:18-35, called at find.py:604) and returns one Dataset per assay
+(pipeline.py:14-29).  A sink is what does that here: ``process_stream(..., sink=s)`` calls ``s(out)`` for every chunk
+while its buffers are valid; the sink copies what it keeps to page-locked host memory on a side stream (the copy of
+chunk k runs beside the kernels of chunk k + 1: the pooled buffers alternate between two sets) and builds, per
+timepoint (= assay, mode P), a Dataset with the reference's schema (find.py:503-555):
+``roi (mark, channel, time, roi_y, roi_x)``, coords ``fg, bg (mark, time, roi_y, roi_x)``, ``x, y, valid (mark, time)``
+(+ ``time`` / ``channel`` labels when the reader gave them).
+
+  * ``HostSink``: keeps the assays in host memory (``.assays``), optionally without ROI pixels.
+  * ``SaveSink(pattern)``: writes every assay with ``mg.save`` as soon as its copy has landed (``pattern`` takes
+    ``{index}`` = global timepoint index; a rank of a multi-GPU run passes a pattern of its own) and keeps only the
+    file names: nothing accumulates, a terabyte-scale series leaves a directory of NetCDF files that ``mg.load`` reads.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import file as mgfile
+from .xr_lite import DataArray, Dataset
+
+
+class _Sink:
+    def __init__(self, want_roi=True, want_masks=True):
+        self.want_roi, self.want_masks = want_roi, want_masks
+        self._side = None
+        self._pending = None  # (event, host tensors, meta) of the chunk whose copy is in flight
+
+    # -- called by process_stream ---------------------------------------------------------------------------------
+    def __call__(self, out):
+        """Queue the device-to-host copy of this chunk's outputs (side stream, page-locked destination) and finish
+        the chunk before it."""
+        dev_keys = [k for k in ("sums", "counts") + (("roi",) if self.want_roi else ()) + (("fg", "bg") if self.want_masks else ())
+                    if out.get(k) is not None]
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        host = {}
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            for k in dev_keys:
+                src = out[k]
+                dst = torch.empty(src.shape, dtype=src.dtype).pin_memory() if src.numel() else torch.empty(src.shape, dtype=src.dtype)
+                dst.copy_(src, non_blocking=True)
+                src.record_stream(self._side)
+                host[k] = dst
+            done = torch.cuda.Event()
+            done.record(self._side)
+        meta = {"beads": [np.asarray(b) for b in out["beads"]], "offsets": np.asarray(out["offsets"]),
+                "first": int(out.get("first_timepoint", 0)), "time": out.get("time"), "channel": out.get("channel")}
+        previous, self._pending = self._pending, (done, host, meta)
+        if previous is not None:
+            self._finish(*previous)
+        return done  # process_stream makes the chunk after next wait for it (that one reuses these device buffers)
+
+    def close(self):
+        if self._pending is not None:
+            previous, self._pending = self._pending, None
+            self._finish(*previous)
+
+    # -- per assay ---------------------------------------------------------------------------------------------------
+    def _finish(self, done, host, meta):
+        done.synchronize()
+        arrays = {k: v.numpy() for k, v in host.items()}
+        off = meta["offsets"]
+        for a, beads in enumerate(meta["beads"]):
+            lo, hi = int(off[a]), int(off[a + 1])
+            self.take(meta["first"] + a, self.assay_dataset(beads, {k: v[lo:hi] for k, v in arrays.items()},
+                                                            None if meta["time"] is None else meta["time"][a], meta["channel"]))
+
+    @staticmethod
+    def assay_dataset(beads, arrays, time_label=None, channels=None):
+        """One timepoint's results as the reference's Dataset (find.py:503-555, after BeadFinder)."""
+        m = len(beads)
+        xy = np.asarray(beads, dtype=np.float64).reshape(m, 3)  # [row, col, r]
+        coords = {"x": (("mark", "time"), xy[:, 1:2].copy()), "y": (("mark", "time"), xy[:, 0:1].copy()),
+                  "valid": (("mark", "time"), np.ones((m, 1), dtype=bool))}
+        for k in ("fg", "bg"):
+            if k in arrays:
+                coords[k] = (("mark", "time", "roi_y", "roi_x"), arrays[k].astype(bool)[:, None])
+        ds = Dataset()
+        if "roi" in arrays:
+            from .utils import roi_mark_chunk
+
+            n_c, length = arrays["roi"].shape[1], arrays["roi"].shape[-1]
+            per = {"mark": roi_mark_chunk(m, n_c, 1, length)}  # the reference's chunk policy (find.py:506-531)
+            ds["roi"] = DataArray(arrays["roi"], ("mark", "channel", "time", "roi_y", "roi_x")).chunk(per)
+        # the fused reductions (not part of the reference's schema; what its users compute from roi / fg / bg)
+        ds["fg_sum"] = DataArray(arrays["sums"][..., 0], ("mark", "channel", "time"))
+        ds["bg_sum"] = DataArray(arrays["sums"][..., 1], ("mark", "channel", "time"))
+        ds["fg_count"] = DataArray(arrays["counts"][:, 0].astype(np.int32), ("mark",))
+        ds["bg_count"] = DataArray(arrays["counts"][:, 1].astype(np.int32), ("mark",))
+        ds["radius"] = DataArray(xy[:, 2].astype(np.int32), ("mark",))
+        ds = ds.assign_coords(coords)
+        if time_label is not None:
+            ds = ds.assign_coords(time=(("time",), np.asarray([time_label])))
+        if channels is not None and "roi" in arrays and len(channels) == arrays["roi"].shape[1]:
+            ds = ds.assign_coords(channel=(("channel",), np.asarray(channels)))
+        return ds
+
+    def take(self, index, ds):
+        raise NotImplementedError
+
+
+class HostSink(_Sink):
+    """Every assay (timepoint) of the stream as a Dataset in host memory: ``sink.assays[index]``."""
+
+    def __init__(self, want_roi=True, want_masks=True):
+        super().__init__(want_roi, want_masks)
+        self.assays = {}
+
+    def take(self, index, ds):
+        self.assays[index] = ds
+
+
+class SaveSink(_Sink):
+    """Every assay written with ``mg.save`` to ``pattern.format(index=...)`` as soon as it is on the host."""
+
+    def __init__(self, pattern, want_roi=True, want_masks=True, shard_bytes=None):
+        super().__init__(want_roi, want_masks)
+        if "{index" not in pattern:
+            raise ValueError("SaveSink: the file pattern needs an {index} field")
+        self.pattern, self.shard_bytes, self.files = pattern, shard_bytes, {}
+
+    def take(self, index, ds):
+        path = self.pattern.format(index=index)
+        mgfile.save(path, ds, shard_bytes=self.shard_bytes)
+        self.files[index] = path

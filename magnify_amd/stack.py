@@ -53,6 +53,7 @@ class StackProcessor:
         self.n_streams = n_streams if (self.n_assays >= 2 * n_streams and not plane_batch) else 1
         self.step_stats = []  # per sub-batch (device counters, host counters) of the last call
         self._roi_bound = None  # markers the ROI pass is launched for before the counts are known (None: capacity)
+        self.pool_tag = ""      # which set of pooled output buffers the ROI pass writes (process_stream alternates two)
         self.stage = None  # device staging buffer of the host-ingest path
         if self.n_streams > 1:
             # The stack is cut into contiguous sub-batches of assays; HIP stream / host thread k works
@@ -174,10 +175,10 @@ class StackProcessor:
         # masks straight from the bead tables (mg_roi_segment_reduce): no label map is written or read
         if self.mode == "P":
             return hp.roi_gather_reduce(self.image.view(T, C, 1, h, w), beads, self.L, None, want_roi=want_roi,
-                                        reuse_buffers=True, disks=True)
+                                        reuse_buffers=True, disks=True, pool_tag=self.pool_tag)
         # mode R: one assay whose image block is stored (T, C, h, w); gathered in place (time_major)
         return hp.roi_gather_reduce(self.image.view(1, T, C, h, w), beads, self.L, None, want_roi=want_roi,
-                                    reuse_buffers=True, disks=True, time_major=True)
+                                    reuse_buffers=True, disks=True, time_major=True, pool_tag=self.pool_tag)
 
     def __call__(self, stack, flatfield=1.0, darkfield=0.0, seed=0, want_roi=True):
         if self.n_streams > 1 and self.mode == "P":
@@ -204,14 +205,15 @@ class StackProcessor:
         # the ROI pass is queued behind the suppression before the host has seen the bead counts (find's `follow`)
         roi_pass = lambda d_out, d_num, cap: hp.roi_gather_reduce(  # noqa: E731
             self.image.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi, reuse_buffers=True, disks=True,
-            device_tables=(d_out, None, self.max_r), device_counts=(d_num, cap, self._roi_bound))
+            device_tables=(d_out, None, self.max_r), device_counts=(d_num, cap, self._roi_bound), pool_tag=self.pool_tag)
         counts, (d_beads, d_scores, _) = self.finder.find(self.image[:, ch], self.minmax[:, ch].contiguous(), self.low_q,
                                                            self.high_q, self.min_roundness, self.min_r, seeds,
                                                            host_results=False, follow=roi_pass)
         out = hp.finish_roi(self.finder.follow_result, counts)
         if out is None:  # more markers than the pass was launched for: once more, with the counts
             out = hp.roi_gather_reduce(self.image.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi,
-                                       reuse_buffers=True, disks=True, device_tables=(d_beads, counts, self.max_r))
+                                       reuse_buffers=True, disks=True, device_tables=(d_beads, counts, self.max_r),
+                                       pool_tag=self.pool_tag)
         # the next call's launch bound: 10 % above this call's markers (its workgroups beyond the real count only cost
         # their start; the per-plane capacity x planes would be ~30 % above)
         self._roi_bound = int(1.1 * int(np.sum(counts))) + 16 * self.n_assays
@@ -225,7 +227,8 @@ def stitched_shape(rows, cols, tile_y, tile_x, overlap):
     return rows * (tile_y - 2 * clip - rem), cols * (tile_x - 2 * clip - rem)
 
 
-def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False, prefetch=2, overlap=0, **processor_kwargs):
+def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False, prefetch=2, overlap=0, sink=None,
+                   **processor_kwargs):
     """Mode-P processing of a time series that arrives chunk by chunk (config C5: ``reader.iter_time_chunks``
     or any iterator of (T_chunk, C, H, W) blocks -- or TILED blocks (T_chunk, C, rows, cols, tile_y, tile_x), which the
     flat-field pass crops and joins with ``overlap`` on the device, so the stitched assay never exists on the host --
@@ -235,7 +238,11 @@ def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False,
     timepoint is its own assay, and its RNG stream only depends on its global index: the results equal
     those of the whole stack in one ``StackProcessor`` call, whatever the chunk size.
     Yields one result dict per chunk (as ``StackProcessor.__call__``, plus ``first_timepoint``); ROI pixel
-    stacks / masks (``want_roi``) are views of pooled buffers that the next chunk overwrites."""
+    stacks / masks (``want_roi``) are views of pooled buffers that the chunk after next overwrites (two sets in turn).
+    ``sink`` (``magnify_amd.sink.HostSink`` / ``SaveSink``): called with every chunk's result while its buffers are
+    valid -- it copies what it keeps to the host beside the next chunk's kernels and turns every timepoint into a
+    Dataset with the reference's schema (kept in memory or saved with ``mg.save``): the streamed results persist,
+    as the reference's do through ``Dataset.mg.cache`` (accessor.py:18-35, find.py:604)."""
     import queue
     import threading
 
@@ -251,10 +258,12 @@ def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False,
             q.put(exc)
 
     threading.Thread(target=produce, daemon=True).start()
-    procs, done = {}, 0
+    procs, done, n_chunk, copied = {}, 0, 0, [None, None]
     while True:
         item = q.get()
         if item is stop:
+            if sink is not None:
+                sink.close()
             return
         if isinstance(item, BaseException):
             raise item
@@ -272,6 +281,10 @@ def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False,
                 t, c, h, w = block.shape
                 procs[key] = StackProcessor(t, c, h, w, dtype=block.dtype, mode="P", **processor_kwargs)
         t = block.shape[0]
+        parity = n_chunk & 1
+        if copied[parity] is not None:  # the sink's host copy of the chunk that last wrote this buffer set
+            torch.cuda.current_stream().wait_event(copied[parity])
+        procs[key].pool_tag = f"#{parity}"
         out = procs[key](block, flatfield, darkfield, seed=(seed + 1000003 * done) & 0xFFFFFFFFFFFFFFFF, want_roi=want_roi)
         out["first_timepoint"] = done
         for k in ("sums", "counts"):  # small; the pooled buffers behind them are reused by the next chunk
@@ -279,7 +292,10 @@ def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False,
                 out[k] = out[k].clone()
         if isinstance(item, tuple) and len(item) == 3:
             out["time"], out["channel"] = item[0], item[1]
+        if sink is not None:
+            copied[parity] = sink(out)
         done += t
+        n_chunk += 1
         yield out
 
 

@@ -48,6 +48,17 @@ def bounding_box(x: int, y: int, box_length: int, image_width: int, image_height
     return top, bottom, left, right
 
 
+def roi_mark_chunk(bound: int, n_channels: int, n_times: int, roi_length: int, chunk_bytes: float = 1e6) -> int:
+    """Markers per chunk of ``roi / fg / bg`` as the reference chunks them (find.py:185-188, 506-531): every channel
+    and timepoint of a marker in one chunk, as many markers as make at least ``chunk_bytes`` -- counted in pixels, "since
+    fg/bg bool arrays should also be 1MB" --, at most ``bound`` (the bead count; for chips the reference bounds by the
+    number of marker ROWS, find.py:187)."""
+    import math
+
+    per_marker = roi_length ** 2 * n_channels * n_times
+    return int(max(0, min(math.ceil(chunk_bytes / max(per_marker, 1)), bound)))
+
+
 def circle_points(r, four_connected=False):
     return _native.circle_points(int(r), four_connected)
 

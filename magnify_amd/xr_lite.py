@@ -136,6 +136,34 @@ class DataArray:
         out.attrs.update(kw)
         return out
 
+    # -- chunk policy (the reference's dask chunking of roi / fg / bg, find.py:63-88, 185-201, 506-531) ----------------
+    def chunk(self, sizes=None, **kw):
+        """Record a chunk size per dimension (``xarray.DataArray.chunk``).  Nothing is cut here -- the data stays one
+        resident array -- but the policy travels with the variable: ``to_xarray()`` hands it to dask when that is
+        installed, and ``mg.save`` cuts its parts at chunk boundaries."""
+        out = self.copy()
+        have = dict(out.attrs.get("__mg_chunks__", {}))
+        have.update({d: int(n) for d, n in dict(sizes or {}, **kw).items() if d in out.dims})
+        out.attrs["__mg_chunks__"] = have
+        return out
+
+    @property
+    def chunksizes(self):
+        """{dim: chunk lengths} as xarray reports them, or {} when no policy is attached."""
+        pol = self.attrs.get("__mg_chunks__")
+        if not pol:
+            return {}
+        out = {}
+        for d, n in self.sizes.items():
+            c = max(1, min(int(pol.get(d, n)), n)) if n else 1
+            out[d] = tuple([c] * (n // c) + ([n % c] if n % c else [])) if n else (0,)
+        return out
+
+    @property
+    def chunks(self):
+        cs = self.chunksizes
+        return tuple(cs[d] for d in self.dims) if cs else None
+
     def rename(self, mapping=None, **kw):
         mapping = dict(mapping or {}, **kw)
         dims = tuple(mapping.get(d, d) for d in self.dims)
@@ -305,7 +333,9 @@ class DataArray:
         import xarray as xr
 
         coords = {k: (v.dims, v.values) for k, v in self.coords.items()}
-        return xr.DataArray(self.values, dims=self.dims, coords=coords, name=self.name, attrs=self.attrs)
+        attrs = {k: v for k, v in self.attrs.items() if not k.startswith("__mg")}
+        out = xr.DataArray(self.values, dims=self.dims, coords=coords, name=self.name, attrs=attrs)
+        return _xr_chunk(out, self.attrs.get("__mg_chunks__"))
 
 
 def _align(arr: DataArray, dims):
@@ -422,6 +452,34 @@ class Dataset:
         out.attrs.update(kw)
         return out
 
+    # -- chunk policy (the reference's dask chunking of roi / fg / bg, find.py:63-88, 185-201, 506-531) ----------------
+    def chunk(self, sizes=None, **kw):
+        """Record a chunk size per dimension (``xarray.DataArray.chunk``).  Nothing is cut here -- the data stays one
+        resident array -- but the policy travels with the variable: ``to_xarray()`` hands it to dask when that is
+        installed, and ``mg.save`` cuts its parts at chunk boundaries."""
+        out = self.copy()
+        have = dict(out.attrs.get("__mg_chunks__", {}))
+        have.update({d: int(n) for d, n in dict(sizes or {}, **kw).items() if d in out.dims})
+        out.attrs["__mg_chunks__"] = have
+        return out
+
+    @property
+    def chunksizes(self):
+        """{dim: chunk lengths} as xarray reports them, or {} when no policy is attached."""
+        pol = self.attrs.get("__mg_chunks__")
+        if not pol:
+            return {}
+        out = {}
+        for d, n in self.sizes.items():
+            c = max(1, min(int(pol.get(d, n)), n)) if n else 1
+            out[d] = tuple([c] * (n // c) + ([n % c] if n % c else [])) if n else (0,)
+        return out
+
+    @property
+    def chunks(self):
+        cs = self.chunksizes
+        return tuple(cs[d] for d in self.dims) if cs else None
+
     def assign_coords(self, coords=None, **kw):
         out = self.copy()
         for k, v in dict(coords or {}, **kw).items():
@@ -530,23 +588,77 @@ class Dataset:
         """A real xarray.Dataset with the reference's schema (needs xarray)."""
         import xarray as xr
 
-        coords = {k: (v.dims, v.values) for k, v in self.coords.items()}
-        data_vars = {k: (v.dims, v.values) for k, v in self.data_vars.items()}
+        def var(v):
+            return xr.Variable(v.dims, v.values, {k: a for k, a in v.attrs.items() if not k.startswith("__mg")})
+
+        coords = {k: var(v) for k, v in self.coords.items()}
+        data_vars = {k: var(v) for k, v in self.data_vars.items()}
         attrs = {k: v for k, v in self.attrs.items() if not k.startswith("__mg")}
         ds = xr.Dataset(data_vars, coords=coords, attrs=attrs)
+        for k, v in list(self.data_vars.items()) + list(self.coords.items()):  # the reference's dask chunks, if dask is here
+            if v.attrs.get("__mg_chunks__"):
+                ds[k] = _xr_chunk(ds[k], v.attrs["__mg_chunks__"])
         if "mark_shape" in self._cache and "mark" in self.sizes:
             ds = ds.set_index(mark=("mark_row", "mark_col"))
         return ds
 
 
+def _xr_chunk(obj, policy):
+    if not policy:
+        return obj
+    try:
+        import dask  # noqa: F401
+    except Exception:  # no dask: a NumPy-backed xarray object (chunking is a property of the lazy backend)
+        return obj
+    return obj.chunk({d: n for d, n in policy.items() if d in obj.dims})
+
+
+_SPILL_DIRS = []  # TemporaryDirectory objects of disk spills, alive as long as the process (accessor.py:8, 13-16)
+
+
 class _Accessor:
+    """``Dataset.mg`` (reference: src/magnify/accessor.py:11-35).  The reference's ``cache`` writes lazy dask arrays to
+    a zarr store in a temporary directory and swaps the stored array in -- how it holds "terabytes on a laptop".  Here
+    the arrays are device-resident tensors: ``cache()`` forces pending operands and keeps them in HBM (288 GB);
+    ``cache(spill="host")`` moves the named variables to page-locked host memory, ``cache(spill="disk")`` (or a
+    directory path) to memory-mapped ``.npy`` files in a temporary directory that lives as long as the process -- the
+    swap-in-place the reference does, with the same call."""
+
     def __init__(self, ds):
         self._ds = ds
 
-    def cache(self, variables=None):
+    def cache(self, variables=None, spill=None):
         names = [variables] if isinstance(variables, str) else list(variables or self._ds.variables)
+        if spill is None:
+            import os
+
+            spill = os.environ.get("MG_CACHE_SPILL") or None
         for n in names:
-            self._ds.variables[n].data  # forces a pending operand
+            arr = self._ds.variables[n]
+            data = arr.data  # forces a pending operand
+            if spill is None or not _is_tensor(data) or not data.is_cuda:
+                continue
+            if spill == "host":
+                host = torch.empty(data.shape, dtype=data.dtype).pin_memory() if data.numel() else torch.empty(data.shape, dtype=data.dtype)
+                host.copy_(data)  # (also materialises expanded views: one copy per variable)
+                arr.data = host.numpy()
+            else:
+                import os
+                import tempfile
+
+                if spill == "disk":
+                    if not _SPILL_DIRS:
+                        _SPILL_DIRS.append(tempfile.TemporaryDirectory(prefix="magnify_amd_cache_"))
+                    root = _SPILL_DIRS[0].name
+                else:
+                    root = str(spill)
+                    os.makedirs(root, exist_ok=True)
+                path = os.path.join(root, f"{id(self._ds):x}_{n}.npy")
+                host = _to_numpy(data)
+                mm = np.lib.format.open_memmap(path, mode="w+", dtype=host.dtype, shape=host.shape)
+                mm[...] = host
+                mm.flush()
+                arr.data = np.load(path, mmap_mode="r+")
         return self._ds
 
 

@@ -761,3 +761,87 @@ def scipy_components(mask):
     import scipy.ndimage
 
     return scipy.ndimage.label(mask, structure=np.ones((3, 3), bool))[1]
+
+
+def test_roi_chunk_policy():
+    """The reference's dask chunking of roi / fg / bg (find.py:63-88, 185-201, 506-531) as numbers: markers per chunk so
+    that a chunk holds >= 1e6 pixels with every channel and timepoint of a marker together, bounded by the marker
+    count (chips: by the ROW count, as the reference does); carried by the variables and honoured by mg.save's parts."""
+    import math
+
+    import magnify_amd as mg
+    from magnify_amd.utils import roi_mark_chunk
+
+    assert roi_mark_chunk(2000, 4, 1, 100) == math.ceil(1e6 / (100 * 100 * 4)) == 25   # C2 / C4
+    assert roi_mark_chunk(2000, 4, 64, 100) == 1                                       # mode R: a marker is 2.56 Mpx
+    assert roi_mark_chunk(5, 1, 1, 20) == 5 and roi_mark_chunk(0, 1, 1, 20) == 0       # never more than there are
+    assert roi_mark_chunk(28, 2, 3, 72) == min(math.ceil(1e6 / (72 * 72 * 6)), 28) == 28  # chip: bounded by 28 rows
+    a = mg.DataArray(np.zeros((7, 2, 1, 4, 4), np.uint16), ("mark", "channel", "time", "roi_y", "roi_x"))
+    assert a.chunks is None and a.chunksizes == {}
+    b = a.chunk({"mark": 3})
+    assert b.chunks == ((3, 3, 1), (2,), (1,), (4,), (4,)) and b.chunksizes["mark"] == (3, 3, 1)
+    assert a.chunks is None                                             # chunk() returns a new object
+    assert b.transpose("channel", "mark", ...).chunksizes["mark"] == (3, 3, 1)  # the policy follows the variable
+    assert b.isel(mark=[0, 1]).chunksizes["mark"] == (2,)
+
+
+def test_save_replaces_what_an_earlier_save_left(tmp_path):
+    """Parts of an earlier, larger save (or the unsharded file) do not survive a new save under the same name; a file
+    AND parts of it are refused by load; parts end on chunk boundaries of the variables' chunk policy."""
+    import glob
+
+    import magnify_amd as mg
+
+    ds = _bead_result_dataset()
+    mg.save(tmp_path / "b.nc", ds, shard_bytes=300)           # three parts
+    assert len(glob.glob(str(tmp_path / "b.nc.part*"))) == 3
+    mg.save(tmp_path / "b.nc", ds, shard_bytes=600)           # two parts now: the third must be gone
+    assert len(glob.glob(str(tmp_path / "b.nc.part*"))) == 2
+    np.testing.assert_array_equal(mg.load(tmp_path / "b.nc")["roi"].values, ds["roi"].values)
+    mg.save(tmp_path / "b.nc", ds)                            # unsharded: no parts left
+    assert glob.glob(str(tmp_path / "b.nc.part*")) == [] and (tmp_path / "b.nc").exists()
+    mg.save(tmp_path / "b.nc", ds, shard_bytes=300)           # and back: the single file is gone
+    assert not (tmp_path / "b.nc").exists()
+    assert glob.glob(str(tmp_path / "*.tmp*")) == []          # written under temporary names, renamed
+    mg.save(tmp_path / "c.nc", ds)
+    import shutil
+
+    shutil.copy(glob.glob(str(tmp_path / "b.nc.part000"))[0], tmp_path / "c.nc.part000")
+    with pytest.raises(ValueError, match="both"):
+        mg.load(tmp_path / "c.nc")
+    # chunk-aligned parts: 7 marks, policy 2 per chunk, room for 3 marks per part -> parts of 2, 2, 2, 1
+    rng = np.random.default_rng(4)
+    big = mg.Dataset()
+    big["roi"] = mg.DataArray(rng.integers(0, 9, (7, 1, 1, 8, 8)).astype(np.uint16), ("mark", "channel", "time", "roi_y", "roi_x")).chunk(mark=2)
+    mg.save(tmp_path / "d.nc", big, shard_bytes=3 * 128)
+    sizes = [mg.load(p)["roi"].shape[0] for p in sorted(glob.glob(str(tmp_path / "d.nc.part*")))]
+    assert sizes == [2, 2, 2, 1]
+    np.testing.assert_array_equal(mg.load(tmp_path / "d.nc")["roi"].values, big["roi"].values)
+
+
+def test_sink_assay_dataset_roundtrip(tmp_path):
+    """What a stream sink makes of one timepoint (magnify_amd/sink.py): the reference's bead schema (find.py:503-555)
+    plus the fused reductions, saved and loaded back equal."""
+    import magnify_amd as mg
+    from magnify_amd.sink import _Sink
+
+    rng = np.random.default_rng(2)
+    m, c, L = 5, 3, 10
+    beads = np.column_stack([rng.integers(0, 500, m), rng.integers(0, 500, m), rng.integers(5, 12, m)]).astype(np.int32)
+    arrays = {"roi": rng.integers(0, 60000, (m, c, 1, L, L)).astype(np.uint16), "fg": (rng.random((m, L, L)) > 0.6).astype(np.uint8),
+              "bg": (rng.random((m, L, L)) > 0.5).astype(np.uint8), "sums": rng.integers(0, 10**6, (m, c, 1, 2)).astype(np.float64),
+              "counts": rng.integers(0, 99, (m, 2)).astype(np.int32)}
+    ds = _Sink.assay_dataset(beads, arrays, time_label=1700000000, channels=["a", "b", "c"])
+    assert ds.roi.dims == ("mark", "channel", "time", "roi_y", "roi_x") and ds.fg.dims == ("mark", "time", "roi_y", "roi_x")
+    assert ds.fg.dtype == np.bool_ and ds.x.dims == ("mark", "time") and ds.valid.values.all()
+    np.testing.assert_array_equal(ds.x.values[:, 0], beads[:, 1])  # x = column, y = row (find.py:543-550)
+    np.testing.assert_array_equal(ds.y.values[:, 0], beads[:, 0])
+    mg.save(tmp_path / "t.nc", ds)
+    back = mg.load(tmp_path / "t.nc")
+    for k in ("roi", "fg_sum", "bg_sum", "fg_count", "radius"):
+        np.testing.assert_array_equal(back[k].values, ds[k].values)
+    for k in ("fg", "bg", "x", "y", "valid"):
+        np.testing.assert_array_equal(back.coords[k].values, ds.coords[k].values)
+    assert list(back.channel.values) == ["a", "b", "c"] and int(back.time.values[0]) == 1700000000
+    empty = _Sink.assay_dataset(np.empty((0, 3), np.int32), {k: v[:0] for k, v in arrays.items()})
+    assert empty.roi.shape == (0, c, 1, L, L) and empty.x.shape == (0, 1)

@@ -27,7 +27,7 @@ def _stack():
     return synthetic_stack(T, C, H, W, seed=321, beads_per_mpx=300.0)[0]
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, save_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), MG_SHARE_GPU="1", MG_DIST_BACKEND="gloo")
@@ -43,11 +43,18 @@ def _worker(rank, world, port, ret):
     out = mgd.run_mode_r(proc, stack[lo:hi].contiguous(), 0.9, 100.0, seed=4)
     ret[rank] = (out["beads"][0].copy(), out["roi"].cpu().numpy().copy(), out["sums"].cpu().numpy().copy(),
                  proc.image.cpu().numpy().copy(), (lo, hi))
+    # every rank saves ITS shard of the result from device memory (ROI pixels stay sharded by GPU)
+    import magnify_amd as mg
+
+    ds = mg.Dataset(attrs={"name": "mode R", "first_timepoint": lo})
+    ds["roi"] = mg.DataArray(out["roi"], ("mark", "channel", "time", "roi_y", "roi_x"))
+    ds = ds.assign_coords(fg=(("mark", "roi_y", "roi_x"), out["fg"].bool()), time=(("time",), np.arange(lo, hi)))
+    mg.save(os.path.join(save_dir, f"shard_rank{rank}.nc"), ds)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_mode_r_time_sharded_matches_single_process():
+def test_mode_r_time_sharded_matches_single_process(tmp_path):
     import torch.multiprocessing as mp
 
     from magnify_amd import hotpath
@@ -61,7 +68,13 @@ def test_mode_r_time_sharded_matches_single_process():
     world, port = 2, _free_port()
     manager = mp.get_context("spawn").Manager()
     ret = manager.dict()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, str(tmp_path)), nprocs=world, join=True)
+    import magnify_amd as mg
+
+    shards = [mg.load(tmp_path / f"shard_rank{r}.nc") for r in range(world)]
+    np.testing.assert_array_equal(np.concatenate([s["roi"].values for s in shards], axis=2), want["roi"].cpu().numpy())
+    np.testing.assert_array_equal(shards[1].coords["fg"].values, want["fg"].cpu().numpy().astype(bool))
+    assert [int(s.attrs["first_timepoint"]) for s in shards] == [0, 2] and list(shards[1].coords["time"].values) == [2, 3]
     for rank in range(world):
         beads, roi, sums, image, (lo, hi) = ret[rank]
         np.testing.assert_array_equal(beads, want["beads"][0])  # broadcast from the owner of time 0

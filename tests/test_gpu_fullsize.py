@@ -326,3 +326,81 @@ def test_streamed_tiled_series_equals_eager_pipeline(mg, tmp_path):
         for a, b in zip(beads, want["beads"]):
             np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(np.concatenate(sums), want_sums)
+
+
+def test_stream_sinks_persist_every_assay(mg, tmp_path):
+    """the results of a streamed run persist.  process_stream(sink=...) copies every chunk's ROI
+    pixels, masks and reductions to the host beside the next chunk's kernels (two sets of pooled device buffers in
+    turn) and turns every timepoint into a Dataset with the reference's schema -- kept (HostSink) or written with
+    mg.save and read back with mg.load (SaveSink) -- equal, assay for assay, to one StackProcessor call on the stack."""
+    from magnify_amd.stack import StackProcessor, process_stream, synthetic_stack
+
+    T, C, S, L = 7, 2, 320, 40
+    stack, _ = synthetic_stack(T, C, S, S, seed=717, beads_per_mpx=350.0)
+    kw = dict(num_iter=60000, search_channels=(0,), roi_length=L, min_bead_diameter=10, max_bead_diameter=44)
+    whole = StackProcessor(T, C, S, S, mode="P", **kw)(stack, 0.9, 90.0, seed=5)
+    want = {k: whole[k].cpu().numpy().copy() for k in ("roi", "fg", "bg", "sums", "counts")}
+    off, beads = whole["offsets"], whole["beads"]
+    assert off[-1] > 40
+
+    def chunks(n):
+        for lo in range(0, T, n):
+            yield list(range(100 + lo, 100 + min(lo + n, T))), ["dna", "cy5"], stack[lo: lo + n].cpu()
+
+    def check(ds, t):
+        lo, hi = off[t], off[t + 1]
+        np.testing.assert_array_equal(ds["roi"].values, want["roi"][lo:hi])
+        np.testing.assert_array_equal(ds.coords["fg"].values[:, 0], want["fg"][lo:hi].astype(bool))
+        np.testing.assert_array_equal(ds.coords["bg"].values[:, 0], want["bg"][lo:hi].astype(bool))
+        np.testing.assert_array_equal(ds["fg_sum"].values, want["sums"][lo:hi, ..., 0])
+        np.testing.assert_array_equal(ds["bg_count"].values, want["counts"][lo:hi, 1])
+        np.testing.assert_array_equal(ds.coords["x"].values[:, 0], beads[t][:, 1])
+        np.testing.assert_array_equal(ds.coords["y"].values[:, 0], beads[t][:, 0])
+        assert ds["roi"].dims == ("mark", "channel", "time", "roi_y", "roi_x") and list(ds.coords["channel"].values) == ["dna", "cy5"]
+        assert int(ds.coords["time"].values[0]) == 100 + t
+
+    host = mg.HostSink()
+    n_out = sum(1 for _ in process_stream(chunks(2), 0.9, 90.0, seed=5, want_roi=True, sink=host, **kw))  # 4 chunks: 2, 2, 2, 1
+    assert n_out == 4 and sorted(host.assays) == list(range(T))
+    for t in range(T):
+        check(host.assays[t], t)
+    assert host.assays[0]["roi"].chunksizes["mark"][0] == min(len(beads[0]), -(-10**6 // (L * L * C)))
+    saver = mg.SaveSink(str(tmp_path / "series_t{index:04d}.nc"))
+    for _ in process_stream(chunks(3), 0.9, 90.0, seed=5, want_roi=True, sink=saver, **kw):
+        pass
+    assert sorted(saver.files) == list(range(T))
+    for t in range(T):
+        check(mg.load(saver.files[t]), t)
+    light = mg.HostSink(want_roi=False, want_masks=False)  # reductions only: nothing but tables crosses the bus
+    for _ in process_stream(chunks(7), 0.9, 90.0, seed=5, sink=light, **kw):
+        pass
+    assert "roi" not in light.assays[3].data_vars
+    np.testing.assert_array_equal(light.assays[3]["fg_sum"].values, want["sums"][off[3]:off[4], ..., 0])
+
+
+def test_save_and_spill_a_gpu_resident_result(mg, tmp_path):
+    """mg.save of a result whose roi / fg / bg still live in HBM (file.py:6-17 on the output of mg.beads), and
+    Dataset.mg.cache(spill=...) -- the reference's zarr spill (accessor.py:18-35) as a move to page-locked host memory
+    or to memory-mapped files: same values, other backing."""
+    from synth import noisy_bead_image
+
+    img = np.stack([noisy_bead_image(900 + c, (512, 640), 25, r_lo=6, r_hi=12)[0] for c in range(2)])
+    xp = mg.beads(data=mg.DataArray(data=img, dims=("channel", "y", "x")), min_bead_diameter=10, max_bead_diameter=30,
+                  overlap=0, num_iter=100000, search_channel=0)
+    m = xp.roi.sizes["mark"]
+    assert m >= 15 and torch.is_tensor(xp.roi.raw) and xp.roi.raw.is_cuda  # device-resident
+    assert xp.roi.chunksizes["mark"][0] == min(m, -(-10**6 // (60 * 60 * 2)))
+    ref = {k: np.asarray(xp[k].values).copy() for k in ("roi", "fg", "bg", "x", "y", "valid")}
+    mg.save(tmp_path / "beads.nc", xp)
+    back = mg.load(tmp_path / "beads.nc")
+    for k, v in ref.items():
+        np.testing.assert_array_equal(np.asarray(back[k].values), v, err_msg=k)
+        assert back[k].dims == xp[k].dims
+    mg.save(tmp_path / "parts.nc", xp, shard_bytes=200000)  # parts cut from the device-resident arrays
+    np.testing.assert_array_equal(mg.load(tmp_path / "parts.nc")["roi"].values, ref["roi"])
+    xp.mg.cache(["roi", "fg"], spill="host")
+    assert isinstance(xp.roi.raw, np.ndarray) and isinstance(xp.fg.raw, np.ndarray) and torch.is_tensor(xp.bg.raw)
+    xp.mg.cache("bg", spill="disk")
+    assert isinstance(xp.variables["bg"].raw, np.memmap)  # backed by a file in the process's spill directory
+    for k, v in ref.items():
+        np.testing.assert_array_equal(np.asarray(xp[k].values), v, err_msg=k)
