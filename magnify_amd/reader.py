@@ -199,7 +199,15 @@ class Reader:
         return Reader()
 
 
-def iter_time_chunks(pattern, chunk: int, pinned: bool = False):
+_PINNED_RING = {}
+
+
+def release_pinned():
+    """Give the page-locked blocks of ``iter_time_chunks(pinned=True)`` back (they are kept for the next series)."""
+    _PINNED_RING.clear()
+
+
+def iter_time_chunks(pattern, chunk: int, pinned: bool = False, workers: int = 8, ring: int = 4):
     """Streamed ingest of a time series too large to hold: the files behind
     ``pattern`` are read ``chunk`` timepoints at a time, in time order, page by page, never all at once.
     Groups as in ``extract_paths``: ``(channel)``, ``(time|format)``, and for tiled acquisitions ``(row)`` /
@@ -209,7 +217,11 @@ def iter_time_chunks(pattern, chunk: int, pinned: bool = False):
     Yields ``(time_values, channels, block)`` with ``block`` (T_chunk, C, H, W) -- tiled series:
     (T_chunk, C, rows, cols, tile_y, tile_x), stitched later on the device (``stack.process_stream(overlap=...)``)
     -- of the files' dtype: a NumPy array, or with ``pinned`` a page-locked torch tensor ready for an
-    asynchronous upload.  One assay per pattern."""
+    asynchronous upload.  ``workers`` threads read a chunk's pages side by side (positional reads straight into the
+    block: one thread copies ~6 GB/s out of the page cache, a tile series is 16+ files).  Page-locked blocks come from
+    a ring of ``ring`` buffers (pinning a fresh 1.3 GB block per chunk cost 0.2 s, six times the reading): a yielded
+    block is overwritten once ``ring - 1`` further chunks have been yielded -- ``stack.process_stream`` with its default
+    ``prefetch=2`` holds at most three.  One assay per pattern."""
     path_dict, _ = extract_paths(os.fspath(pattern), assay="str", channel="str", time="time", row="int", col="int")
     if len(path_dict) == 0:
         raise FileNotFoundError(f"The pattern {pattern} did not lead to any files.")
@@ -236,15 +248,21 @@ def iter_time_chunks(pattern, chunk: int, pinned: bool = False):
     channel_names = channels if path_dims["channel"] or lay["channels"] is None or len(lay["channels"]) != n_c_file else lay["channels"]
     assay = next(iter(path_dict))[0]
     open_files = {}  # path -> TiffFile, kept open across pages (a chunk touches each of its files many times)
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+
+    files_lock = threading.Lock()
+    pool = ThreadPoolExecutor(max_workers=max(1, int(workers))) if workers and workers > 1 else None
 
     def read_page(path, index, out):
         from . import tiff
 
-        tif = open_files.get(path)
-        if tif is None:
-            if len(open_files) >= 64:
-                open_files.pop(next(iter(open_files))).close()
-            tif = open_files[path] = tiff.TiffFile(path)
+        with files_lock:
+            tif = open_files.get(path)
+            if tif is None:
+                if len(open_files) >= 256:  # (files dropped here are closed by the garbage collector, not under a reader)
+                    open_files.pop(next(iter(open_files)))
+                tif = open_files[path] = tiff.TiffFile(path)
         tif.read_page_into(index, out)
 
     def page_of(t, c, r, cc):  # -> (path, page index inside the file)
@@ -254,24 +272,37 @@ def iter_time_chunks(pattern, chunk: int, pinned: bool = False):
         index = (0 if path_dims["time"] else t * stride.get("time", 0)) + (0 if path_dims["channel"] else c * stride.get("channel", 0))
         return path_dict[key], index
 
+    pinned_ring, n_yielded = _PINNED_RING, 0  # (kept by the module: a second pass over a series pins nothing new)
     for lo in range(0, len(times), int(chunk)):
         part = times[lo: lo + int(chunk)]
         shape = (len(part), len(channels)) + ((len(rows), len(cols)) if tiled else ()) + (h, w)
         if pinned:
             import torch
 
-            block_t = torch.empty(shape, dtype=torch.from_numpy(np.empty(0, dtype)).dtype).pin_memory()
+            slot = (n_yielded % max(int(ring), 1), shape, str(dtype))
+            block_t = pinned_ring.get(slot)
+            if block_t is None:
+                block_t = pinned_ring[slot] = torch.empty(shape, dtype=torch.from_numpy(np.empty(0, dtype)).dtype).pin_memory()
             block = block_t.numpy()
+            n_yielded += 1
         else:
             block = np.empty(shape, dtype=dtype)
+        jobs = []
         for i, t in enumerate(part):
             for j, c in enumerate(channels):
                 for a, r in enumerate(rows):
                     for b, cc in enumerate(cols):
                         path, index = page_of(t, c, r, cc)
                         dst = block[i, j, a, b] if tiled else block[i, j]
-                        read_page(path, index, dst)
+                        if pool is None:
+                            read_page(path, index, dst)
+                        else:
+                            jobs.append(pool.submit(read_page, path, index, dst))
+        for job in jobs:
+            job.result()  # (re-raises what a reader thread met)
         stamps = [int(t.timestamp()) if isinstance(t, datetime.datetime) else t for t in time_values[lo: lo + int(chunk)]]
         yield stamps, list(channel_names), (block_t if pinned else block)
+    if pool is not None:
+        pool.shutdown()
     for tif in open_files.values():
         tif.close()

@@ -19,8 +19,8 @@ Singleton axes are dropped, as tifffile's squeezed ``series[0].axes`` does.  Mic
 from __future__ import annotations
 
 import json
-import mmap
 import os
+import threading
 import re
 import struct
 import zlib
@@ -93,6 +93,7 @@ class TiffFile:
         self._pages = []
         self._series = None
         self._mm = None
+        self._lock = threading.Lock()  # the IFD walk; pixel reads are positional (pread) and need none
 
     # -- context management ---------------------------------------------------------------------------------
     def close(self):
@@ -110,10 +111,12 @@ class TiffFile:
     def _read_at(self, offset, n):
         if offset < 0 or offset + n > self._size:
             raise TiffError(f"{self.path}: read of {n} bytes at {offset} beyond the end of the file ({self._size})")
-        self._fh.seek(offset)
-        data = self._fh.read(n)
-        if len(data) != n:
-            raise TiffError(f"{self.path}: short read at {offset}")
+        data = os.pread(self._fh.fileno(), n, offset)  # positional: several threads may read pages of one file
+        while len(data) < n:
+            more = os.pread(self._fh.fileno(), n - len(data), offset + len(data))
+            if not more:
+                raise TiffError(f"{self.path}: short read at {offset}")
+            data += more
         return data
 
     def _values(self, typ, count, raw_value):
@@ -205,15 +208,18 @@ class TiffFile:
         return True
 
     def page(self, index):
-        while len(self._pages) <= index:
-            if not self._parse_next():
-                raise IndexError(f"{self.path}: page {index} of {len(self._pages)}")
+        if len(self._pages) <= index:
+            with self._lock:
+                while len(self._pages) <= index:
+                    if not self._parse_next():
+                        raise IndexError(f"{self.path}: page {index} of {len(self._pages)}")
         return self._pages[index]
 
     @property
     def pages(self):
-        while self._parse_next():
-            pass
+        with self._lock:
+            while self._parse_next():
+                pass
         return self._pages
 
     def __len__(self):
@@ -335,10 +341,12 @@ class TiffFile:
             off, nbytes = run
             if off + nbytes > self._size:
                 raise TiffError(f"{self.path}: page {index} reaches beyond the end of the file")
-            self._fh.seek(off)
-            got = self._fh.readinto(memoryview(out).cast("B"))
-            if got != nbytes:
-                raise TiffError(f"{self.path}: short read in page {index}")
+            view, got = memoryview(out).cast("B"), 0
+            while got < nbytes:  # straight into the caller's (page-locked) buffer, no seek: thread-safe
+                n = os.preadv(self._fh.fileno(), [view[got:]], off + got)
+                if n <= 0:
+                    raise TiffError(f"{self.path}: short read in page {index}")
+                got += n
             if swap:
                 out.byteswap(inplace=True)
             return out
