@@ -36,7 +36,7 @@ def algorithmic_bytes(stage, p):
         "mg_flatfield_apply_stitch": 4 * c * n * p["n_t"],   # read u16 + write u16
         "mg_to_uint8_blur": 3 * planes * n,                 # read u16, write blurred u8
         "mg_scharr_hist": 1 * planes * n * p["hist_passes"],  # read u8
-        "mg_canny_nms": (1 + 2 / 8) * planes * n,           # read u8, write weak + strong bitmaps
+        "mg_canny_nms": (1 + 5 / 8) * planes * n,           # read u8, write weak + strong bitmaps + 3 orientation bit planes
         "mg_canny_hysteresis": (3 / 8) * planes * n * p["sweeps"],  # weak + strong bits in, strong out, per sweep
         "mg_edge_angles": p["edges"] * (8 + 9 + 4),          # coordinate, 3x3 blurred neighbourhood, angle
         "mg_edge_grid": 2 * planes * n / 8 + 8 * p["edges"],  # bitmap twice (count, fill), write coords

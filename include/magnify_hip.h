@@ -306,8 +306,8 @@ int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, const ui
  * terms 4 |d - pi/2| / pi - 1 (utils.py:244-249) from the pair's table (mg_score_pair_table: the distance
  * between the points' radial direction and the pixel's orientation bin bounds the term); the bounds are summed
  * in 1/64 (rounded up) and a circle whose bound is below min_roundness * P - 1e-3 is dropped -- exact: every
- * term <= its bound.  Survivors are appended to d_surv_list[n_planes][surv_cap][2] (scratch: list index and key; surv_cap >=
- * circle_cap can never overflow), d_num_surv[n_planes] (scratch, zeroed here).
+ * term <= its bound.  Survivors are appended to d_surv_list[n_planes][surv_cap][2] (scratch: list index and key;
+ * surv_cap >= circle_cap is required: it can then never overflow), d_num_surv[n_planes] (scratch, zeroed here).
  * Exact pass: the reference's float64 sum in perimeter order, 16 lanes per survivor (the edge pixels on the
  * perimeter and their angles are found in parallel, the terms added in order); the gradient angle of a
  * hit is d_angle's entry or, with d_angle == NULL, computed on demand from d_blur exactly as mg_edge_angles

@@ -501,7 +501,7 @@ extern "C" int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angl
       !d_per_rc || !d_per_expected || !d_per_starts || !d_pair_table || !d_scores || !d_alive || !d_num_alive ||
       !d_max_rc || !d_surv_list || !d_num_surv)
     return MG_EINVAL;
-  if (n_planes < 0 || n_planes > 65535 || per_total <= 0 || surv_cap < 0) return MG_EINVAL;
+  if (n_planes < 0 || n_planes > 65535 || per_total <= 0 || surv_cap < circle_cap) return MG_EINVAL;  // (a survivor per circle)
   if (mg_score_keyed_supported(min_r, max_r) != 1) return MG_EINVAL;
   if (h <= 0 || w <= 0 || h >= (1 << 24) || w >= (1 << 24) || (int64_t)h * w >= (1LL << 31)) return MG_EINVAL;
   const int nr = max_r - min_r + 1;

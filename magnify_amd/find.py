@@ -149,12 +149,18 @@ def _group_stats(labels, num_clusters, *columns):
 
 
 def _line_fit(x, y):
-    """Least-squares line through (x, y): slope = cov(x, y) / var(x), intercept = mean(y) - slope * mean(x)
-    -- what scipy.stats.linregress returns (find.py:710,719,735)."""
+    """Slope and intercept as scipy.stats.linregress computes them (find.py:710, 719, 735), operation for operation:
+    the means by np.mean, the mean squares by np.cov(x, y, bias=1) -- centred rows, one matrix product, times 1 / n --,
+    slope = ssxym / ssxm, intercept = ymean - slope * xmean.  (A grouped-sums variant, Sxy / Sxx over bincounts, agreed
+    to an ulp or two; the slopes feed a median and rounded chamber centres, so the product does what the reference's
+    library does.)"""
     x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
-    dx, dy = x - x.mean(), y - y.mean()
-    slope = np.dot(dx, dy) / np.dot(dx, dx)
-    return slope, y.mean() - slope * x.mean()
+    if len(x) > 1 and np.amax(x) == np.amin(x):
+        raise ValueError("Cannot calculate a linear regression if all x values are identical")  # (scipy's own refusal)
+    xmean, ymean = np.mean(x, None), np.mean(y, None)
+    ssxm, ssxym, _, _ = np.cov(x, y, bias=1).flat
+    slope = ssxym / ssxm
+    return slope, ymean - slope * xmean
 
 
 def label_clusters(points, offset, num_clusters, cluster_length, cluster_gap):
@@ -169,18 +175,22 @@ def label_clusters(points, offset, num_clusters, cluster_length, cluster_gap):
 def regress_clusters(x, y, labels, num_clusters, ideal_num_points):
     """find.py:698-748: a line per cluster, the median of their slopes for all, per-cluster median intercepts at
     that slope, blended -- by how complete a cluster is -- with the evenly spaced estimate from a line through
-    (cluster index, intercept).  All clusters at once: grouped sums for the fits, one sort for the medians."""
+    (cluster index, intercept).  The fits are linregress's own operations per cluster (_line_fit); the medians of all
+    clusters come from one sort."""
     x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
     labels = np.asarray(labels)
     if num_clusters == 1:
         return (0, y) if len(x) == 1 else _line_fit(x, y)
     ideal = np.asarray(ideal_num_points, dtype=np.float64)
-    inside, lab, n, (mx, my) = _group_stats(labels, num_clusters, x, y)
+    inside, lab, n, _ = _group_stats(labels, num_clusters)
     gx, gy = x[inside], y[inside]
-    dx, dy = gx - mx[lab], gy - my[lab]
-    with np.errstate(invalid="ignore", divide="ignore"):
-        slopes = np.bincount(lab, weights=dx * dy, minlength=num_clusters) / np.bincount(lab, weights=dx * dx, minlength=num_clusters)
-    slopes[n < 2] = np.nan  # a line needs two points
+    # a line per cluster with two points or more (a few dozen clusters of a few dozen points: the loop is microseconds)
+    slopes = np.full(num_clusters, np.nan)
+    order0 = np.argsort(lab, kind="stable")
+    bounds = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    for i in np.flatnonzero(n >= 2):
+        sel = order0[bounds[i]: bounds[i + 1]]  # the cluster's points in their original order, as x[labels == i]
+        slopes[i] = _line_fit(gx[sel], gy[sel])[0]
     if ((n[[0, -1]] < 2) & (ideal[[0, -1]] >= 2)).any():
         print("Boundary cluster has fewer than 2 points.The chip is unlikely to be segmented correctly.")
     slope = np.nanmedian(slopes)

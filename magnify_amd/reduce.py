@@ -21,10 +21,38 @@ def _masks(xp, name):
     return m.cuda()
 
 
+def _sums_counts(xp, mask):
+    """(sums (M, C, T) float64, counts (M, T) int64) of roi under a mask, by the masked-sum kernel (mg_masked_sums):
+    one call when the mask is the same at every timepoint (beads: geometry replicated over time, find.py:585-586),
+    one per timepoint otherwise (chips searched at several timesteps)."""
+    roi = xp.data_vars["roi"].transpose("mark", "channel", "time", "roi_y", "roi_x").data
+    if not isinstance(roi, torch.Tensor):
+        roi = torch.from_numpy(np.ascontiguousarray(roi))
+    roi = roi.cuda()
+    m = _masks(xp, mask)
+    m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+    n_m, n_c, n_t = roi.shape[:3]
+    if n_t == 1 or m.stride(1) == 0:
+        one = m[:, 0].contiguous()
+        sums, cnt = hotpath.masked_sums(roi.contiguous(), one, one)
+        return sums[..., 0], cnt[:, :1].to(torch.int64).expand(n_m, n_t)
+    sums = torch.empty((n_m, n_c, n_t), dtype=torch.float64, device=roi.device)
+    cnt = torch.empty((n_m, n_t), dtype=torch.int64, device=roi.device)
+    for t in range(n_t):
+        one = m[:, t].contiguous()
+        s_t, c_t = hotpath.masked_sums(roi[:, :, t:t + 1].contiguous(), one, one)
+        sums[:, :, t] = s_t[:, :, 0, 0]
+        cnt[:, t] = c_t[:, 0]
+    return sums, cnt
+
+
 def counts(xp, mask="fg"):
     """xp.fg.sum(dim=["roi_x", "roi_y"])  (README.md:21) -> (mark, time) int64."""
-    m = _masks(xp, mask)
-    return DataArray(m.to(torch.int32).sum(dim=(-1, -2)).to(torch.int64), ("mark", "time"))
+    cached = xp._cache.get("roi_counts")
+    n_t = xp.sizes.get("time", 1)
+    if cached is not None and mask in ("fg", "bg") and "mark" in xp.sizes and cached.shape[0] == xp.sizes["mark"]:
+        return DataArray(cached[:, 0 if mask == "fg" else 1].to(torch.int64)[:, None].expand(-1, n_t), ("mark", "time"))
+    return DataArray(_sums_counts(xp, mask)[1], ("mark", "time"))
 
 
 def masked_sum(xp, mask="fg"):
@@ -32,9 +60,7 @@ def masked_sum(xp, mask="fg"):
     cached = xp._cache.get("roi_sums")
     if cached is not None and mask in ("fg", "bg"):
         return DataArray(cached[..., 0 if mask == "fg" else 1], ("mark", "channel", "time"))
-    roi = xp.data_vars["roi"].transpose("mark", "channel", "time", "roi_y", "roi_x").data.cuda()
-    m = _masks(xp, mask)[:, None].to(torch.float64)
-    return DataArray((roi.to(torch.float64) * m).sum(dim=(-1, -2)), ("mark", "channel", "time"))
+    return DataArray(_sums_counts(xp, mask)[0], ("mark", "channel", "time"))
 
 
 def masked_mean(xp, mask="fg"):

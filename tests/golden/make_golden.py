@@ -188,6 +188,23 @@ def clusters():
     y1 = np.array([100.0, 101.0, 103.5, 104.0])
     s, b = find.regress_clusters(x1, y1, labels=np.zeros(4, int), num_clusters=1, ideal_num_points=np.array([4]))
     out.update(x1=x1, y1=y1, single_slope=np.float64(s), single_intercept=np.float64(b))
+    # Ragged clusters: sizes 2 .. 9, one EMPTY cluster (2), one with a single point (5), unsorted labels, a few points
+    # outside every cluster (-1); lines with a common slope plus noise.
+    sizes = [4, 9, 0, 2, 7, 1, 5]
+    rx, ry, rlab = [], [], []
+    for i, k in enumerate(sizes):
+        px = rng.uniform(50, 950, k)
+        rx.append(px)
+        ry.append(120.0 * i + 0.013 * px + rng.normal(0, 1.5, k))
+        rlab.append(np.full(k, i))
+    rx, ry, rlab = np.concatenate(rx + [rng.uniform(0, 900, 3)]), np.concatenate(ry + [rng.uniform(0, 900, 3)]), \
+        np.concatenate(rlab + [np.full(3, -1)]).astype(int)
+    perm = rng.permutation(len(rx))
+    rx, ry, rlab = rx[perm], ry[perm], rlab[perm]
+    ideal_rag = np.array([5, 9, 4, 0, 7, 3, 5])
+    s, b = find.regress_clusters(rx, ry, labels=rlab, num_clusters=len(sizes), ideal_num_points=ideal_rag)
+    out.update(rag_x=rx, rag_y=ry, rag_labels=rlab, rag_ideal=ideal_rag, rag_slope=np.float64(s),
+               rag_intercepts=np.asarray(b, dtype=np.float64))
     save("clusters", **out)
 
 

@@ -144,6 +144,18 @@ def test_beads_roi_contents_and_reductions(mg):
     med = mg.reduce.masked_median(xp, "bg").values
     assert (med == 0).all()
     np.testing.assert_array_equal(mg.reduce.counts(xp, "fg").values[:, 0], fg[:, 0].sum(axis=(-1, -2)))
+    # without the finder's cached reductions (any Dataset with roi / fg / bg): the masked-sum kernel, also for masks
+    # that differ from timepoint to timepoint
+    xp._cache.pop("roi_sums"), xp._cache.pop("roi_counts")
+    np.testing.assert_array_equal(mg.reduce.masked_sum(xp, "bg").values[:, 0, 0], (roi[:, 0, 0].astype(np.int64) * bg[:, 0]).sum(axis=(-1, -2)))
+    np.testing.assert_array_equal(mg.reduce.counts(xp, "bg").values[:, 0], bg[:, 0].sum(axis=(-1, -2)))
+    rng = np.random.default_rng(0)
+    roi3 = rng.integers(0, 60000, (3, 2, 3, 12, 12)).astype(np.uint16)
+    fg3 = rng.random((3, 3, 12, 12)) > 0.5
+    ds = mg.Dataset({"roi": mg.DataArray(roi3, ("mark", "channel", "time", "roi_y", "roi_x"))},
+                    coords={"fg": (("mark", "time", "roi_y", "roi_x"), fg3)})
+    np.testing.assert_array_equal(mg.reduce.masked_sum(ds, "fg").values, (roi3.astype(np.int64) * fg3[:, None]).sum(axis=(-1, -2)))
+    np.testing.assert_array_equal(mg.reduce.counts(ds, "fg").values, fg3.sum(axis=(-1, -2)))
     # user-side algebra through the container (README.md:21-22)
     np.testing.assert_allclose(xp.roi.where(xp.fg).mean(dim=["roi_x", "roi_y"]).values[:, 0, 0], mean)
 

@@ -108,3 +108,32 @@ def test_clusters(golden):
     np.testing.assert_allclose(b, g["col_intercepts"], rtol=1e-12)
     s, b = rp.regress_clusters(g["x1"], g["y1"], np.zeros(4, int), 1, np.array([4]))
     np.testing.assert_allclose([s, b], [g["single_slope"], g["single_intercept"]], rtol=1e-12)
+    # ragged clusters with an empty one, a single-point one and points outside every cluster
+    s, b = rp.regress_clusters(g["rag_x"], g["rag_y"], g["rag_labels"], 7, g["rag_ideal"])
+    np.testing.assert_allclose(s, g["rag_slope"], rtol=1e-12)
+    np.testing.assert_allclose(b, g["rag_intercepts"], rtol=1e-12)
+
+
+def test_product_cluster_helpers_equal_the_reference_bit_for_bit(golden):
+    """magnify_amd.find.regress_clusters / label_clusters (host-side product code, written independently of the
+    oracle: linregress's own operations per cluster, one sort for the medians) against the values the REFERENCE's
+    functions returned (tests/golden/make_golden.py): exactly equal, ragged / empty / single-point clusters included --
+    the slopes feed a median and rounded chamber centres, an ulp can move a pixel."""
+    from magnify_amd import find as product
+
+    g = golden("clusters")
+    rl, cl = g["row_labels"], g["col_labels"]
+    inside = (rl >= 0) & (cl >= 0)
+    x, y = g["x"][inside], g["y"][inside]
+    s, b = product.regress_clusters(x, y, rl[inside], 6, g["ideal_r"])
+    assert s == g["row_slope"]
+    np.testing.assert_array_equal(b, g["row_intercepts"])
+    s, b = product.regress_clusters(y, x, cl[inside], 5, g["ideal_c"])
+    assert s == g["col_slope"]
+    np.testing.assert_array_equal(b, g["col_intercepts"])
+    s, b = product.regress_clusters(g["x1"], g["y1"], np.zeros(4, int), 1, np.array([4]))
+    assert (s, b) == (g["single_slope"], g["single_intercept"])
+    s, b = product.regress_clusters(g["rag_x"], g["rag_y"], g["rag_labels"], 7, g["rag_ideal"])
+    assert s == g["rag_slope"]
+    np.testing.assert_array_equal(b, g["rag_intercepts"])
+    np.testing.assert_array_equal(product.label_clusters(g["y"], 120, 6, 60, float(g["rd"]) - 60), g["row_labels_fixed"])
