@@ -299,7 +299,7 @@ int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, const ui
 
 /* The keyed path's scoring (same scores and same passing set as mg_score_circles input (a), which remains for
  * radii outside mg_score_keyed_supported): two kernels.
- * Prefilter: a workgroup per super-tile of 2 x 2 centre tiles with the edge window in LDS as one byte per
+ * Prefilter: a workgroup per super-tile of 2 x 4 centre tiles (128 x 256 positions) with the edge window in LDS as one byte per
  * pixel (the gradient-orientation bin of mg_canny_nms' class planes, 0x0C = no edge); a lane per circle, all
  * circles of a wave of one radius, the perimeter walked as straight-line code per radius.  For every pair of
  * opposite perimeter points the two window bytes select, in one byte permute, UPPER BOUNDS of the two pixels'
@@ -308,8 +308,8 @@ int mg_score_circles(const float* d_angle, const uint32_t* d_edge_bits, const ui
  * in 1/64 (rounded up) and a circle whose bound is below min_roundness * P - 1e-3 is dropped -- exact: every
  * term <= its bound.  Survivors are appended to d_surv_list[n_planes][surv_cap][2] (scratch: list index and key;
  * surv_cap >= circle_cap is required: it can then never overflow), d_num_surv[n_planes] (scratch, zeroed here).
- * Exact pass: the reference's float64 sum in perimeter order, 16 lanes per survivor (the edge pixels on the
- * perimeter and their angles are found in parallel, the terms added in order); the gradient angle of a
+ * Exact pass: the reference's float64 sum in perimeter order, 4 (16 at small batches) lanes per survivor (the edge
+ * pixels on the perimeter and their angles are found in parallel, the terms added in order); the gradient angle of a
  * hit is d_angle's entry or, with d_angle == NULL, computed on demand from d_blur exactly as mg_edge_angles
  * does (so neither the angle map nor its pass is needed).  Outputs as mg_score_circles (no same-centre
  * reduction: the suppression treats same-centre circles correctly by itself); d_num_scored = survivors.
@@ -453,6 +453,15 @@ int mg_button_masks(const int32_t* d_centers, const int32_t* d_radii, int m, int
  * d_sums double[m][n_ct][2] = {fg sum, bg sum}, d_counts int32[m][2] (optional). */
 int mg_masked_sums(const void* d_roi, int dtype, const uint8_t* d_fg, const uint8_t* d_bg, int m, int n_ct,
                    int roi_len, double* d_sums, int32_t* d_counts, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Measurement aid ("confirm with a measured streaming-copy ceiling on the box")
+ * ---------------------------------------------------------------------------------- */
+
+/* One streaming pass over n_bytes (a multiple of 16, 16-byte aligned buffers) by this library's own 16-byte-per-lane
+ * grid-stride kernel on `blocks` workgroups of 256: mode 0 copies d_src to d_dst, mode 1 only reads d_src (every
+ * workgroup leaves four words in d_sink[4 * blocks]), mode 2 only writes d_dst.  The caller times it (HIP events). */
+int mg_stream_probe(const void* d_src, void* d_dst, int64_t n_bytes, int mode, uint32_t* d_sink, int blocks, void* stream);
 
 #ifdef __cplusplus
 }

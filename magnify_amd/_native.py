@@ -71,6 +71,7 @@ PROTOTYPES = {
     "mg_roi_masked_median_u16": [_p, _p, _i, _i, _i, _i, _p, _p],
     "mg_cluster1d_costs": [_p, _i, _i, _i, _d, _p, _d, _p, _p],
     "mg_button_masks": [_p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p],
+    "mg_stream_probe": [_p, _p, _l, _i, _p, _i, _p],
     "mg_masked_sums": [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p],
 }
 

@@ -2,10 +2,11 @@
 // mg_keys_to_circles, as two kernels.
 //
 //   k_prefilter  exact rejection of the circles that cannot reach min_roundness -- 99.6 % of them on noisy images.
-//                A workgroup owns a super-tile of 2 x 2 centre tiles; its window of the edge map lives in LDS as
+//                A (persistent, 768-thread) workgroup owns a super-tile of MG_SCORE_SUBY x MG_SCORE_SUBX = 2 x 4 centre
+//                tiles (128 x 256 positions); its window of the edge map lives in LDS as
 //                ONE BYTE per pixel: the pixel's gradient-orientation bin (eighths of pi, decided exactly on the
 //                integer gradient by mg_canny_nms) or 0x0C for "no edge".  A lane owns a circle; all 64 circles of
-//                a wave have the SAME radius (the keys of a tile are sorted by radius: the block cuts the four key
+//                a wave have the SAME radius (the keys of a tile are sorted by radius: the block cuts the eight key
 //                lists at the radius boundaries and deals 64-circle chunks of one radius to its waves), so the
 //                perimeter walk is straight-line code per radius (template <R>, the midpoint circle evaluated at
 //                compile time): the offset of a perimeter point is the immediate of its ds_read_u8 and the bound
@@ -16,9 +17,12 @@
 //                a pixel of that bin can contribute to the reference's sum; a circle whose bounds add up to less
 //                than min_roundness * P cannot pass (every term <= its bound) and is dropped.  Survivors are
 //                appended to a per-plane list.  Bounding roofline: LDS (one byte read per perimeter point).
-//   k_exact      the survivors' reference sum, one lane per survivor: float64, sequential in perimeter order,
-//                gradient angles computed on demand from the blurred image exactly as mg_edge_angles does (the
-//                dense angle map and its pass are not needed), score stored float32; circles that pass go to d_alive.
+//   k_exact      the survivors' reference sum (float64, sequential in perimeter order) in workgroup-level phases over
+//                XS = 64 (16 at small batches) survivors: NT / XS lanes per survivor find the edge pixels on its
+//                perimeter, a lane lists them in order, all lanes evaluate (survivor, hit) terms -- gradient angles
+//                computed on demand from the blurred image exactly as mg_edge_angles does (the dense angle map and
+//                its pass are not needed) --, a lane per survivor adds them in order with the reference-exact early
+//                exit; score stored float32; circles that pass go to d_alive.
 #include <math.h>
 
 #include <algorithm>

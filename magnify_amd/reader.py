@@ -207,7 +207,7 @@ def release_pinned():
     _PINNED_RING.clear()
 
 
-def iter_time_chunks(pattern, chunk: int, pinned: bool = False, workers: int = 8, ring: int = 4):
+def iter_time_chunks(pattern, chunk: int, pinned: bool = False, workers: int | None = None, ring: int = 4):
     """Streamed ingest of a time series too large to hold: the files behind
     ``pattern`` are read ``chunk`` timepoints at a time, in time order, page by page, never all at once.
     Groups as in ``extract_paths``: ``(channel)``, ``(time|format)``, and for tiled acquisitions ``(row)`` /
@@ -252,6 +252,8 @@ def iter_time_chunks(pattern, chunk: int, pinned: bool = False, workers: int = 8
     from concurrent.futures import ThreadPoolExecutor
 
     files_lock = threading.Lock()
+    if workers is None:
+        workers = min(16, os.cpu_count() or 1)
     pool = ThreadPoolExecutor(max_workers=max(1, int(workers))) if workers and workers > 1 else None
 
     def read_page(path, index, out):
