@@ -163,6 +163,28 @@ def _line_fit(x, y):
     return slope, ymean - slope * xmean
 
 
+def _cluster_slopes(gx, gy, order0, bounds, cnt, num_clusters):
+    """``_line_fit(...)[0]`` of every cluster with two points or more.  Clusters of the same size are fitted together
+    with the same operations on stacked arrays: row means of a (k, 2, n) block (NumPy's pairwise row sum, as np.mean
+    of each row alone), the centred block times its transpose through np.matmul (one dgemm per cluster, as np.cov's
+    np.dot), times 1 / n.  tests/test_oracle_golden.py compares it bit for bit with the per-cluster np.cov form and
+    with scipy's linregress on reference-generated goldens.  (A chip has a few distinct sizes -- 28 buttons a row,
+    one or two missed here and there: a few groups instead of 56 Python-level fits, 1 ms of a 4 ms C3 call.)"""
+    slopes = np.full(num_clusters, np.nan)
+    for size in np.unique(cnt[cnt >= 2]):
+        which = np.flatnonzero(cnt == size)
+        sel = order0[bounds[which][:, None] + np.arange(size)[None, :]]  # (k, size): the points in their original order
+        X = np.empty((len(which), 2, size))
+        X[:, 0], X[:, 1] = gx[sel], gy[sel]
+        if (X[:, 0].max(axis=1) == X[:, 0].min(axis=1)).any():
+            raise ValueError("Cannot calculate a linear regression if all x values are identical")  # (scipy's refusal)
+        X -= X.mean(axis=2)[:, :, None]
+        c = np.matmul(X, X.transpose(0, 2, 1).conj())
+        c *= np.true_divide(1, size)
+        slopes[which] = c[:, 0, 1] / c[:, 0, 0]
+    return slopes
+
+
 def label_clusters(points, offset, num_clusters, cluster_length, cluster_gap):
     """find.py:680-695: cluster i is the interval [offset + i (length + gap), ... + length); -1 outside.
     One binary search of every point in the 2 n interval ends (no sort of the points, no loop over clusters)."""
@@ -175,8 +197,8 @@ def label_clusters(points, offset, num_clusters, cluster_length, cluster_gap):
 def regress_clusters(x, y, labels, num_clusters, ideal_num_points):
     """find.py:698-748: a line per cluster, the median of their slopes for all, per-cluster median intercepts at
     that slope, blended -- by how complete a cluster is -- with the evenly spaced estimate from a line through
-    (cluster index, intercept).  The fits are linregress's own operations per cluster (_line_fit); the medians of all
-    clusters come from one sort."""
+    (cluster index, intercept).  The fits are linregress's own operations (_line_fit; clusters of equal size fitted
+    together, _cluster_slopes); the medians of all clusters come from one sort."""
     x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
     labels = np.asarray(labels)
     if num_clusters == 1:
@@ -184,13 +206,10 @@ def regress_clusters(x, y, labels, num_clusters, ideal_num_points):
     ideal = np.asarray(ideal_num_points, dtype=np.float64)
     inside, lab, n, _ = _group_stats(labels, num_clusters)
     gx, gy = x[inside], y[inside]
-    # a line per cluster with two points or more (a few dozen clusters of a few dozen points: the loop is microseconds)
-    slopes = np.full(num_clusters, np.nan)
+    # a line per cluster with two points or more (the cluster's points in their original order, as x[labels == i])
     order0 = np.argsort(lab, kind="stable")
     bounds = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
-    for i in np.flatnonzero(n >= 2):
-        sel = order0[bounds[i]: bounds[i + 1]]  # the cluster's points in their original order, as x[labels == i]
-        slopes[i] = _line_fit(gx[sel], gy[sel])[0]
+    slopes = _cluster_slopes(gx, gy, order0, bounds, n.astype(np.int64), num_clusters)
     if ((n[[0, -1]] < 2) & (ideal[[0, -1]] >= 2)).any():
         print("Boundary cluster has fewer than 2 points.The chip is unlikely to be segmented correctly.")
     slope = np.nanmedian(slopes)

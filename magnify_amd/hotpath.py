@@ -341,6 +341,7 @@ class CircleFinder:
         # hipGraphs of the optimistic chain (_optimistic_chain), by launch-sequence key
         self._graphs = None if os.environ.get("MG_NO_GRAPH") else {}
         self._graph_bufs, self.graph_replays, self.graph_captures = None, 0, 0
+        self._graph_seen, self._in_stage = set(), None
         self._mm = torch.empty((P, 2), dtype=torch.float64, device=dev)
         self.words = 2 * ((h * w + 63) // 64) + 2  # bitmap words per plane (even, one spare)
         self.edge_bits = torch.zeros((P, self.words), dtype=i32, device=dev)  # strong bits = edges
@@ -743,16 +744,20 @@ class CircleFinder:
         return self.nms_stage(min_dist, optimistic=True, bufs=bufs)
 
     def _optimistic_chain(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw, keep_u8,
-                          passthrough_u8):
+                          passthrough_u8, stable_input=False):
         """The chain as ONE hipGraph launch: the ~40 kernel launches / clears of a call are a fixed sequence as long as
         the inputs sit at the same addresses and the hints (window passes, sweeps, rounds, list and output capacities)
-        have not moved -- all of that is the graph's key; a sequence is captured when it first shows and replayed from
-        then on (up to 8 graphs are kept).  What changes from call to call travels through fixed buffers: the per-plane
-        min / max (copied into the finder's own block before the launch), the seeds (the pinned block the captured
-        upload reads) and the ordered output (the graph's own set, copied to the caller's).  Per-stage timing (a
+        have not moved -- all of that is the graph's key (up to 8 graphs are kept).  What changes from call to call
+        travels through fixed buffers: the per-plane min / max (copied into the finder's own block before the launch),
+        the seeds (the pinned block the captured upload reads), the ordered output (the graph's own set, copied to the
+        caller's) and, for small inputs (<= 32 MB: the chip's 784 chamber windows, gathered afresh every call), the
+        planes themselves (copied into the finder's own input block).  A sequence is captured the first time it shows
+        when the input is the finder's block or the caller vouches for its buffer (``stable_input``), else the second
+        time (a capture costs ~9 ms: not to be spent on addresses that never come back).  Single planes are launched
+        eagerly (measured: a replay is no faster there and its three extra copies cost 50 us).  Per-stage timing (a
         StageTimer without allow_graphs), debug maps and the raw / uint8 side outputs need the eager launches.
         MG_NO_GRAPH=1 turns the graphs off."""
-        usable = (self._graphs is not None and (TIMER is _NO_TIMER or getattr(TIMER, "allow_graphs", False))
+        usable = (self._graphs is not None and self.P >= 2 and (TIMER is _NO_TIMER or getattr(TIMER, "allow_graphs", False))
                   and not (keep_raw or keep_u8 or self.keep_debug_maps)
                   and not self.need_angle_map() and planes.stride(2) == 1)
         if not usable:
@@ -763,6 +768,11 @@ class CircleFinder:
         if minmax is not None:
             self._mm.copy_(minmax.reshape(self.P, 2))  # (stream-ordered: the values are read by the launch behind it)
             minmax = self._mm
+        if not stable_input and planes.numel() * planes.element_size() <= (32 << 20):
+            if self._in_stage is None or self._in_stage.dtype != planes.dtype:
+                self._in_stage = torch.empty((self.P, self.h, self.w), dtype=planes.dtype, device=self.dev)
+            self._in_stage.copy_(planes)
+            planes, stable_input = self._in_stage, True
         win = max(self._recent_win) if self._recent_win else 0
         sweeps = min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP)
         rounds = min(self._hint(self._recent_rounds, 2, spare=0), self.MAX_GROUP) if min_dist > 0 else 0
@@ -780,11 +790,16 @@ class CircleFinder:
                self._graph_bufs[0].data_ptr(), self.nms_grid.data_ptr() if self.nms_grid is not None else 0)
         entry = self._graphs.get(key)
         if entry is None and ready and self.graph_captures < self.MAX_CAPTURES:
-            # captured when a launch sequence first shows (a steady caller shows one; hints that drift -- one sweep more
-            # or less -- add a few; a caller whose sequences never repeat stops capturing after MAX_CAPTURES)
-            entry = self._capture_chain(key, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, passthrough_u8)
-            if self._graphs is None:
-                entry = None
+            # (hints that drift -- one sweep more or less -- add a few graphs; a caller whose sequences never repeat stops
+            # capturing after MAX_CAPTURES)
+            seen = stable_input or key in self._graph_seen
+            if len(self._graph_seen) >= 16:
+                self._graph_seen.clear()
+            self._graph_seen.add(key)
+            if seen:
+                entry = self._capture_chain(key, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, passthrough_u8)
+                if self._graphs is None:
+                    entry = None
         if entry is None:
             return self._launch_chain(planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw, keep_u8,
                                       passthrough_u8)
@@ -840,13 +855,16 @@ class CircleFinder:
         return entry
 
     def find(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw=False, keep_u8=False,
-             passthrough_u8=False, host_results=True, follow=None):
+             passthrough_u8=False, host_results=True, follow=None, stable_input=False):
         """Returns per-plane lists (circles int32 (M,3) [row, col, r], scores float32 (M,)) on the
         host plus the device tensors (out, out_scores, num_out).  ``host_results=False``: only the
         counts come back -- (counts, (out, out_scores, num_out)); ``fetch_results`` copies the lists
         later (e.g. after the ROI pass, which reads the tables on the device, has been launched).
         ``out`` / ``out_scores`` stay valid until the next-but-one ``find`` of this finder (two buffer sets used in
         turn); ``num_out`` is a row of the status block and is cleared by the next ``find``.
+
+        ``stable_input``: the caller hands in the same buffer call after call (StackProcessor's own image block): a
+        hipGraph of the chain may be captured the first time a launch sequence shows (_optimistic_chain).
 
         ``follow(out, num_out, out_cap)``: device work that consumes the ordered tables (the ROI pass), queued BEFORE
         the host waits for the status block -- the GPU goes straight on instead of idling through the round trip and the
@@ -866,7 +884,7 @@ class CircleFinder:
         self.stats["optimistic"] = False
         if opt:
             bufs, rounds = self._optimistic_chain(planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw,
-                                                  keep_u8, passthrough_u8)
+                                                  keep_u8, passthrough_u8, stable_input)
             followed = None
             if follow is not None:
                 chain_done = torch.cuda.Event()

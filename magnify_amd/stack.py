@@ -107,7 +107,8 @@ class StackProcessor:
                 planes = self.image[lo : lo + self.batch, ch]  # strided view, no copy
                 mm = self.minmax[lo : lo + self.batch, ch].contiguous()
                 seeds = [(seed + 1000003 * a + 7919 * k) & 0xFFFFFFFFFFFFFFFF for a in ids]
-                res, _ = self.finder.find(planes, mm, self.low_q, self.high_q, self.min_roundness, self.min_r, seeds)
+                res, _ = self.finder.find(planes, mm, self.low_q, self.high_q, self.min_roundness, self.min_r, seeds,
+                                          stable_input=True)  # (a view of this processor's own image block)
                 for j, a in enumerate(ids):
                     if a >= done:
                         beads[a] = np.concatenate([beads[a], dedup_against(beads[a], res[j][0], 2 * self.min_r)])
@@ -208,7 +209,7 @@ class StackProcessor:
             device_tables=(d_out, None, self.max_r), device_counts=(d_num, cap, self._roi_bound), pool_tag=self.pool_tag)
         counts, (d_beads, d_scores, _) = self.finder.find(self.image[:, ch], self.minmax[:, ch].contiguous(), self.low_q,
                                                            self.high_q, self.min_roundness, self.min_r, seeds,
-                                                           host_results=False, follow=roi_pass)
+                                                           host_results=False, follow=roi_pass, stable_input=True)
         out = hp.finish_roi(self.finder.follow_result, counts)
         if out is None:  # more markers than the pass was launched for: once more, with the counts
             out = hp.roi_gather_reduce(self.image.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi,

@@ -589,7 +589,7 @@ class Dataset:
         import xarray as xr
 
         def var(v):
-            return xr.Variable(v.dims, v.values, {k: a for k, a in v.attrs.items() if not k.startswith("__mg")})
+            return (v.dims, v.values, {k: a for k, a in v.attrs.items() if not k.startswith("__mg")})  # (dims, data, attrs)
 
         coords = {k: var(v) for k, v in self.coords.items()}
         data_vars = {k: var(v) for k, v in self.data_vars.items()}

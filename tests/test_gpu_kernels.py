@@ -697,8 +697,9 @@ def test_optimistic_chain_equals_checked_chain(hp):
 
 
 def test_graph_replay_equals_eager_launches(hp):
-    """The optimistic chain replayed as one hipGraph launch (same input buffer, same hints: captured at the second
-    coming of a launch sequence) against a finder that launches every kernel eagerly: same tables call after call,
+    """The optimistic chain replayed as one hipGraph launch (same input buffer, same hints: captured when the launch
+    sequence first shows, the caller vouching for its buffers) against a finder that launches every kernel eagerly:
+    same tables call after call,
     with new images and seeds travelling through the fixed buffers, through a call whose image breaks the hints (many
     more beads: the chain is repaired eagerly) and back, and with the ROI pass queued behind the replay (`follow`)."""
     shape = (320, 384)
@@ -720,7 +721,7 @@ def test_graph_replay_equals_eager_launches(hp):
             if cf.coords.shape[1] < 80000:
                 cf.coords = torch.empty((2, 80000, 2), dtype=torch.int32, device="cuda")
         seeds = [7000 + 2 * n, 7001 + 2 * n]
-        got, (d_out, _, d_num) = cf.find(buf, None, 0.1, 0.9, 0.3, 5, seeds,
+        got, (d_out, _, d_num) = cf.find(buf, None, 0.1, 0.9, 0.3, 5, seeds, stable_input=True,
                                          follow=lambda out, num, cap: (out.clone(), num.clone()))
         followed.append(cf.follow_result)
         want, _ = ref.find(buf, None, 0.1, 0.9, 0.3, 5, seeds)
@@ -735,6 +736,26 @@ def test_graph_replay_equals_eager_launches(hp):
     assert "graph_error" not in cf.stats, cf.stats.get("graph_error")
     assert cf.graph_replays >= 8 and 2 <= cf.graph_captures <= 6, (cf.graph_replays, cf.graph_captures, cf.calls)
     assert ref.graph_replays == 0
+    # a caller that hands in a fresh tensor every call (the chip's gathered chamber windows): small inputs are copied
+    # into the finder's own block, the graph is keyed on that; a single plane is always launched eagerly
+    st = hp.CircleFinder(2, shape[0], shape[1], 5, 21, 60000)
+    one = hp.CircleFinder(1, shape[0], shape[1], 5, 21, 60000)
+    for n, planes in enumerate(images[:6]):
+        seeds = [7000 + 2 * n, 7001 + 2 * n]
+        if n > 0:
+            st._recent_sweeps[:], st._recent_rounds[:] = [12], [12]
+            if st.coords.shape[1] < 80000:
+                st.coords = torch.empty((2, 80000, 2), dtype=torch.int32, device="cuda")
+        fresh = dev(planes).clone()
+        got, _ = st.find(fresh, None, 0.1, 0.9, 0.3, 5, seeds)
+        want, _ = ref.find(fresh, None, 0.1, 0.9, 0.3, 5, seeds)
+        single, _ = one.find(fresh[:1], None, 0.1, 0.9, 0.3, 5, seeds[:1])
+        for p in range(2):
+            np.testing.assert_array_equal(got[p][0], want[p][0], err_msg=f"staged call {n} plane {p}")
+            np.testing.assert_array_equal(got[p][1], want[p][1], err_msg=f"staged call {n} plane {p}")
+        np.testing.assert_array_equal(single[0][0], want[0][0])
+    assert st.graph_replays >= 3 and st.graph_captures <= 3, (st.graph_replays, st.graph_captures)
+    assert one.graph_replays == 0 and one.graph_captures == 0
 
 
 def test_edge_grid_chunked_scan(hp):

@@ -137,3 +137,28 @@ def test_product_cluster_helpers_equal_the_reference_bit_for_bit(golden):
     assert s == g["rag_slope"]
     np.testing.assert_array_equal(b, g["rag_intercepts"])
     np.testing.assert_array_equal(product.label_clusters(g["y"], 120, 6, 60, float(g["rd"]) - 60), g["row_labels_fixed"])
+
+
+def test_product_grouped_cluster_fits_equal_the_single_fits():
+    """find._cluster_slopes (clusters of one size fitted together on stacked arrays) against find._line_fit (np.mean +
+    np.cov per cluster, linregress's operations): the same bits for every cluster, over sizes 2 .. 70 and a chip-like
+    mix of sizes; a cluster whose x are all equal is refused as linregress refuses it."""
+    from magnify_amd import find as product
+
+    rng = np.random.default_rng(77)
+    sizes = np.concatenate([np.arange(2, 71), rng.integers(26, 29, size=56), [1, 0, 128, 257]])
+    labels = np.repeat(np.arange(len(sizes)), sizes)
+    perm = rng.permutation(len(labels))
+    labels = labels[perm]
+    x, y = rng.normal(3500, 2000, len(labels)), rng.normal(3500, 2000, len(labels))
+    order0 = np.argsort(labels, kind="stable")
+    bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    got = product._cluster_slopes(x, y, order0, bounds, sizes.astype(np.int64), len(sizes))
+    for i, n in enumerate(sizes):
+        if n < 2:
+            assert np.isnan(got[i])
+        else:
+            assert got[i] == product._line_fit(x[labels == i], y[labels == i])[0], (i, n)
+    x[labels == 5] = 12.0
+    with pytest.raises(ValueError):
+        product._cluster_slopes(x, y, order0, bounds, sizes.astype(np.int64), len(sizes))

@@ -60,6 +60,11 @@ def main():
         tot += ms / args.calls
         print(f"  {name:28s} {1e3 * ms / args.calls:8.1f} us/call  {cnt / args.calls:5.1f} launches/call")
     print(f"  stages together {tot:.3f} ms/call")
+    from magnify_amd import find as mgfind
+
+    for key, f in mgfind._FINDERS.items():
+        print(f"  finder P={f.P} {f.h}x{f.w}: graph replays {f.graph_replays}, captures {f.graph_captures}, "
+              f"error {f.stats.get('graph_error')}")
     if args.profile:
         pr = cProfile.Profile()
         pr.enable()
