@@ -370,7 +370,7 @@ def main():
             unique, alive, scored = int(f.num_circles.sum().item()), int(f.num_alive.sum().item()), int(f.num_scored.sum().item())
             edges, fstats, search_planes = int(f.n_edges_host.sum()), [f.stats], f.P
         finders = list(getattr(proc, "finders", None) or [f])
-        chain = {k: sum(x.calls[k] for x in finders) for k in ("optimistic", "repaired", "checked")}
+        chain = {k: sum(x.calls[k] for x in finders) for k in ("optimistic", "repaired", "checked", "followed_again")}
         per_starts = f.per_starts.cpu().numpy()
         mean_perimeter = float(np.mean(np.diff(per_starts)))
         p = {"h": S, "w": S, "n_c": C, "n_t": T, "search_planes": search_planes, "num_iter": args.num_iter,
@@ -448,7 +448,8 @@ def main():
                       "alive_circles": alive, "edges": p["edges"],
                       "hysteresis_sweeps": p["sweeps"], "nms_rounds": p["nms_rounds"],
                       # calls of find() since start-up (warm-up included): with ONE host round trip (optimistic),
-                      # with a repair after it, with the three round trips of the checked chain
+                      # with a repair after it, with the three round trips of the checked chain; followed_again:
+                      # optimistic calls whose ROI pass had to run a second time (output regathered)
                       "find_calls": chain,
                       # optimistic calls whose ~40 launches went out as one hipGraph replay
                       "graph_replays": sum(getattr(x, "graph_replays", 0) for x in finders),

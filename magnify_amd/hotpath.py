@@ -335,13 +335,15 @@ class CircleFinder:
         # at the one host round trip at the end.  MG_CHECKED_CHAIN=1 keeps the three-round-trip chain.
         self.optimistic = not os.environ.get("MG_CHECKED_CHAIN")
         self._recent_sweeps, self._recent_rounds = [], []
-        self.calls = {"optimistic": 0, "repaired": 0, "checked": 0}  # how the calls of this finder went (find)
+        # how the calls of this finder went (find); followed_again: optimistic calls whose follow-up pass ran twice
+        self.calls = {"optimistic": 0, "repaired": 0, "checked": 0, "followed_again": 0}
         self._out_sets, self._out_turn, self._out_cap = [None, None], 0, 0
         self._n_collects, self.follow_result = 0, None
         # hipGraphs of the optimistic chain (_optimistic_chain), by launch-sequence key
         self._graphs = None if os.environ.get("MG_NO_GRAPH") else {}
         self._graph_bufs, self.graph_replays, self.graph_captures = None, 0, 0
         self._graph_seen, self._in_stage = set(), None
+        self._round_spare = 0
         self._mm = torch.empty((P, 2), dtype=torch.float64, device=dev)
         self.words = 2 * ((h * w + 63) // 64) + 2  # bitmap words per plane (even, one spare)
         self.edge_bits = torch.zeros((P, self.words), dtype=i32, device=dev)  # strong bits = edges
@@ -692,7 +694,8 @@ class CircleFinder:
             rounds = 0
             if min_dist > 0:
                 self._nms_prepare(min_dist)
-                rounds = min(self._hint(self._recent_rounds, 2, spare=0), self.MAX_GROUP)  # (a missing round is cheap to add)
+                # (a missing round is cheap to add -- unless a follow-up pass has been queued on the tables: _round_spare)
+                rounds = min(self._hint(self._recent_rounds, 2, spare=self._round_spare), self.MAX_GROUP)
                 self._nms_rounds(min_dist, True, rounds, bufs[0].shape[1])
             self._collect(bufs, min_dist)
             return bufs, rounds
@@ -753,11 +756,12 @@ class CircleFinder:
         caller's) and, for small inputs (<= 32 MB: the chip's 784 chamber windows, gathered afresh every call), the
         planes themselves (copied into the finder's own input block).  A sequence is captured the first time it shows
         when the input is the finder's block or the caller vouches for its buffer (``stable_input``), else the second
-        time (a capture costs ~9 ms: not to be spent on addresses that never come back).  Single planes are launched
-        eagerly (measured: a replay is no faster there and its three extra copies cost 50 us).  Per-stage timing (a
+        time (a capture costs ~9 ms: not to be spent on addresses that never come back).  A single plane from a caller
+        that does not vouch for its buffer is launched eagerly (measured through mg.beads: C2 1.09 ms eager, 1.17 replayed;
+        a one-timepoint StackProcessor shard, which does: 1.31 eager, 1.17 replayed).  Per-stage timing (a
         StageTimer without allow_graphs), debug maps and the raw / uint8 side outputs need the eager launches.
         MG_NO_GRAPH=1 turns the graphs off."""
-        usable = (self._graphs is not None and self.P >= 2 and (TIMER is _NO_TIMER or getattr(TIMER, "allow_graphs", False))
+        usable = (self._graphs is not None and (self.P >= 2 or stable_input) and (TIMER is _NO_TIMER or getattr(TIMER, "allow_graphs", False))
                   and not (keep_raw or keep_u8 or self.keep_debug_maps)
                   and not self.need_angle_map() and planes.stride(2) == 1)
         if not usable:
@@ -775,7 +779,7 @@ class CircleFinder:
             planes, stable_input = self._in_stage, True
         win = max(self._recent_win) if self._recent_win else 0
         sweeps = min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP)
-        rounds = min(self._hint(self._recent_rounds, 2, spare=0), self.MAX_GROUP) if min_dist > 0 else 0
+        rounds = min(self._hint(self._recent_rounds, 2, spare=self._round_spare), self.MAX_GROUP) if min_dist > 0 else 0
         # the graph writes its ordered output into a set of its own (the public sets alternate from call to call --
         # a graph per set would double the captures); two small copies hand it to the caller's set after the replay
         if self._graph_bufs is None or self._graph_bufs[0].shape[1] != self._out_cap:
@@ -882,6 +886,10 @@ class CircleFinder:
         opt = (self.optimistic and self.coords is not None and self._out_cap > 0
                and bool(self._recent_sweeps) and (min_dist <= 0 or bool(self._recent_rounds)))
         self.stats["optimistic"] = False
+        # a suppression round too few is added after the status fetch at the price of a round trip; with a follow-up
+        # pass queued on the tables it would also cost that pass again (the ROI pass: 4.5 ms at 64 planes, seen once in
+        # 20 steps) -- one spare round (~10 us when nothing is undecided) is launched instead
+        self._round_spare = 1 if follow is not None else 0
         if opt:
             bufs, rounds = self._optimistic_chain(planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw,
                                                   keep_u8, passthrough_u8, stable_input)
@@ -927,6 +935,7 @@ class CircleFinder:
         counts = self._out_counts  # came back with the suppression's convergence check
         self.stats["n_edges"] = n_edges
         if follow is not None and (not opt or followed != (self._n_collects, out.data_ptr())):
+            self.calls["followed_again"] += int(opt)
             self.follow_result = follow(out, num_out, out.shape[1])  # (the tables it read before were not the final ones)
         if not host_results:
             return counts, (out, out_scores, num_out)
