@@ -459,8 +459,10 @@ int mg_masked_sums(const void* d_roi, int dtype, const uint8_t* d_fg, const uint
  * ---------------------------------------------------------------------------------- */
 
 /* One streaming pass over n_bytes (a multiple of 16, 16-byte aligned buffers) by this library's own 16-byte-per-lane
- * grid-stride kernel on `blocks` workgroups of 256: mode 0 copies d_src to d_dst, mode 1 only reads d_src (every
- * workgroup leaves four words in d_sink[4 * blocks]), mode 2 only writes d_dst.  The caller times it (HIP events). */
+ * grid-stride kernel on `blocks` workgroups of 256 (1 .. 65535; 0: one 16-byte access per lane, n_bytes / 4096
+ * workgroups): mode 0 copies d_src to d_dst, mode 1 only reads d_src (d_sink: one word, written only if a lane's
+ * words XOR to one particular value -- it keeps the loads alive), mode 2 only writes d_dst.  The caller times it
+ * (HIP events). */
 int mg_stream_probe(const void* d_src, void* d_dst, int64_t n_bytes, int mode, uint32_t* d_sink, int blocks, void* stream);
 
 #ifdef __cplusplus

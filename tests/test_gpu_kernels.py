@@ -806,3 +806,27 @@ def test_edge_grid_chunked_scan(hp):
     np.testing.assert_array_equal(num_d.cpu().numpy(), [num[0], 0, 0])
     c0 = coords[0, : num[0]].cpu().numpy()
     assert (c0 >= 0).all() and len(np.unique(c0[:, 0].astype(np.int64) * w + c0[:, 1])) == num[0]
+
+
+def test_stream_probe_moves_the_bytes(hp):
+    """mg_stream_probe (the measured streaming ceiling of bench.py): the copy copies, in both launch shapes (a given
+    number of workgroups; 0 = one access per lane), the fill writes its pattern, arguments are checked."""
+    from magnify_amd import _native as nat
+
+    n = (1 << 20) + 4096 + 16  # not a multiple of a workgroup's 4 KiB
+    src = torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda")
+    sink = torch.zeros(4 * (n // 4096 + 1), dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for blocks in (7, 64, 0):
+        dst = torch.zeros_like(src)
+        nat.check(nat.lib().mg_stream_probe(src.data_ptr(), dst.data_ptr(), n, 0, sink.data_ptr(), blocks, s), "probe")
+        assert torch.equal(src, dst)
+        nat.check(nat.lib().mg_stream_probe(src.data_ptr(), dst.data_ptr(), n, 1, sink.data_ptr(), blocks, s), "probe")
+        nat.check(nat.lib().mg_stream_probe(src.data_ptr(), dst.data_ptr(), n, 2, sink.data_ptr(), blocks, s), "probe")
+        np.testing.assert_array_equal(dst.cpu().numpy().view(np.uint32).reshape(-1, 4), np.tile([1, 2, 3, 4], (n // 16, 1)))
+    with pytest.raises(ValueError):
+        nat.check(nat.lib().mg_stream_probe(src.data_ptr(), dst.data_ptr(), n - 8, 0, sink.data_ptr(), 8, s), "probe")
+    with pytest.raises(ValueError):
+        nat.check(nat.lib().mg_stream_probe(src.data_ptr(), dst.data_ptr(), n, 3, sink.data_ptr(), 8, s), "probe")
+    with pytest.raises(ValueError):
+        nat.check(nat.lib().mg_stream_probe(src.data_ptr(), dst.data_ptr(), n, 0, sink.data_ptr(), -1, s), "probe")
