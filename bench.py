@@ -47,7 +47,7 @@ def algorithmic_bytes(stage, p):
         # planes once + the survivors' records and scores; its real bound is the LDS (one byte read per perimeter
         # point), the HBM bytes are small
         "mg_score_circles": p["unique"] * 4 + planes * n / 8 * 4 + p.get("scored", 0) * 16,
-        "mg_nms_round": p["alive"] * p["ring_len"] * 16 * p["nms_rounds"],
+        "mg_nms_rounds": p["alive"] * p["ring_len"] * 16 * p["nms_rounds"],
         "mg_collect_circles": p["alive"] * 4 + p["markers"] * 16,
         "mg_circle_labels": p["markers"] * p["mean_disk"] * 8,
         "mg_roi_gather_reduce_batched": p["markers"] * p["L"] ** 2 * (4 * c + 6),

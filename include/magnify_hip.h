@@ -75,10 +75,14 @@ int mg_perimeter_table(int min_r, int max_r, int32_t* out_rc, double* out_expect
  * assays when every time slice is its own assay).  d_max2 is double[n_groups][2], pre-initialised
  * by the caller to -inf.  dark/flat: scalar when d_dark / d_flat is NULL, else a (ty, tx) image
  * of type dark_dtype / flat_dtype (MG_F32 or MG_F64) broadcast over tiles.
- * d_scratch (optional): mg_flatfield_max_scratch_floats(dtype, ty, tx) floats owned by the caller; with it the
- * integer-pixel / float32-flat path reads the flat image through a per-chunk bound an eighth (a sixteenth) of its
- * size and touches the image itself only where a pixel can still raise M2 (same result, less traffic). */
+ * d_scratch (optional): mg_flatfield_max_scratch_floats(dtype, ty, tx) floats owned by the caller and filled by
+ * mg_flatfield_bound for THIS flat image (float32, integer pixel type `dtype`; -1 / MG_EINVAL where there is no such
+ * path: the tile size must be a multiple of 8 (16) pixels): a per-chunk bound an eighth (a sixteenth) of the image's
+ * size.  With it the integer-pixel / float32-flat path touches the flat image itself only where a pixel can still raise
+ * M2 (same result, less traffic); the bound is computed once per flat image, not once per call. */
 int64_t mg_flatfield_max_scratch_floats(int dtype, int ty, int tx);
+int mg_flatfield_bound(const void* d_flat, int flat_dtype, int dtype, int ty, int tx, float* d_scratch,
+                       int64_t scratch_floats, void* stream);
 int mg_flatfield_max(const void* d_tiles, int dtype, int64_t n_tiles, int n_groups, int ty, int tx,
                      double dark, const void* d_dark, int dark_dtype,
                      double flat, const void* d_flat, int flat_dtype,
@@ -242,19 +246,23 @@ int mg_candidate_keys(const int32_t* d_coords, int64_t coord_cap, const int32_t*
  * list, the iterations that can place a centre in a given 64 x 64 tile form one contiguous key range
  * per cell row within max_r + 2 of the tile; one workgroup per pair of tiles scans them, ORs its own
  * keys into an LDS copy of the tiles' layers, counts, reserves its slice of the plane's list with one
- * atomicAdd on d_num_circles (zeroed by this call) and stores the unique keys of each tile in
+ * atomicAdd on d_num_circles (zeroed by this call unless counters_clear, see below) and stores the unique keys of each tile in
  * (r, row, col) order:
  *   d_unique_keys[n_planes][circle_cap] uint32, d_tile_ranges[n_planes][n_tiles][2] int32 = (first, count)
  *   of every tile (n_tiles = tile rows x tile cols of mg_dedup_layout), d_num_circles[n_planes].
  * The slices of different workgroups land in arrival order: list positions are not canonical, the
- * keys are (mg_nms_round / mg_collect_circles take them as tie-breakers).  d_cell_* / d_num_edges /
+ * keys are (mg_nms_rounds / mg_collect_circles take them as tie-breakers).  d_cell_* / d_num_edges /
  * grid / num_iter must be those the keys were generated with.
  * d_layer_starts (optional, [n_planes][n_tiles][nr + 1], nr = max_r - min_r + 1): list index of the first key
- * of every radius of every tile, entry nr = the tile's end (mg_score_circles_keyed deals its work by radius). */
+ * of every radius of every tile, entry nr = the tile's end (mg_score_circles_keyed deals its work by radius).
+ * counters_clear (here and in mg_score_circles_keyed, mg_nms_rounds, mg_collect_circles): 0 -- the call clears the
+ * per-plane counters it accumulates into (d_num_circles / d_num_surv / d_undecided / d_num_out) with a launch of its
+ * own; 1 -- the caller has cleared them (a caller that keeps all its counters in one block clears it once per chain:
+ * eight ~5 us launches fewer, a tenth of a single-plane call). */
 int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, const int32_t* d_cell_starts,
                        const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w, int grid,
                        int min_r, int max_r, uint32_t* d_unique_keys, int64_t circle_cap, int32_t* d_tile_ranges,
-                       int32_t* d_num_circles, int32_t* d_layer_starts, void* stream);
+                       int32_t* d_num_circles, int32_t* d_layer_starts, int counters_clear, void* stream);
 
 /* Ordered compaction of the bitmap into the unique circle list in the build's canonical order
  * (tile_row, tile_col, r, row, col): d_circles[n_planes][circle_cap][3] int32 (row, col, r),
@@ -327,28 +335,31 @@ int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angle, const ui
                            const double* d_per_expected, const int32_t* d_per_starts, int per_total,
                            const uint64_t* d_pair_table, float min_roundness, int write_skipped, float* d_scores,
                            int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc, int32_t* d_num_scored,
-                           int32_t* d_surv_list, int64_t surv_cap, int32_t* d_num_surv, void* stream);
+                           int32_t* d_surv_list, int64_t surv_cap, int32_t* d_num_surv, int counters_clear,
+                           void* stream);
 
-/* One round of the parallel-but-equivalent greedy suppression of filter_neighbors
+/* n_rounds rounds of the parallel-but-equivalent greedy suppression of filter_neighbors
  * (utils.py:254-292).  Priority = (score desc, tie key asc) -- the build's canonical tie order
  * (tile_row, tile_col, r, row, col): d_tie_keys[n_planes][circle_cap] (the unique keys of
  * mg_keys_to_circles) or, when NULL, the index in d_circles (canonical after mg_bitmap_to_circles).
  * d_grid[n_planes][grid_cap] uint64 claim grid pre-set to all-ones;
  * d_state[n_planes][circle_cap] uint8 (0 undecided, 1 kept, 2 dropped) pre-zeroed for
- * alive circles; d_undecided[n_planes] is set to 0, or to 1 when a circle is still undecided.
+ * alive circles; round k sets d_undecided[k * undecided_stride + plane] to 0 (counters_clear: the caller has), or to
+ * 1 when a circle of the plane is still undecided after it: the rounds have converged when a round leaves none.
  * Ring = 4-connected perimeter of radius min_dist (d_ring_rc, ring_len); indices wrap
  * modulo the claim grid extent like negative numba indices do. */
-/* max_alive (both calls): an upper bound of d_num_alive known to the caller, used only to size the
+/* max_alive (all suppression calls): an upper bound of d_num_alive known to the caller, used only to size the
  * launch grid (0 = unknown: a grid for circle_cap). */
-int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
-                 const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist,
-                 const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
-                 int32_t* d_undecided, const uint32_t* d_tie_keys, int64_t max_alive, void* stream);
+int mg_nms_rounds(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
+                  const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist,
+                  const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
+                  int32_t* d_undecided, int64_t undecided_stride, int n_rounds, int counters_clear,
+                  const uint32_t* d_tie_keys, int64_t max_alive, void* stream);
 
 /* Before the rounds (optional, exact): of the alive circles that share a centre only the first in suppression
  * order (score desc, tie key asc) stays undecided, the others are marked rejected -- they have the same ring and
  * are rejected whatever happens to the first (utils.py:254-292).  One bid on the centre's own claim-grid cell,
- * which is restored before returning; d_state as for mg_nms_round. */
+ * which is restored before returning; d_state as for mg_nms_rounds. */
 int mg_nms_same_centre(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
                        const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist, uint64_t* d_grid,
                        int64_t grid_cap, uint8_t* d_state, const uint32_t* d_tie_keys, int64_t max_alive, void* stream);
@@ -367,7 +378,7 @@ int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, const float* d_
 int mg_collect_circles(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
                        const int32_t* d_num_alive, const uint8_t* d_state, int keep_all, int n_planes,
                        int32_t* d_out, float* d_out_scores, int64_t out_cap, int32_t* d_num_out,
-                       int32_t* d_scratch, const uint32_t* d_tie_keys, void* stream);
+                       int32_t* d_scratch, const uint32_t* d_tie_keys, int counters_clear, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * A12-A15, A18 labels, ROI gather, fg/bg masks, masked reductions

@@ -33,6 +33,7 @@ PROTOTYPES = {
     "mg_perimeter_table": [_i, _i, _p, _p, _p, _i],
     "mg_flatfield_max": [_p, _i, _l, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p, _l, _p],
     "mg_flatfield_max_scratch_floats": [_i, _i, _i],
+    "mg_flatfield_bound": [_p, _i, _i, _i, _i, _p, _l, _p],
     "mg_flatfield_is_identity": [_i, _d, _p, _d, _p],
     "mg_flatfield_apply_stitch": [_p, _i, _l, _i, _i, _i, _i, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p, _p, _p],
     "mg_plane_minmax": [_p, _i, _i, _l, _i, _i, _l, _p, _p],
@@ -49,7 +50,7 @@ PROTOTYPES = {
     "mg_edge_grid": [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p, _p, _i, _p],
     "mg_candidate_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _p, _p],
     "mg_candidate_keys": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _i, _p, _p, _p],
-    "mg_keys_to_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _l, _p, _p, _p, _p],
+    "mg_keys_to_circles": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _l, _p, _p, _p, _i, _p],
     "mg_bitmap_to_circles": [_p, _l, _i, _i, _i, _i, _i, _p, _p, _l, _p, _p],
     "mg_edge_angles": [_p, _i, _i, _i, _p, _l, _p, _p, _p],
     "mg_dedup_layout": [_i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
@@ -58,10 +59,10 @@ PROTOTYPES = {
     "mg_score_pair_table": [_p, _i],
     "mg_score_pairs": [_i, _p, _i],
     "mg_score_circles_keyed": [_p, _p, _p, _p, _l, _i, _i, _i, _p, _l, _p, _p, _i, _i, _p, _p, _p, _i, _p, _f, _i,
-                               _p, _p, _p, _p, _p, _p, _l, _p, _p],
-    "mg_nms_round": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _p, _l, _p],
+                               _p, _p, _p, _p, _p, _p, _l, _p, _i, _p],
+    "mg_nms_rounds": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _l, _i, _i, _p, _l, _p],
     "mg_nms_same_centre": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _l, _p, _p, _l, _p],
-    "mg_collect_circles": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p],
+    "mg_collect_circles": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _i, _p],
     "mg_circle_labels": [_p, _l, _p, _i, _i, _i, _p, _i, _p, _i, _p],
     "mg_nms_cleanup": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _l, _p],
     "mg_roi_gather_reduce": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],

@@ -1043,7 +1043,7 @@ extern "C" int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, cons
                                   const int32_t* d_cell_counts, const int32_t* d_num_edges, int n_planes, int h, int w,
                                   int grid, int min_r, int max_r, uint32_t* d_unique_keys, int64_t circle_cap,
                                   int32_t* d_tile_ranges, int32_t* d_num_circles, int32_t* d_layer_starts,
-                                  void* stream) {
+                                  int counters_clear, void* stream) {
   if (!d_keys || !d_cell_starts || !d_cell_counts || !d_num_edges || !d_unique_keys || !d_tile_ranges ||
       !d_num_circles || n_planes < 0 || n_planes > 65535 || circle_cap < 0 || num_iter < 0 || grid <= 0)
     return MG_EINVAL;
@@ -1057,7 +1057,7 @@ extern "C" int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, cons
   const int gr = (h + grid - 1) / grid, gc = (w + grid - 1) / grid;
   hipStream_t s = mg_stream(stream);
   if (ntr > 65535) return MG_EINVAL;
-  if (mg_zero_async(d_num_circles, (size_t)n_planes * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
+  if (!counters_clear && mg_zero_async(d_num_circles, (size_t)n_planes * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
   const int tx = DEDUP_TX;  // 1 / 2 / 4 measured: 4.4 / 4.1 / 5.4 ms per step for the whole compaction
   hipLaunchKernelGGL(k_tile_dedup<DEDUP_TX>,
                      dim3((ntc + tx - 1) / tx, ntr, n_planes), dim3(NT), (size_t)tx * nr * LAYER_WORDS * 4, s, d_keys,
@@ -1124,29 +1124,33 @@ inline int nms_circles_per_wave(int64_t alive_bound, int n_planes) {
 }
 }  // namespace
 
-extern "C" int mg_nms_round(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
-                            const int32_t* d_alive, const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes,
-                            int min_dist, const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap,
-                            uint8_t* d_state, int32_t* d_undecided, const uint32_t* d_tie_keys, int64_t max_alive,
-                            void* stream) {
+extern "C" int mg_nms_rounds(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
+                             const int32_t* d_alive, const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes,
+                             int min_dist, const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap,
+                             uint8_t* d_state, int32_t* d_undecided, int64_t undecided_stride, int n_rounds,
+                             int counters_clear, const uint32_t* d_tie_keys, int64_t max_alive, void* stream) {
   if (!d_circles || !d_scores || !d_alive || !d_num_alive || !d_max_rc || !d_ring_rc || !d_grid || !d_state ||
       !d_undecided)
     return MG_EINVAL;
-  if (n_planes < 0 || n_planes > 65535 || min_dist <= 0 || ring_len <= 0) return MG_EINVAL;
+  if (n_planes < 0 || n_planes > 65535 || min_dist <= 0 || ring_len <= 0 || n_rounds < 0) return MG_EINVAL;
+  if (n_rounds > 1 && undecided_stride < n_planes) return MG_EINVAL;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
   hipStream_t s = mg_stream(stream);
-  if (mg_zero_async(d_undecided, sizeof(int32_t) * n_planes, s) != hipSuccess) return MG_ELAUNCH;
   // the kernels walk d_alive with a grid-stride loop: max_alive (> 0: the caller's upper bound of
   // d_num_alive) only sizes the grid -- an all-capacity grid of empty blocks costs ~0.1 ms per launch
   const int64_t bound = max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap;
   const int cpw = nms_circles_per_wave(bound, n_planes);
   const dim3 g(grid_x(bound * (64 / cpw)), n_planes);
-  hipLaunchKernelGGL((k_nms<0>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                     min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided, d_tie_keys, cpw);
-  MG_CHECK_LAUNCH();
-  hipLaunchKernelGGL((k_nms<1>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                     min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, d_undecided, d_tie_keys, cpw);
-  MG_CHECK_LAUNCH();
+  for (int k = 0; k < n_rounds; ++k) {
+    int32_t* und = d_undecided + (int64_t)k * undecided_stride;
+    if (!counters_clear && mg_zero_async(und, sizeof(int32_t) * n_planes, s) != hipSuccess) return MG_ELAUNCH;
+    hipLaunchKernelGGL((k_nms<0>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
+                       min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, und, d_tie_keys, cpw);
+    MG_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_nms<1>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
+                       min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, und, d_tie_keys, cpw);
+    MG_CHECK_LAUNCH();
+  }
   return MG_OK;
 }
 
@@ -1192,13 +1196,14 @@ extern "C" int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, cons
 extern "C" int mg_collect_circles(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
                                   const int32_t* d_alive, const int32_t* d_num_alive, const uint8_t* d_state,
                                   int keep_all, int n_planes, int32_t* d_out, float* d_out_scores, int64_t out_cap,
-                                  int32_t* d_num_out, int32_t* d_scratch, const uint32_t* d_tie_keys, void* stream) {
+                                  int32_t* d_num_out, int32_t* d_scratch, const uint32_t* d_tie_keys, int counters_clear,
+                                  void* stream) {
   if (!d_circles || !d_scores || !d_alive || !d_num_alive || !d_out || !d_num_out || !d_scratch) return MG_EINVAL;
   if (!keep_all && !d_state) return MG_EINVAL;
   if (n_planes < 0 || n_planes > 65535 || out_cap < 0) return MG_EINVAL;
   if (n_planes == 0) return MG_OK;
   hipStream_t s = mg_stream(stream);
-  if (mg_zero_async(d_num_out, sizeof(int32_t) * n_planes, s) != hipSuccess) return MG_ELAUNCH;
+  if (!counters_clear && mg_zero_async(d_num_out, sizeof(int32_t) * n_planes, s) != hipSuccess) return MG_ELAUNCH;
   if (circle_cap == 0 || out_cap == 0) return MG_OK;
   // out_cap bounds the alive counts in practice; the grid-stride loop covers the rest otherwise
   hipLaunchKernelGGL(k_collect_list, dim3(grid_x(std::min(circle_cap, std::max<int64_t>(out_cap, NT))), n_planes),

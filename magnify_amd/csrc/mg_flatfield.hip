@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_flat_rcmax(const float* __restrict__ d_
   }
 }
 
-template <typename T>
+template <typename T, bool SHARE>
 __global__ __launch_bounds__(256) void k_flatfield_max_lean(const T* __restrict__ tiles, int64_t tiles_per_group,
                                                              int64_t tile_elems, double dark,
                                                              const float* __restrict__ d_flat,
@@ -370,10 +370,24 @@ __global__ __launch_bounds__(256) void k_flatfield_max_lean(const T* __restrict_
   // plain read, tools/micro/copy_bw.hip -- 1.66 ms here instead of 1.51: four tiles 32 MiB apart walk in step)
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t vend = nvec;
+  // The threshold a lane tests against comes from its own running maximum AND from the group's (out[1]): the first
+  // PUBLISHERS workgroups of a group add the maximum of their first trip to it (a wave at a time, look-first), every
+  // lane looks at it on trips 1, 2, 4, 8, ....  A lane of a small batch sees a few dozen chunks: on its own maximum alone a sixth
+  // of them took the exact path (one 4 x 4096^2 assay: 81 -> 62 us; 8 assays: 277 -> 239 us).  Any value found there
+  // is the exact quotient of a pixel some lane holds in its m2, so a pixel skipped against it cannot be the maximum.
+  // SHARE is off where a lane has hundreds of chunks of its own (64 assays: the sharing cost 5 %).
+  constexpr int PUBLISHERS = 32;
+  float gthr = -INFINITY;
+  int trip = 0;
+  const bool publish = SHARE && blockIdx.x < PUBLISHERS && (int64_t)(blockIdx.x + 1) * blockDim.x <= nvec;  // (whole waves on trip 0)
   for (int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v0 < nvec; v0 += UV * stride) {
     float rcm[UV];
 #pragma unroll
     for (int u = 0; u < UV; ++u) rcm[u] = d_rcmax[min(v0 + u * stride, nvec - 1)];
+    if (SHARE && trip > 0 && (trip & (trip - 1)) == 0) {  // trips 1, 2, 4, 8, ...: a look every trip cost 10 % at 64 assays
+      const double gm = __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (gm == gm && gm < 1e30 && gm > -INFINITY) gthr = fmaxf(gthr, (float)gm * (1.0f - 1e-5f));
+    }
     any = true;
     for (int64_t g0 = 0; g0 < tiles_per_group; g0 += 4) {  // four tiles (channels) of the group per trip, loads together
       T x4[UV][4][N];
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(256) void k_flatfield_max_lean(const T* __restrict_
           // t -> float(x) - dark -> max(., 0) and the product with a non-negative reciprocal are monotone: if the chunk's
           // largest pixel with the chunk's largest reciprocal stays at or below the threshold, every pixel does
           const float tf = fmaxf((float)cm - dk_f, 0.0f);
-          if (rcm[u] >= 0.0f && tf * rcm[u] <= thr) continue;
+          if (rcm[u] >= 0.0f && tf * rcm[u] <= fmaxf(thr, gthr)) continue;
           float fl[N];
 #pragma unroll
           for (int k4 = 0; k4 < N / 4; ++k4) {
@@ -409,7 +423,7 @@ __global__ __launch_bounds__(256) void k_flatfield_max_lean(const T* __restrict_
             const uint32_t xi = (uint32_t)x4[u][q][j];
             const float t_f = fmaxf((float)xi - dk_f, 0.0f);
             const bool in_range = fl[j] > 1e-30f && fl[j] < 1e30f;
-            if (in_range && t_f * __builtin_amdgcn_rcpf(fl[j]) <= thr) continue;  // provably below the running maximum
+            if (in_range && t_f * __builtin_amdgcn_rcpf(fl[j]) <= fmaxf(thr, gthr)) continue;  // provably below the running maximum
             double t = (double)xi - dark;
             t = t < 0.0 ? 0.0 : t;
             m2 = mg_nanmax(m2, t / (double)fl[j]);
@@ -418,6 +432,11 @@ __global__ __launch_bounds__(256) void k_flatfield_max_lean(const T* __restrict_
         }
       }
     }
+    if (trip == 0 && publish) {  // (block-uniform: every lane of the wave is here)
+      const double wm = mg_wave_nanmax(m2);
+      if ((threadIdx.x & 63) == 0 && wm == wm && wm > -INFINITY) mg_atomic_nanmax(out + 1, wm);
+    }
+    ++trip;
   }
   double m1 = -INFINITY;
   if (any) {
@@ -803,15 +822,17 @@ int launch_max(const void* d_tiles, int64_t tiles_per_group, int n_groups, int64
       fabs(dark) < 16777216.0 && (double)(float)dark == dark) {
     constexpr int N = VecOf<T>::N;
     if (d_scratch && scratch_floats >= tile_elems / N && (reinterpret_cast<uintptr_t>(d_scratch) & 3) == 0) {
-      const int64_t cvec = tile_elems / N;
-      hipLaunchKernelGGL((k_flat_rcmax<N>), dim3((unsigned)std::min<int64_t>((cvec + 255) / 256, 2048)), dim3(256), 0, s,
-                         (const float*)d_flat, cvec, d_scratch);
-      MG_CHECK_LAUNCH();
+      const int64_t cvec = tile_elems / N;  // (d_scratch: the bound of this flat image, mg_flatfield_bound)
       // one resident round of workgroups in all (74 VGPRs: 6 per CU), however many groups share them: every workgroup
       // ends with two compare-and-swap maxima on its group's cache line
       const int per = (int)std::max<int64_t>(1, std::min<int64_t>((cvec + 255) / 256, std::max(1, 1536 / n_groups)));
-      hipLaunchKernelGGL((k_flatfield_max_lean<T>), dim3(per, n_groups), dim3(256), 0, s, (const T*)d_tiles, tiles_per_group,
-                         tile_elems, dark, (const float*)d_flat, d_scratch, d_max2);
+      const int64_t chunks_per_lane = (cvec + (int64_t)per * 256 - 1) / ((int64_t)per * 256) * tiles_per_group;
+      if (chunks_per_lane < 512)
+        hipLaunchKernelGGL((k_flatfield_max_lean<T, true>), dim3(per, n_groups), dim3(256), 0, s, (const T*)d_tiles,
+                           tiles_per_group, tile_elems, dark, (const float*)d_flat, d_scratch, d_max2);
+      else
+        hipLaunchKernelGGL((k_flatfield_max_lean<T, false>), dim3(per, n_groups), dim3(256), 0, s, (const T*)d_tiles,
+                           tiles_per_group, tile_elems, dark, (const float*)d_flat, d_scratch, d_max2);
       MG_CHECK_LAUNCH();
       return MG_OK;
     }
@@ -897,6 +918,26 @@ extern "C" int64_t mg_flatfield_max_scratch_floats(int dtype, int ty, int tx) {
   if (ty <= 0 || tx <= 0) return -1;
   const int n = dtype == MG_U8 ? 16 : dtype == MG_U16 ? 8 : 0;  // (only the integer fast path uses the scratch)
   return n ? ((int64_t)ty * tx + n - 1) / n : 0;
+}
+
+extern "C" int mg_flatfield_bound(const void* d_flat, int flat_dtype, int dtype, int ty, int tx, float* d_scratch,
+                                  int64_t scratch_floats, void* stream) {
+  if (!d_flat || !d_scratch || ty <= 0 || tx <= 0 || flat_dtype != MG_F32) return MG_EINVAL;
+  const int64_t need = mg_flatfield_max_scratch_floats(dtype, ty, tx);
+  const int64_t tile_elems = (int64_t)ty * tx;
+  const int n = dtype == MG_U8 ? 16 : dtype == MG_U16 ? 8 : 0;
+  if (need <= 0 || scratch_floats < need || tile_elems % n || (reinterpret_cast<uintptr_t>(d_flat) & 15) ||
+      (reinterpret_cast<uintptr_t>(d_scratch) & 3))
+    return MG_EINVAL;
+  hipStream_t s = mg_stream(stream);
+  const int64_t cvec = tile_elems / n;
+  const dim3 grid((unsigned)std::min<int64_t>((cvec + 255) / 256, 2048));
+  if (n == 16)
+    hipLaunchKernelGGL((k_flat_rcmax<16>), grid, dim3(256), 0, s, (const float*)d_flat, cvec, d_scratch);
+  else
+    hipLaunchKernelGGL((k_flat_rcmax<8>), grid, dim3(256), 0, s, (const float*)d_flat, cvec, d_scratch);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
 }
 
 extern "C" int mg_flatfield_max(const void* d_tiles, int dtype, int64_t n_tiles, int n_groups, int ty, int tx,

@@ -500,7 +500,7 @@ extern "C" int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angl
                                       const uint64_t* d_pair_table, float min_roundness, int write_skipped,
                                       float* d_scores, int32_t* d_alive, int32_t* d_num_alive, int32_t* d_max_rc,
                                       int32_t* d_num_scored, int32_t* d_surv_list, int64_t surv_cap, int32_t* d_num_surv,
-                                      void* stream) {
+                                      int counters_clear, void* stream) {
   if ((!d_blur && !d_angle) || !d_edge_bits || !d_class_bits || !d_circles || !d_unique_keys || !d_layer_starts ||
       !d_per_rc || !d_per_expected || !d_per_starts || !d_pair_table || !d_scores || !d_alive || !d_num_alive ||
       !d_max_rc || !d_surv_list || !d_num_surv)
@@ -515,7 +515,8 @@ extern "C" int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angl
   if ((int64_t)ntr * ntc >= 32768) return MG_EINVAL;  // the 32-bit key
   if ((size_t)per_total * 12 > 48 * 1024 || NSUB * (nr + 1) > NP) return MG_EINVAL;
   hipStream_t s = mg_stream(stream);
-  if (mg_zero_async(d_num_surv, (size_t)std::max(n_planes, 1) * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
+  if (!counters_clear && mg_zero_async(d_num_surv, (size_t)std::max(n_planes, 1) * sizeof(int32_t), s) != hipSuccess)
+    return MG_ELAUNCH;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
   const size_t lds_bytes = (size_t)WBASE + (size_t)(STY + 2 * max_r) * WSTR;
   const int nsr = (ntr + SUBY - 1) / SUBY, nsc = (ntc + SUBX - 1) / SUBX, n_st = nsr * nsc;

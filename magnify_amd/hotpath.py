@@ -152,12 +152,27 @@ def flatfield_max(tiles: torch.Tensor, flatfield=1.0, darkfield=0.0, n_groups=1)
     max2 = torch.full((n_groups, 2), -math.inf, dtype=torch.float64, device=tiles.device)
     n_tiles = tiles.numel() // (ty * tx)
     code = nat.dtype_code(tiles.dtype)
-    words = int(nat.lib().mg_flatfield_max_scratch_floats(code, ty, tx)) if flt is not None else 0
-    # (one block per stream: the sub-batch threads of a multi-stream StackProcessor fill it side by side)
-    scratch = pooled(f"flatfield_max_scratch@{_stream()}", words, (), torch.float32, tiles.device) if words > 0 else None
+    f32_image = flt is not None and flt.dtype == torch.float32 and dkt is None and (ty * tx) % (16 // tiles.element_size()) == 0
+    words = int(nat.lib().mg_flatfield_max_scratch_floats(code, ty, tx)) if f32_image else 0
+    scratch = None
+    if words > 0:
+        # the per-chunk bound of the flat image (mg_flatfield_bound), computed when the image changes, not per call:
+        # a caller's device tensor is recognised by identity + version counter (the entry holds a reference to it);
+        # anything converted or uploaded on the way in (NumPy, float64, host tensors) is bounded afresh.
+        # (one block per stream: the sub-batch threads of a multi-stream StackProcessor fill it side by side)
+        name = f"flatfield_max_scratch@{_stream()}"
+        scratch = pooled(name, words, (), torch.float32, tiles.device)
+        same = flt is flatfield
+        key = (id(flatfield), flatfield._version, flt.data_ptr(), scratch.data_ptr(), code, ty, tx) if same else None
+        if key is None or _BOUND_OF.get(name, (None, None))[0] != key:
+            _call("mg_flatfield_bound", flt.data_ptr(), flc, code, ty, tx, scratch.data_ptr(), words, _stream())
+            _BOUND_OF[name] = (key, flatfield if same else None)
     _call("mg_flatfield_max", tiles.data_ptr(), code, n_tiles, n_groups, ty, tx, dk, _ptr(dkt),
                                          dkc, fl, _ptr(flt), flc, max2.data_ptr(), _ptr(scratch), words, _stream())
     return max2
+
+
+_BOUND_OF = {}  # scratch block -> (key of the flat image it bounds, the image)
 
 
 def flatfield_stitch(tiles: torch.Tensor, overlap: int, flatfield=1.0, darkfield=0.0, apply_flatfield=True,
@@ -195,8 +210,7 @@ def flatfield_stitch(tiles: torch.Tensor, overlap: int, flatfield=1.0, darkfield
         else:
             minmax = minmax_out
             assert minmax.is_contiguous() and minmax.numel() == c * t * 2 and minmax.dtype == torch.float64
-        minmax.view(-1, 2)[:, 0] = math.inf
-        minmax.view(-1, 2)[:, 1] = -math.inf
+        minmax.view(-1, 2).copy_(_minmax_init(c * t, tiles.device))  # (+inf, -inf) rows: one copy, not two fills
     _call("mg_flatfield_apply_stitch", tiles.data_ptr(), nat.dtype_code(tiles.dtype), c * t, nr, nc, ty, tx,
                                                   overlap, int(bool(apply_flatfield)), (c * t) // n_groups, dk, _ptr(dkt), dkc, fl,
                                                   _ptr(flt), flc, _ptr(max2), image.data_ptr(), _ptr(minmax),
@@ -204,14 +218,27 @@ def flatfield_stitch(tiles: torch.Tensor, overlap: int, flatfield=1.0, darkfield
     return image, minmax
 
 
+_MINMAX_INIT = {}
+
+
+def _minmax_init(n, device):
+    """(n, 2) float64 rows (+inf, -inf) on the device: what the min / max atomics start from."""
+    key = (int(n), str(device))
+    t = _MINMAX_INIT.get(key)
+    if t is None:
+        if len(_MINMAX_INIT) > 16:
+            _MINMAX_INIT.clear()
+        t = torch.tensor([math.inf, -math.inf], dtype=torch.float64, device=device).repeat(int(n), 1)
+        _MINMAX_INIT[key] = t
+    return t
+
+
 def plane_minmax(planes: torch.Tensor) -> torch.Tensor:
     """Per-plane (min, max) of a (P, H, W) view with uniform plane stride."""
     require_gpu()
     p, h, w = planes.shape
     assert planes.stride(2) == 1 or w <= 1
-    out = torch.empty((p, 2), dtype=torch.float64, device=planes.device)
-    out[:, 0] = math.inf
-    out[:, 1] = -math.inf
+    out = _minmax_init(p, planes.device).clone()
     _call("mg_plane_minmax", planes.data_ptr(), nat.dtype_code(planes.dtype), p, planes.stride(0), h, w,
                                         planes.stride(1), out.data_ptr(), _stream())
     return out
@@ -588,7 +615,7 @@ class CircleFinder:
             _call("mg_keys_to_circles", self.keys.data_ptr(), self.num_iter, self.cell_starts.data_ptr(),
                   self.cell_counts.data_ptr(), self.num_edges.data_ptr(), P, h, w, self.grid, self.min_r, self.max_r,
                   self.unique_keys.data_ptr(), self.cap, self.tile_ranges.data_ptr(), self.num_circles.data_ptr(),
-                  _ptr(self.layer_starts), s, stage="mg_bitmap_to_circles")
+                  _ptr(self.layer_starts), int(counters_clear), s, stage="mg_bitmap_to_circles")
             self._tie_keys = self.unique_keys
         else:
             if self.bitmap is None:
@@ -612,7 +639,7 @@ class CircleFinder:
                   self.per_starts.data_ptr(), int(self.per_rc.shape[0]), self.pair_table.data_ptr(), float(min_roundness),
                   int(self.keep_debug_maps), self.scores.data_ptr(), self.alive.data_ptr(), self.num_alive.data_ptr(),
                   self.max_rc.data_ptr(), self.num_scored.data_ptr(), self.surv_list.data_ptr(), self.cap,
-                  self.num_surv.data_ptr(), s, stage="mg_score_circles")
+                  self.num_surv.data_ptr(), 1, s, stage="mg_score_circles")  # (num_surv: cleared above or by the caller)
             return
         if self.angle is None:  # a path switch after the edge stage (tests flip `keyed`): the map is needed after all
             self.angle = torch.empty((P, h, w), dtype=torch.float32, device=self.dev)
@@ -641,12 +668,14 @@ class CircleFinder:
                                               torch.empty((P, 3 * cap), dtype=torch.int32, device=self.dev))
         return self._out_sets[self._out_turn]
 
-    def _collect(self, bufs, min_dist):
+    def _collect(self, bufs, min_dist, cleared=False):
+        """``cleared``: the status block (num_out) has been cleared since the last gather (the optimistic chain)."""
         self._n_collects += 1
         out, out_scores, scratch = bufs
         _call("mg_collect_circles", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
               self.num_alive.data_ptr(), self.state.data_ptr(), int(min_dist <= 0), self.P, out.data_ptr(),
-              out_scores.data_ptr(), out.shape[1], self.num_out.data_ptr(), scratch.data_ptr(), _ptr(self._tie_keys), _stream())
+              out_scores.data_ptr(), out.shape[1], self.num_out.data_ptr(), scratch.data_ptr(), _ptr(self._tie_keys),
+              int(cleared), _stream())
         # what fetch_results' side stream waits for: the tables, not whatever the caller queues behind them
         if not torch.cuda.is_current_stream_capturing():  # (a graph replay records its own, _optimistic_chain)
             self._results_ready = torch.cuda.Event()
@@ -663,20 +692,21 @@ class CircleFinder:
             self._nms_ring = torch.from_numpy(nat.circle_points(min_dist, True)).to(self.dev)
             self._nms_dist = min_dist
 
-    def _nms_rounds(self, min_dist, first, count, out_cap):
-        """Suppression rounds; round k of this group counts what it left undecided in self.undecided[k].  ``first``:
-        the same-centre pass (only the first circle of a centre enters the rounds: exact, three tiny launches)."""
+    def _nms_rounds(self, min_dist, first, count, out_cap, cleared=False):
+        """Suppression rounds; round k of this group counts what it left undecided in self.undecided[k] (``cleared``:
+        the status block they are rows of has just been cleared).  ``first``: the same-centre pass (only the first
+        circle of a centre enters the rounds: exact, three tiny launches)."""
         P, s, ring = self.P, _stream(), self._nms_ring
         if first:
             _call("mg_nms_same_centre", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
                   self.num_alive.data_ptr(), self.max_rc.data_ptr(), P, min_dist, self.nms_grid.data_ptr(),
-                  self.nms_grid.shape[1], self.state.data_ptr(), _ptr(self._tie_keys), out_cap, s, stage="mg_nms_round")
-        for g in range(count):
-            _call("mg_nms_round", self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
+                  self.nms_grid.shape[1], self.state.data_ptr(), _ptr(self._tie_keys), out_cap, s, stage="mg_nms_rounds")
+        if count > 0:
+            _call("mg_nms_rounds", self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
                   self.alive.data_ptr(), self.num_alive.data_ptr(), self.max_rc.data_ptr(), P,
                   min_dist, ring.data_ptr(), ring.shape[0], self.nms_grid.data_ptr(),
-                  self.nms_grid.shape[1], self.state.data_ptr(), self.undecided[g].data_ptr(),
-                  _ptr(self._tie_keys), out_cap, s)
+                  self.nms_grid.shape[1], self.state.data_ptr(), self.undecided.data_ptr(), self.undecided.stride(0),
+                  int(count), int(cleared), _ptr(self._tie_keys), out_cap, s, stage="mg_nms_rounds")
 
     def _nms_cleanup(self, min_dist, out_cap):
         _call("mg_nms_cleanup", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
@@ -684,7 +714,7 @@ class CircleFinder:
               self._nms_ring.shape[0], self.nms_grid.data_ptr(), self.nms_grid.shape[1], self.state.data_ptr(),
               out_cap, _stream())
 
-    def nms_stage(self, min_dist: int, optimistic=False, bufs=None):
+    def nms_stage(self, min_dist: int, optimistic=False, bufs=None, cleared=False):
         """Checked chain: the alive counts come to the host first (they size the output), the rounds are checked for
         convergence afterwards.  ``optimistic``: output capacity and rounds from the calls before; the caller's (find's)
         single status fetch follows -- returns (buffers, rounds launched) and leaves the checks to ``_nms_finish``."""
@@ -696,8 +726,8 @@ class CircleFinder:
                 self._nms_prepare(min_dist)
                 # (a missing round is cheap to add -- unless a follow-up pass has been queued on the tables: _round_spare)
                 rounds = min(self._hint(self._recent_rounds, 2, spare=self._round_spare), self.MAX_GROUP)
-                self._nms_rounds(min_dist, True, rounds, bufs[0].shape[1])
-            self._collect(bufs, min_dist)
+                self._nms_rounds(min_dist, True, rounds, bufs[0].shape[1], cleared=cleared)
+            self._collect(bufs, min_dist, cleared=cleared)
             return bufs, rounds
         n_alive = self._fetch_status()[3]
         bufs = self._out_buffers(max(1, int(n_alive.max())))
@@ -744,7 +774,7 @@ class CircleFinder:
         self.status.zero_()
         self.edge_stage(planes, minmax, low_q, high_q, keep_u8=keep_u8, passthrough_u8=passthrough_u8, optimistic=True)
         self.circle_stage(seeds, min_roundness, keep_raw=keep_raw, dedup_centres=min_dist > 0, counters_clear=True)
-        return self.nms_stage(min_dist, optimistic=True, bufs=bufs)
+        return self.nms_stage(min_dist, optimistic=True, bufs=bufs, cleared=True)  # (status.zero_() above)
 
     def _optimistic_chain(self, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw, keep_u8,
                           passthrough_u8, stable_input=False):
@@ -765,12 +795,16 @@ class CircleFinder:
                   and not (keep_raw or keep_u8 or self.keep_debug_maps)
                   and not self.need_angle_map() and planes.stride(2) == 1)
         if not usable:
+            if minmax is not None:
+                minmax = minmax.contiguous()
             return self._launch_chain(planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw, keep_u8,
                                       passthrough_u8)
         if minmax is None and not passthrough_u8:
             minmax = plane_minmax(planes)
         if minmax is not None:
-            self._mm.copy_(minmax.reshape(self.P, 2))  # (stream-ordered: the values are read by the launch behind it)
+            # (stream-ordered: the values are read by the launch behind it; a strided view -- one channel's rows of a
+            # (T, C, 2) block -- is gathered by this one copy)
+            self._mm.copy_(minmax.reshape(self.P, 2))
             minmax = self._mm
         if not stable_input and planes.numel() * planes.element_size() <= (32 << 20):
             if self._in_stage is None or self._in_stage.dtype != planes.dtype:
@@ -928,6 +962,8 @@ class CircleFinder:
                 opt = False
         self.calls["optimistic" if opt else "checked"] += 1
         if not opt:
+            if minmax is not None:
+                minmax = minmax.contiguous()
             n_edges = self.edge_stage(planes, minmax, low_q, high_q, keep_u8=keep_u8, passthrough_u8=passthrough_u8)
             # with suppression to follow, passing circles that share a centre are reduced to their first
             self.circle_stage(seeds, min_roundness, keep_raw=keep_raw, dedup_centres=min_dist > 0)
@@ -982,6 +1018,7 @@ def pooled(name, count, tail, dtype, device):
 
 def release_pool():
     _POOL.clear()
+    _BOUND_OF.clear()  # (the bounds lived in pool blocks)
 
 
 

@@ -207,7 +207,7 @@ class StackProcessor:
         roi_pass = lambda d_out, d_num, cap: hp.roi_gather_reduce(  # noqa: E731
             self.image.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi, reuse_buffers=True, disks=True,
             device_tables=(d_out, None, self.max_r), device_counts=(d_num, cap, self._roi_bound), pool_tag=self.pool_tag)
-        counts, (d_beads, d_scores, _) = self.finder.find(self.image[:, ch], self.minmax[:, ch].contiguous(), self.low_q,
+        counts, (d_beads, d_scores, _) = self.finder.find(self.image[:, ch], self.minmax[:, ch], self.low_q,
                                                            self.high_q, self.min_roundness, self.min_r, seeds,
                                                            host_results=False, follow=roi_pass, stable_input=True)
         out = hp.finish_roi(self.finder.follow_result, counts)

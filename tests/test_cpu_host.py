@@ -26,6 +26,12 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert nat.lib().mg_version() >= 1
+    # the ctypes prototypes take as many arguments as the header declares (one short sends a pointer as an int)
+    plain = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    for m in re.finditer(r"\b(?:int|int64_t)\s+(mg_\w+)\s*\(([^;]*?)\)\s*;", plain, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if args in ("", "void") else len(args.split(","))
+        assert len(nat.PROTOTYPES[name]) == n, (name, n, len(nat.PROTOTYPES[name]))
 
 
 def test_product_fails_loudly_without_gpu():

@@ -830,3 +830,41 @@ def test_stream_probe_moves_the_bytes(hp):
         nat.check(nat.lib().mg_stream_probe(src.data_ptr(), dst.data_ptr(), n, 3, sink.data_ptr(), 8, s), "probe")
     with pytest.raises(ValueError):
         nat.check(nat.lib().mg_stream_probe(src.data_ptr(), dst.data_ptr(), n, 0, sink.data_ptr(), -1, s), "probe")
+
+
+def test_flatfield_bound_follows_the_flat_image(hp):
+    """The per-chunk bound of the flat image (mg_flatfield_bound) is kept between calls for a caller's float32 device
+    tensor and made again when the tensor changes (in place: its version counter; another tensor; a NumPy image): the
+    maxima equal the oracle's every time.  Small and large groups (the lanes' shared running maximum)."""
+    rng = np.random.default_rng(21)
+    tiles = rng.integers(90, 60000, size=(3, 4, 1, 1, 256, 512), dtype=np.uint16)
+    d_tiles = dev(tiles)
+    flat = vignette((256, 512)).astype(np.float32)
+    d_flat = dev(flat)
+
+    def want(flat_img, groups):
+        t = np.clip(tiles.astype(np.float64) - 100.0, 0, None).reshape(groups, -1, 256, 512)
+        return np.stack([t.max(axis=(1, 2, 3)), (t / flat_img.astype(np.float64)).max(axis=(1, 2, 3))], axis=1)
+
+    for groups in (3, 1, 12):
+        got = hp.flatfield_max(d_tiles, d_flat, 100.0, groups).cpu().numpy()
+        np.testing.assert_array_equal(got, want(flat, groups))
+    calls = []
+    orig = hp._call
+    hp._call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        hp.flatfield_max(d_tiles, d_flat, 100.0, 3)
+        assert calls == ["mg_flatfield_max"]  # the bound of this tensor is in place
+        d_flat.mul_(0.5)  # in place: same tensor, new content
+        got = hp.flatfield_max(d_tiles, d_flat, 100.0, 3).cpu().numpy()
+        assert calls[1:] == ["mg_flatfield_bound", "mg_flatfield_max"]
+        np.testing.assert_array_equal(got, want(flat * np.float32(0.5), 3))
+        other = dev(np.ascontiguousarray(flat[::-1]))
+        got = hp.flatfield_max(d_tiles, other, 100.0, 3).cpu().numpy()
+        np.testing.assert_array_equal(got, want(flat[::-1], 3))
+        del calls[:]
+        got = hp.flatfield_max(d_tiles, flat, 100.0, 3).cpu().numpy()  # a host image: uploaded and bounded afresh
+        assert calls == ["mg_flatfield_bound", "mg_flatfield_max"]
+        np.testing.assert_array_equal(got, want(flat, 3))
+    finally:
+        hp._call = orig
