@@ -415,6 +415,15 @@ int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int64_t assay_s
  * then be queued (with an upper bound for m) before the host has fetched the counts. */
 int mg_counts_to_offsets(const int32_t* d_counts, int n, int cap, int32_t* d_offsets, void* stream);
 
+/* The marker table a rank contributes to the final all-gather: row g of d_table[m][6 + 2 n_c] (float64)
+ * = [assay_offset + assay, row, col, r, fg_count, bg_count, fg_sum[n_c], bg_sum[n_c]] of marker g, from the bead
+ * tables (d_beads / bead_stride / d_assay_offsets as for mg_roi_segment_reduce: compact, or one padded row per assay)
+ * and the counts (m, 2) / sums (m, n_c, n_t, 2) of the ROI pass at time index t_index.  m: the rows d_table holds; rows
+ * beyond d_assay_offsets[n_assays] are left alone. */
+int mg_marker_table(const int32_t* d_beads, int64_t bead_stride, const int32_t* d_assay_offsets, int n_assays, int m,
+                    int assay_offset, const int32_t* d_counts, const double* d_sums, int n_c, int n_t, int t_index,
+                    double* d_table, void* stream);
+
 /* fg/bg segmentation + ROI gather + reductions WITHOUT a label map (find.py:561-602 with
  * utils.py:380-395 folded in): the masks come straight from the bead table.  A window pixel is
  * foreground iff it lies in the marker's own disk and in no other disk of its assay (labels == i),

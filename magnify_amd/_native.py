@@ -33,6 +33,7 @@ PROTOTYPES = {
     "mg_perimeter_table": [_i, _i, _p, _p, _p, _i],
     "mg_flatfield_max": [_p, _i, _l, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p, _l, _p],
     "mg_flatfield_max_scratch_floats": [_i, _i, _i],
+    "mg_marker_table": [_p, _l, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p, _p],
     "mg_flatfield_bound": [_p, _i, _i, _i, _i, _p, _l, _p],
     "mg_flatfield_is_identity": [_i, _d, _p, _d, _p],
     "mg_flatfield_apply_stitch": [_p, _i, _l, _i, _i, _i, _i, _i, _i, _i, _d, _p, _i, _d, _p, _i, _p, _p, _p, _p],

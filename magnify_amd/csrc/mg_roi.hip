@@ -648,6 +648,54 @@ extern "C" int mg_counts_to_offsets(const int32_t* d_counts, int n, int cap, int
   return MG_OK;
 }
 
+namespace {
+// One row per marker: [assay, row, col, r, fg_count, bg_count, fg_sum[C], bg_sum[C]] (float64: exact for these
+// integers) from the bead tables and the ROI pass's counts / sums where they are -- what a rank contributes to the
+// all-gather of the marker table (collective 3).
+__global__ __launch_bounds__(256) void k_marker_table(const int32_t* __restrict__ d_beads, int64_t bead_stride,
+                                                      const int32_t* __restrict__ d_assay_offsets, int n_assays,
+                                                      int assay_offset, const int32_t* __restrict__ d_counts,
+                                                      const double* __restrict__ d_sums, int n_c, int n_t, int t_index,
+                                                      double* __restrict__ d_table) {
+  const int total = d_assay_offsets[n_assays];
+  const int width = 6 + 2 * n_c;
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_assays;  // the assay whose offset range holds g (empty assays have empty ranges)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (d_assay_offsets[mid] <= g) lo = mid;
+      else hi = mid;
+    }
+    const int local = g - d_assay_offsets[lo];
+    const int32_t* b = bead_stride > 0 ? d_beads + ((int64_t)lo * bead_stride + local) * 3 : d_beads + (int64_t)g * 3;
+    double* row = d_table + (int64_t)g * width;
+    row[0] = (double)(assay_offset + lo);
+    row[1] = (double)b[0], row[2] = (double)b[1], row[3] = (double)b[2];
+    row[4] = (double)d_counts[2 * g], row[5] = (double)d_counts[2 * g + 1];
+    for (int c = 0; c < n_c; ++c) {
+      const double* sm = d_sums + (((int64_t)g * n_c + c) * n_t + t_index) * 2;
+      row[6 + c] = sm[0];
+      row[6 + n_c + c] = sm[1];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int mg_marker_table(const int32_t* d_beads, int64_t bead_stride, const int32_t* d_assay_offsets, int n_assays,
+                               int m, int assay_offset, const int32_t* d_counts, const double* d_sums, int n_c, int n_t,
+                               int t_index, double* d_table, void* stream) {
+  if (!d_assay_offsets || n_assays <= 0 || n_assays > 65535 || m < 0 || bead_stride < 0 || n_c <= 0 || n_t <= 0 ||
+      t_index < 0 || t_index >= n_t)
+    return MG_EINVAL;
+  if (m == 0) return MG_OK;
+  if (!d_beads || !d_counts || !d_sums || !d_table) return MG_EINVAL;
+  hipLaunchKernelGGL(k_marker_table, dim3((unsigned)std::min((m + 255) / 256, 2048)), dim3(256), 0, mg_stream(stream),
+                     d_beads, bead_stride, d_assay_offsets, n_assays, assay_offset, d_counts, d_sums, n_c, n_t, t_index,
+                     d_table);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
 extern "C" int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t,
                                             int h, int w, const int32_t* d_beads, const int32_t* d_marker_assay,
                                             const int32_t* d_marker_local, int m, int roi_len,

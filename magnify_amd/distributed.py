@@ -91,7 +91,15 @@ def gather_marker_table(table: torch.Tensor) -> torch.Tensor:
 
 def marker_table(out: dict, assay_offset: int, n_channels: int, device) -> torch.Tensor:
     """Pack a StackProcessor result into rows
-    [assay, row, col, r, fg_count, bg_count, fg_sum[C], bg_sum[C]] (float64; exact for these ints)."""
+    [assay, row, col, r, fg_count, bg_count, fg_sum[C], bg_sum[C]] (float64; exact for these ints): one kernel over the
+    device-resident bead tables, counts and sums (hotpath.marker_table)."""
+    if out.get("sums") is None or out.get("counts") is None:
+        raise ValueError("marker_table needs the reductions (want_sums) of the result")
+    if out["sums"].is_cuda:
+        from . import hotpath
+
+        return hotpath.marker_table(out, assay_offset, n_channels).to(device)
+    # results that live in host memory (the gloo rehearsal of the multi-rank path): plain tensor packing
     import numpy as np
 
     beads = out["beads"]

@@ -368,7 +368,7 @@ class CircleFinder:
         self._n_collects, self.follow_result = 0, None
         # hipGraphs of the optimistic chain (_optimistic_chain), by launch-sequence key
         self._graphs = None if os.environ.get("MG_NO_GRAPH") else {}
-        self._graph_bufs, self.graph_replays, self.graph_captures = None, 0, 0
+        self.graph_replays, self.graph_captures = 0, 0
         self._graph_seen, self._in_stage = set(), None
         self._round_spare = 0
         self._mm = torch.empty((P, 2), dtype=torch.float64, device=dev)
@@ -780,10 +780,10 @@ class CircleFinder:
                           passthrough_u8, stable_input=False):
         """The chain as ONE hipGraph launch: the ~40 kernel launches / clears of a call are a fixed sequence as long as
         the inputs sit at the same addresses and the hints (window passes, sweeps, rounds, list and output capacities)
-        have not moved -- all of that is the graph's key (up to 8 graphs are kept).  What changes from call to call
+        have not moved, for each of the two output sets used in turn -- all of that is the graph's key (up to 8 graphs are
+        kept).  What changes from call to call
         travels through fixed buffers: the per-plane min / max (copied into the finder's own block before the launch),
-        the seeds (the pinned block the captured upload reads), the ordered output (the graph's own set, copied to the
-        caller's) and, for small inputs (<= 32 MB: the chip's 784 chamber windows, gathered afresh every call), the
+        the seeds (the pinned block the captured upload reads) and, for small inputs (<= 32 MB: the chip's 784 chamber windows, gathered afresh every call), the
         planes themselves (copied into the finder's own input block).  A sequence is captured the first time it shows
         when the input is the finder's block or the caller vouches for its buffer (``stable_input``), else the second
         time (a capture costs ~9 ms: not to be spent on addresses that never come back).  A single plane from a caller
@@ -814,18 +814,14 @@ class CircleFinder:
         win = max(self._recent_win) if self._recent_win else 0
         sweeps = min(self._hint(self._recent_sweeps, 2), self.MAX_GROUP)
         rounds = min(self._hint(self._recent_rounds, 2, spare=self._round_spare), self.MAX_GROUP) if min_dist > 0 else 0
-        # the graph writes its ordered output into a set of its own (the public sets alternate from call to call --
-        # a graph per set would double the captures); two small copies hand it to the caller's set after the replay
-        if self._graph_bufs is None or self._graph_bufs[0].shape[1] != self._out_cap:
-            cap = self._out_cap
-            self._graph_bufs = (torch.empty((self.P, cap, 3), dtype=torch.int32, device=self.dev),
-                                torch.empty((self.P, cap), dtype=torch.float32, device=self.dev),
-                                torch.empty((self.P, 3 * cap), dtype=torch.int32, device=self.dev))
+        # the ordered output goes straight into the public set whose turn it is (two sets used in turn: a graph per
+        # set -- twice the captures, once; a set of the graph's own cost two copies per call)
+        bufs = self._out_buffers(self._out_cap)
         ready = ((self.nms_grid is not None or min_dist <= 0) and (self.hist_win is not None or win == 0)
                  and (min_dist <= 0 or getattr(self, "_nms_dist", None) == min_dist))  # nothing left to allocate / upload
         key = (planes.data_ptr(), planes.stride(0), planes.stride(1), planes.dtype, passthrough_u8, float(low_q), float(high_q),
                float(min_roundness), int(min_dist), win, sweeps, rounds, self.coords.data_ptr(), self.coords.shape[1],
-               self._graph_bufs[0].data_ptr(), self.nms_grid.data_ptr() if self.nms_grid is not None else 0)
+               bufs[0].data_ptr(), self.nms_grid.data_ptr() if self.nms_grid is not None else 0)
         entry = self._graphs.get(key)
         if entry is None and ready and self.graph_captures < self.MAX_CAPTURES:
             # (hints that drift -- one sweep more or less -- add a few graphs; a caller whose sequences never repeat stops
@@ -835,12 +831,13 @@ class CircleFinder:
                 self._graph_seen.clear()
             self._graph_seen.add(key)
             if seen:
-                entry = self._capture_chain(key, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, passthrough_u8)
+                entry = self._capture_chain(key, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, passthrough_u8,
+                                            bufs)
                 if self._graphs is None:
                     entry = None
         if entry is None:
             return self._launch_chain(planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, keep_raw, keep_u8,
-                                      passthrough_u8)
+                                      passthrough_u8, bufs=bufs)
         self.seeds_host.numpy()[:] = np.asarray(seeds, dtype=np.uint64).reshape(self.P).view(np.int64)
         entry["graph"].replay()
         # the host-side state the eager launches would have left behind
@@ -848,15 +845,12 @@ class CircleFinder:
             setattr(self, name, value)
         self.stats.update(entry["stats"])
         self._n_collects += 1
-        bufs = self._out_buffers(self._out_cap)
-        bufs[0].copy_(self._graph_bufs[0])
-        bufs[1].copy_(self._graph_bufs[1])
         self._results_ready = torch.cuda.Event()
         self._results_ready.record()
         self.graph_replays += 1
         return bufs, entry["rounds"]
 
-    def _capture_chain(self, key, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, passthrough_u8):
+    def _capture_chain(self, key, planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, passthrough_u8, bufs):
         """Stream capture of _launch_chain (on a side stream; nothing runs); None if the capture fails -- the graphs
         of this finder are then off for good and the caller launches eagerly."""
         global _CAPTURING
@@ -873,7 +867,7 @@ class CircleFinder:
             # (thread-local: what other host threads do on their streams meanwhile does not concern this capture)
             with torch.cuda.graph(graph, stream=self._cap_stream, capture_error_mode="thread_local"):
                 _, rounds = self._launch_chain(planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, False, False,
-                                               passthrough_u8, bufs=self._graph_bufs)
+                                               passthrough_u8, bufs=bufs)
             main.wait_stream(self._cap_stream)
         except Exception as exc:  # noqa: BLE001  (whatever the runtime refuses: fall back in-process)
             self._graphs = None
@@ -1148,10 +1142,12 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         max_r = max(int(max_r), 2)
         tab = _halfwidth_table(max_r, dev)
         if device_counts is not None:
-            d_off = pooled("roi_offsets", a + 1, (), torch.int32, dev)
+            d_off = pooled("roi_offsets" + pool_tag, a + 1, (), torch.int32, dev)
             _call("mg_counts_to_offsets", d_counts.data_ptr(), a, min(int(cap), d_tab.shape[1]), d_off.data_ptr(), _stream())
         else:
             d_off = _upload_i32(offsets, dev)
+        # where the markers' rows and offsets are on the device (marker_table reads them there)
+        res["device_tables"] = (d_tab, int(d_tab.shape[1]), d_off)
         _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
               int(time_major), d_tab.data_ptr(), d_tab.shape[1], d_off.data_ptr(), a, m, L, tab.data_ptr(), max_r,
               _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
@@ -1195,6 +1191,33 @@ def finish_roi(res, counts):
     out = {k: (v[:m] if isinstance(v, torch.Tensor) else v) for k, v in res.items()}
     out["offsets"] = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     return out
+
+
+def marker_table(out: dict, assay_offset: int, n_channels: int) -> torch.Tensor:
+    """Rows [assay, row, col, r, fg_count, bg_count, fg_sum[C], bg_sum[C]] (float64: exact for these integers) of a
+    ``roi_gather_reduce`` / ``StackProcessor`` result, assembled on the device by one kernel (mg_marker_table) from the
+    bead tables where they are; a result that only has host bead lists uploads them first."""
+    require_gpu()
+    offsets = out.get("offsets")
+    if offsets is None:
+        offsets = np.concatenate([[0], np.cumsum([len(b) for b in out["beads"]])])
+    offsets = np.asarray(offsets, dtype=np.int64)
+    m, a = int(offsets[-1]), len(offsets) - 1
+    sums, counts = out["sums"], out["counts"]
+    dev = sums.device
+    tab = torch.empty((m, 6 + 2 * n_channels), dtype=torch.float64, device=dev)
+    if m == 0:
+        return tab
+    assert sums.shape[1] == n_channels and sums.is_contiguous() and counts.is_contiguous()
+    tables = out.get("device_tables")
+    if tables is not None:
+        d_beads, stride, d_off = tables
+    else:
+        beads = [np.asarray(b, dtype=np.int32).reshape(-1, 3) for b in out["beads"]]
+        d_beads, stride, d_off = _upload_i32(np.concatenate(beads).reshape(-1), dev), 0, _upload_i32(offsets, dev)
+    _call("mg_marker_table", d_beads.data_ptr(), stride, d_off.data_ptr(), a, m, int(assay_offset), counts.data_ptr(),
+          sums.data_ptr(), n_channels, int(sums.shape[2]), 0, tab.data_ptr(), _stream())
+    return tab
 
 
 def masked_median_u16(roi: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:

@@ -136,3 +136,33 @@ def test_bench_starts_its_own_ranks():
     one = _bench("--gpus", "1", "--timepoints", "2")
     assert one["n_gpus"] == 1 and one["strong"] is None and one["ranks"]["world_size"] == 1
     assert one["roofline"]["frac"] is not None and "cpu_baseline" in one
+
+
+@pytest.mark.gpu
+def test_marker_table_kernel_equals_tensor_packing():
+    """mg_marker_table (one kernel over the device-resident bead tables, counts and sums) against the plain tensor
+    packing of the same result: a StackProcessor result (padded bead rows + device offsets, an assay without beads in
+    the middle), a result with host bead lists only, and an empty one."""
+    import numpy as np
+    import torch
+
+    from magnify_amd import distributed as mgd
+    from magnify_amd import hotpath as hp
+    from magnify_amd.stack import StackProcessor, synthetic_stack
+
+    hp.require_gpu()
+    stack = synthetic_stack(3, 2, 256, 320, seed=11, beads_per_mpx=400.0)[0]
+    stack[1] = 100  # a timepoint without beads
+    proc = StackProcessor(3, 2, 256, 320, num_iter=40000, search_channels=(0,), mode="P")
+    for call in range(2):  # the checked call and an optimistic one (ROI pass queued before the counts are known)
+        out = proc(stack, 0.9, 100.0, seed=4)
+        assert len(out["beads"][1]) == 0 and len(out["beads"][0]) > 0
+        got = mgd.marker_table(out, 7, 2, torch.device("cuda"))
+        host = {"beads": out["beads"], "counts": out["counts"].cpu(), "sums": out["sums"].cpu()}
+        want = mgd.marker_table(host, 7, 2, torch.device("cpu"))
+        assert got.is_cuda and torch.equal(got.cpu(), want)
+        only_lists = {"beads": out["beads"], "counts": out["counts"], "sums": out["sums"]}
+        assert torch.equal(mgd.marker_table(only_lists, 7, 2, torch.device("cuda")).cpu(), want)
+    empty = {"beads": [np.empty((0, 3), np.int32)], "counts": torch.empty((0, 2), dtype=torch.int32, device="cuda"),
+             "sums": torch.empty((0, 2, 1, 2), dtype=torch.float64, device="cuda")}
+    assert mgd.marker_table(empty, 0, 2, torch.device("cuda")).shape == (0, 10)

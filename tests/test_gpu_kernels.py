@@ -734,7 +734,7 @@ def test_graph_replay_equals_eager_launches(hp):
             np.testing.assert_array_equal(followed[-1][0][p, :k].cpu().numpy(), got[p][0])
         np.testing.assert_array_equal(cf.n_edges_host, ref.n_edges_host)
     assert "graph_error" not in cf.stats, cf.stats.get("graph_error")
-    assert cf.graph_replays >= 8 and 2 <= cf.graph_captures <= 6, (cf.graph_replays, cf.graph_captures, cf.calls)
+    assert cf.graph_replays >= 6 and 2 <= cf.graph_captures <= 10, (cf.graph_replays, cf.graph_captures, cf.calls)
     assert ref.graph_replays == 0
     # a caller that hands in a fresh tensor every call (the chip's gathered chamber windows): small inputs are copied
     # into the finder's own block, the graph is keyed on that; a single plane is always launched eagerly
