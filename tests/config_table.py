@@ -26,7 +26,8 @@ from magnify_amd.stack import synthetic_stack  # noqa: E402
 
 
 def timed(fn, repeat):
-    out = fn()  # warm-up: workspaces, tables
+    for _ in range(3):  # warm-up: workspaces, tables, the launch-sequence graphs of both output sets
+        out = fn()
     torch.cuda.synchronize()
     best = float("inf")
     for _ in range(repeat):

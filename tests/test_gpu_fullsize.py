@@ -98,7 +98,7 @@ def test_full_size_assays_match_c_oracle(mg):
     proc(stack, torch.from_numpy(flat_np).cuda(), 100.0, seed=5)
     assert not proc.finder.stats["optimistic"]
     out = proc(stack, torch.from_numpy(flat_np).cuda(), 100.0, seed=9)
-    assert proc.finder.stats["optimistic"] and proc.finder.calls == {"optimistic": 1, "repaired": 0, "checked": 1}
+    assert proc.finder.stats["optimistic"] and proc.finder.calls == {"optimistic": 1, "repaired": 0, "checked": 1, "followed_again": 0}
     host = stack.cpu().numpy()
     off = out["offsets"]
     for t in range(T):
