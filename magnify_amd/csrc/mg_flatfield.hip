@@ -654,9 +654,75 @@ __global__ __launch_bounds__(256) void k_apply_stitch(const T* __restrict__ tile
   }
 }
 
+// A value that is the same in every lane, held in scalar registers (the compiler keeps uniform float64 values in
+// vector registers otherwise: 2 per value and lane).
+__device__ __forceinline__ double uniform_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// max(x - d, 0) of N integer pixels in the integer domain (d: an integer-valued scalar dark in [0, 65535]); uint16
+// pixels two at a time (v_pk_sub_u16 with clamp).
+typedef unsigned short mg_u16x2 __attribute__((ext_vector_type(2)));
+template <typename T, int N>
+__device__ __forceinline__ void sub_dark_int(const T (&x)[N], uint32_t d, uint32_t (&ti)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const uint32_t xi = (uint32_t)x[j];
+    ti[j] = xi > d ? xi - d : 0u;
+  }
+}
+template <>
+__device__ __forceinline__ void sub_dark_int<uint16_t, 8>(const uint16_t (&x)[8], uint32_t d, uint32_t (&ti)[8]) {
+  uint32_t w[4];
+  __builtin_memcpy(w, x, 16);
+  const mg_u16x2 dd = {(unsigned short)d, (unsigned short)d};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const mg_u16x2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(mg_u16x2, w[q]), dd);
+    ti[2 * q] = r.x;
+    ti[2 * q + 1] = r.y;
+  }
+}
+
+// The fast products of a chunk against per-position factors rk = rcp(flat) * (M1 / M2) (made once per position and
+// group, not per pixel): v = t * rk agrees with the reference's three roundings to ~1e-15 relative; the integer part
+// is the conversion's own truncation (v >= 0), the distance to the next integer comes from v_fract_f64.  Returns
+// whether any pixel sits within 1e-6 of an integer (t == 0 gives exactly 0 either way and does not count).
+template <typename T, int N>
+__device__ __forceinline__ bool fast_chunk_int(const uint32_t (&ti)[N], const double (&rk)[N], T (&o)[N]) {
+  bool unsure = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double v = (double)ti[j] * rk[j];
+    const double fr = __builtin_amdgcn_fract(v);
+    o[j] = (T)(unsigned int)v;
+    unsure |= !(fr > 1e-6 && fr < 1.0 - 1e-6) && ti[j] != 0u;
+  }
+  return unsure;
+}
+template <typename T, int N>
+__device__ __forceinline__ bool fast_chunk_f64(const double (&t)[N], const double (&rk)[N], T (&o)[N]) {
+  bool unsure = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double v = t[j] * rk[j];
+    const double fr = __builtin_amdgcn_fract(v);
+    o[j] = (T)(unsigned int)v;
+    unsure |= !(fr > 1e-6 && fr < 1.0 - 1e-6) && t[j] != 0.0;
+  }
+  return unsure;
+}
+
 // Lean variant for the aligned case (hx % N == 0 and aligned bases: every N-pixel chunk lies
 // inside one tile and all accesses are 16-byte vectors); integer pixel types only.
-template <typename T, bool APPLY>
+// Arithmetic of the correction, per pixel: the conversion, ONE float64 product with the position's factor, fract,
+// the truncating conversion and three compares (12 vector instructions a pixel where the per-pixel form -- subtract,
+// clip, two products, floor, subtract, five compares, the group's M1 / M2 divided anew in every row -- took 24:
+// the pass was co-limited by the VALU, 2.55 ms of vector issue in 3.9 ms).  INT_DARK: an integer-valued scalar dark,
+// subtracted in the integer domain (two uint16 pixels per instruction).
+template <typename T, bool APPLY, bool INT_DARK>
 __global__ __launch_bounds__(256) void k_apply_stitch_aligned(const T* __restrict__ tiles, int n_planes, int n_tr,
                                                                int n_tc, int ty, int tx, int clip, int hy, int hx,
                                                                int planes_per_group, double dark,
@@ -667,16 +733,48 @@ __global__ __launch_bounds__(256) void k_apply_stitch_aligned(const T* __restric
                                                                int rows_per_block) {
   constexpr int N = VecOf<T>::N;
   constexpr int PB = PLANES_PER_BLOCK;
-  const int plane0 = blockIdx.z * PB;
+  // Which part of the grid this workgroup is: the plane groups (z) of one (x, y) part read the same rows of the flat /
+  // dark images -- 64 MB of float32 per plane group at 4096^2, 2 GB of the pass's 19 GB at 64 assays when the parts
+  // are worked through plane group by plane group (the hardware's order: x, y, then z).  Workgroups are dealt to the
+  // eight XCDs in turn, each XCD has its own L2: XCD k takes the (x, y) parts k, k + 8, ... and runs all plane groups
+  // of a part one after the other, so the flat rows of a part are fetched once and then found in that XCD's L2.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (APPLY && gridDim.z >= 16 && ((gridDim.x * gridDim.y) & 7) == 0) {  // (4 plane groups: 0.50 -> 0.55 ms; 32: 3.76 -> 3.47)
+    const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const uint32_t xcd = lin & 7, slot = lin >> 3;
+    bz = slot % gridDim.z;
+    const uint32_t xy = (slot / gridDim.z) * 8 + xcd;
+    bx = xy % gridDim.x;
+    by = xy / gridDim.x;
+  }
+  const int plane0 = bz * PB;
   const int np = min(PB, n_planes - plane0);
   const int h_out = n_tr * hy, w_out = n_tc * hx;
-  const int ox0 = (blockIdx.x * blockDim.x + threadIdx.x) * N;
+  const int ox0 = (bx * blockDim.x + threadIdx.x) * N;
   uint32_t imin[PB], imax[PB];
 #pragma unroll
   for (int b = 0; b < PB; ++b) imin[b] = 0xFFFFFFFFu, imax[b] = 0u;
   const int64_t tile_elems = (int64_t)ty * tx, plane_elems = (int64_t)n_tr * n_tc * tile_elems;
+  // per plane, once per workgroup (scalar registers): the quotient of the group's maxima and whether the fast path
+  // holds for them (the maxima themselves are read again by the rare exact path: 16 more scalar registers spilled)
+  double kka[PB];
+  uint32_t ok_mask = 0;
+#pragma unroll
+  for (int b = 0; b < PB; ++b) {
+    kka[b] = 1.0;
+    if (APPLY && b < np) {
+      const int group = (plane0 + b) / planes_per_group;
+      const double m1 = d_max2[2 * group], m2 = d_max2[2 * group + 1];
+      const double kk = m1 / m2;
+      kka[b] = uniform_f64(kk);
+      const bool ok = kk > 0.0 && kk < 1e30 && m1 > 0.0 && m1 < 1e300 && m2 > 0.0 && m2 < 1e300;
+      ok_mask |= ok ? (1u << b) : 0u;
+    }
+  }
+  ok_mask = __builtin_amdgcn_readfirstlane(ok_mask);
+  const uint32_t dark_i = INT_DARK ? (uint32_t)dark : 0u;
   if (ox0 < w_out)
-  for (int yg = blockIdx.y; yg * rows_per_block < h_out; yg += gridDim.y) {  // (as in k_apply_stitch)
+  for (int yg = by; yg * rows_per_block < h_out; yg += gridDim.y) {  // (as in k_apply_stitch)
     const int row_end = min((yg + 1) * rows_per_block, h_out);
     const int tc0 = ox0 / hx;
     const int x0 = ox0 - tc0 * hx + clip;
@@ -685,28 +783,66 @@ __global__ __launch_bounds__(256) void k_apply_stitch_aligned(const T* __restric
       const int64_t p0 = (int64_t)(oy - tr * hy + clip) * tx + x0;
       const int64_t src0 = ((int64_t)tr * n_tc + tc0) * tile_elems + p0;
       double dk[N], fl[N], rr[N];
+      bool flat_bad = false;  // a flat value outside the range the reciprocal path is valid in
       if (APPLY) {
-        load_field<N>(d_dark, dark_dt, p0, dark, dk);
+        if (!INT_DARK) load_field<N>(d_dark, dark_dt, p0, dark, dk);
         load_field<N>(d_flat, flat_dt, p0, flat, fl);
 #pragma unroll
-        for (int j = 0; j < N; ++j) rr[j] = refined_rcp(fl[j]);
+        for (int j = 0; j < N; ++j) {
+          rr[j] = refined_rcp(fl[j]);
+          flat_bad |= rr[j] == 0.0;
+        }
       }
       // all planes' loads are issued before the first pixel is corrected (more bytes in flight per lane)
       T xin[PB][N];
 #pragma unroll
       for (int b = 0; b < PB; ++b)
         if (b < np) load_vec16<T, N>(tiles + (int64_t)(plane0 + b) * plane_elems + src0, xin[b], false);
+      double rk[N];
+      double kk_of_rk = -1.0;  // the quotient rk was made with (planes of one group follow each other)
+      bool rk_large = true;
 #pragma unroll
       for (int b = 0; b < PB; ++b) {
         if (b >= np) break;
         T o[N];
         T(&x)[N] = xin[b];
         if (APPLY) {
-          const int group = (plane0 + b) / planes_per_group;
-          const double m1 = d_max2[2 * group], m2 = d_max2[2 * group + 1];
-          const double kk = m1 / m2;
-          const bool ok = kk > 0.0 && kk < 1e30 && m1 > 0.0 && m1 < 1e300 && m2 > 0.0 && m2 < 1e300;
-          correct_chunk<T, N>(x, dk, fl, rr, m1, m2, kk, ok, o);
+          if (kka[b] != kk_of_rk) {  // (uniform: a new group)
+            kk_of_rk = kka[b];
+            rk_large = false;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+              rk[j] = rr[j] * kk_of_rk;
+              rk_large |= !(rk[j] < 61035.0);  // t <= 65535: v = t rk stays below 4e9 (the unsigned conversion)
+            }
+          }
+          const bool rk_bad = rk_large || flat_bad || !((ok_mask >> b) & 1u);
+          bool unsure;
+          uint32_t ti[N];
+          double t[N];
+          if (INT_DARK) {
+            sub_dark_int<T, N>(x, dark_i, ti);
+            unsure = fast_chunk_int<T, N>(ti, rk, o);
+          } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+              t[j] = (double)x[j] - dk[j];
+              t[j] = t[j] < 0.0 ? 0.0 : t[j];
+            }
+            unsure = fast_chunk_f64<T, N>(t, rk, o);
+          }
+          if (unsure || rk_bad) {  // a few chunks in a million: the reference's own operations
+            const int group = (plane0 + b) / planes_per_group;
+            const double m1 = d_max2[2 * group], m2 = d_max2[2 * group + 1];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+              const double tj = INT_DARK ? (double)ti[j] : t[j];
+              double e = tj / fl[j];
+              e = e * m1;
+              e = e / m2;
+              o[j] = cast_trunc<T>(e);
+            }
+          }
         } else {
 #pragma unroll
           for (int j = 0; j < N; ++j) o[j] = x[j];
@@ -873,14 +1009,19 @@ int launch_apply(const void* d_tiles, int64_t n_planes, int n_tr, int n_tc, int 
                        (!d_flat || (reinterpret_cast<uintptr_t>(d_flat) & 15) == 0) &&
                        (!d_dark || (reinterpret_cast<uintptr_t>(d_dark) & 15) == 0);
   if (aligned) {
-    if (apply)
-      hipLaunchKernelGGL((k_apply_stitch_aligned<T, true>), grid, dim3(256), 0, s, (const T*)d_tiles, (int)n_planes, n_tr,
-                         n_tc, ty, tx, clip, hy, hx, planes_per_group, dark, d_dark, dark_dt, flat, d_flat, flat_dt,
-                         d_max2, (T*)d_image, d_minmax, rows);
+    // an integer-valued scalar dark inside the pixel range: subtracted in the integer domain
+    const bool int_dark = apply && !d_dark && dark >= 0.0 && dark <= 65535.0 && dark == (double)(uint32_t)dark;
+#define MG_ALIGNED(AP, ID) \
+    hipLaunchKernelGGL((k_apply_stitch_aligned<T, AP, ID>), grid, dim3(256), 0, s, (const T*)d_tiles, (int)n_planes, n_tr, \
+                       n_tc, ty, tx, clip, hy, hx, planes_per_group, dark, d_dark, dark_dt, flat, d_flat, flat_dt, \
+                       d_max2, (T*)d_image, d_minmax, rows)
+    if (!apply)
+      MG_ALIGNED(false, false);
+    else if (int_dark)
+      MG_ALIGNED(true, true);
     else
-      hipLaunchKernelGGL((k_apply_stitch_aligned<T, false>), grid, dim3(256), 0, s, (const T*)d_tiles, (int)n_planes, n_tr,
-                         n_tc, ty, tx, clip, hy, hx, planes_per_group, dark, d_dark, dark_dt, flat, d_flat, flat_dt,
-                         d_max2, (T*)d_image, d_minmax, rows);
+      MG_ALIGNED(true, false);
+#undef MG_ALIGNED
     MG_CHECK_LAUNCH();
     return MG_OK;
   }
