@@ -718,9 +718,10 @@ __device__ __forceinline__ bool fast_chunk_f64(const double (&t)[N], const doubl
 // Lean variant for the aligned case (hx % N == 0 and aligned bases: every N-pixel chunk lies
 // inside one tile and all accesses are 16-byte vectors); integer pixel types only.
 // Arithmetic of the correction, per pixel: the conversion, ONE float64 product with the position's factor, fract,
-// the truncating conversion and three compares (12 vector instructions a pixel where the per-pixel form -- subtract,
-// clip, two products, floor, subtract, five compares, the group's M1 / M2 divided anew in every row -- took 24:
-// the pass was co-limited by the VALU, 2.55 ms of vector issue in 3.9 ms).  INT_DARK: an integer-valued scalar dark,
+// the truncating conversion and three compares (15 vector instructions a pixel, measured, where the per-pixel form --
+// subtract, clip, two products, floor, subtract, five compares, the group's M1 / M2 divided anew in every row -- took
+// 24: 2.55 -> 1.65 ms of vector issue at 64 assays; what it bought is at small batches, 0.55 -> 0.50 ms at 8 assays --
+// at 64 the pass waits for memory, see the workgroup order below).  INT_DARK: an integer-valued scalar dark,
 // subtracted in the integer domain (two uint16 pixels per instruction).
 template <typename T, bool APPLY, bool INT_DARK>
 __global__ __launch_bounds__(256) void k_apply_stitch_aligned(const T* __restrict__ tiles, int n_planes, int n_tr,
