@@ -895,7 +895,33 @@ __global__ __launch_bounds__(256) void k_plane_minmax(const T* __restrict__ src,
   double vmin = INFINITY, vmax = -INFINITY;
   const int vec_per_row = (w + N - 1) / N;
   const int64_t total = (int64_t)h * vec_per_row;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (IsIntegral<T>::value && w % N == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (row_stride * (int64_t)sizeof(T)) % 16 == 0) {
+    // integer pixels, rows of whole 16-byte vectors: integer min / max, four loads in flight per lane (one 4096^2
+    // uint16 plane: 28 -> ~10 us; the float64 compares of the general loop kept the lanes busy, one load at a time)
+    uint32_t imin = 0xFFFFFFFFu, imax = 0u;
+    for (; i < total; i += 4 * stride) {
+      T x[4][N];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t iq = min(i + q * stride, total - 1);  // (a clamped repeat does not change a min / max)
+        const int r = (int)(iq / vec_per_row);
+        const int c0 = (int)(iq - (int64_t)r * vec_per_row) * N;
+        load_vec16<T, N>(base + (int64_t)r * row_stride + c0, x[q], false);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          imin = min(imin, (uint32_t)x[q][j]);
+          imax = max(imax, (uint32_t)x[q][j]);
+        }
+    }
+    if (imin <= imax) vmin = (double)imin, vmax = (double)imax;
+    i = total;
+  }
+  for (; i < total; i += stride) {
     const int r = (int)(i / vec_per_row);
     const int c0 = (int)(i - (int64_t)r * vec_per_row) * N;
     const T* p = base + (int64_t)r * row_stride + c0;

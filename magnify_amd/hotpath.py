@@ -787,7 +787,8 @@ class CircleFinder:
         planes themselves (copied into the finder's own input block).  A sequence is captured the first time it shows
         when the input is the finder's block or the caller vouches for its buffer (``stable_input``), else the second
         time (a capture costs ~9 ms: not to be spent on addresses that never come back).  A single plane from a caller
-        that does not vouch for its buffer is launched eagerly (measured through mg.beads: C2 1.09 ms eager, 1.17 replayed;
+        that does not vouch for its buffer is launched eagerly (measured through mg.beads: C2 1.06 ms eager, 1.07 replayed,
+        C3 3.83 / 3.90;
         a one-timepoint StackProcessor shard, which does: 1.31 eager, 1.17 replayed).  Per-stage timing (a
         StageTimer without allow_graphs), debug maps and the raw / uint8 side outputs need the eager launches.
         MG_NO_GRAPH=1 turns the graphs off."""

@@ -44,9 +44,9 @@ def restore_format(xp):
             if "__time__" in v.dims:
                 v = v.rename({"__time__": "time"})
         # remove dimensions that standardize_format added
-        for dim in STANDARD_DIMS:
-            if dim not in original and dim in v.dims:
-                v = v.squeeze(dim)
+        added = [dim for dim in STANDARD_DIMS if dim not in original and dim in v.dims]
+        if added:
+            v = v.squeeze(added)
         # restore the original relative order of the original dimensions
         orig = [d for d in original if d in v.dims]
         if orig:

@@ -189,13 +189,30 @@ class DataArray:
         return self._replace(data, dims, dict(self.coords))
 
     def squeeze(self, dim=None):
-        dims = [d for d in self.dims if self.sizes[d] == 1] if dim is None else ([dim] if isinstance(dim, str) else list(dim))
-        out = self
+        """Drop dimensions of size 1 (all of them, one, or the listed ones): one reshape of the data and of the coords
+        that carry such a dimension (they stay as lower-dimensional / scalar coords, as after ``isel({d: 0})``)."""
+        sizes = self.sizes
+        dims = [d for d in self.dims if sizes[d] == 1] if dim is None else ([dim] if isinstance(dim, str) else list(dim))
         for d in dims:
-            if out.sizes[d] != 1:
-                raise ValueError(f"cannot squeeze dimension {d} of size {out.sizes[d]}")
-            out = out.isel({d: 0})
-        return out
+            if sizes[d] != 1:
+                raise ValueError(f"cannot squeeze dimension {d} of size {sizes[d]}")
+        if not dims:
+            return self
+        gone = set(dims)
+        keep = tuple(d for d in self.dims if d not in gone)
+        data = self.data
+        data = data.reshape(tuple(sizes[d] for d in keep))
+        coords = {}
+        for name, c in self.coords.items():
+            if all(cd in sizes for cd in c.dims):
+                if gone.isdisjoint(c.dims):
+                    coords[name] = DataArray(c.raw, c.dims, None, c.name, c.attrs)
+                else:
+                    cdims = tuple(cd for cd in c.dims if cd not in gone)
+                    cdata = c.data
+                    coords[name] = DataArray(cdata.reshape(tuple(s for cd, s in zip(c.dims, c.shape) if cd not in gone)), cdims,
+                                             None, c.name, c.attrs)
+        return DataArray(data, keep, coords, self.name, self.attrs)
 
     def isel(self, indexers=None, **kw):
         indexers = dict(indexers or {}, **kw)

@@ -868,3 +868,19 @@ def test_flatfield_bound_follows_the_flat_image(hp):
         np.testing.assert_array_equal(got, want(flat, 3))
     finally:
         hp._call = orig
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint8, np.float32])
+def test_plane_minmax_paths(hp, dtype):
+    """mg_plane_minmax: the integer fast path (rows of whole 16-byte vectors, four loads in flight, clamped repeats at
+    the end), the general path (ragged rows) and planes taken as a strided view of a (T, C, h, w) block."""
+    rng = np.random.default_rng(31)
+    for shape in ((3, 64, 128), (2, 37, 48), (1, 5, 16), (2, 33, 50), (1, 1, 8)):
+        a = (rng.random((shape[0], 2) + shape[1:]) * 250).astype(dtype)
+        a[0, 1, shape[1] // 2, shape[2] // 3] = 251  # a unique maximum
+        a[-1, 1, 0, shape[2] - 1] = 0
+        d = dev(a)
+        for ch in (0, 1):
+            got = hp.plane_minmax(d[:, ch]).cpu().numpy()
+            np.testing.assert_array_equal(got[:, 0], a[:, ch].min(axis=(1, 2)).astype(np.float64))
+            np.testing.assert_array_equal(got[:, 1], a[:, ch].max(axis=(1, 2)).astype(np.float64))

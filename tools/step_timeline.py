@@ -1,6 +1,7 @@
 """One steady-state step of bench.py as the GPU ran it, from a rocprofv3 --kernel-trace CSV: every kernel in order with
 its duration and the idle time before it, and the totals per kernel name.
-usage: python tools/step_timeline.py <dir with *kernel_trace.csv> [step index from the end = 5]"""
+usage: python tools/step_timeline.py <dir with *kernel_trace.csv> [step index from the end = 5] [first kernel of a step]
+(default first kernel: the flat-field maxima pass; e.g. k_plane_minmax for a call of mg.beads without flat-field)"""
 import collections
 import csv
 import glob
@@ -23,7 +24,8 @@ def main():
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if "k_flatfield_max" in r[2] or "k_flat_rcmax" in r[2]]
+    first = sys.argv[3] if len(sys.argv) > 3 else None
+    starts = [i for i, r in enumerate(rows) if (first in r[2] if first else ("k_flatfield_max" in r[2] or "k_flat_rcmax" in r[2]))]
     starts = [i for k, i in enumerate(starts) if k == 0 or i - starts[k - 1] > 3]  # (rcmax + lean: one step start)
     if len(starts) < back + 2:
         print("too few steps in the trace")
