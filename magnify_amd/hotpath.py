@@ -315,7 +315,10 @@ class CircleFinder:
     """
 
     MAX_GROUP = 64  # most hysteresis sweeps / suppression rounds launched between two host checks
-    MAX_CAPTURES = 12  # hipGraph captures per finder (a capture costs ~9 ms: callers whose launch sequences never repeat stop)
+    # hipGraph captures per finder: 12 to start with, one more per 64 optimistic calls after that (a capture costs ~9 ms:
+    # a caller whose launch sequences never repeat pays at most ~0.15 ms a call for trying; one whose hints drift over a
+    # long run keeps getting graphs)
+    MAX_CAPTURES = 12
 
     def __init__(self, n_planes, h, w, min_radius, max_radius, num_iter, device="cuda", grid_length=GRID_LENGTH):
         require_gpu()
@@ -780,7 +783,7 @@ class CircleFinder:
                           passthrough_u8, stable_input=False):
         """The chain as ONE hipGraph launch: the ~40 kernel launches / clears of a call are a fixed sequence as long as
         the inputs sit at the same addresses and the hints (window passes, sweeps, rounds, list and output capacities)
-        have not moved, for each of the two output sets used in turn -- all of that is the graph's key (up to 8 graphs are
+        have not moved, for each of the two output sets used in turn -- all of that is the graph's key (up to 16 graphs are
         kept).  What changes from call to call
         travels through fixed buffers: the per-plane min / max (copied into the finder's own block before the launch),
         the seeds (the pinned block the captured upload reads) and, for small inputs (<= 32 MB: the chip's 784 chamber windows, gathered afresh every call), the
@@ -824,7 +827,7 @@ class CircleFinder:
                float(min_roundness), int(min_dist), win, sweeps, rounds, self.coords.data_ptr(), self.coords.shape[1],
                bufs[0].data_ptr(), self.nms_grid.data_ptr() if self.nms_grid is not None else 0)
         entry = self._graphs.get(key)
-        if entry is None and ready and self.graph_captures < self.MAX_CAPTURES:
+        if entry is None and ready and self.graph_captures < self.MAX_CAPTURES + self.calls["optimistic"] // 64:
             # (hints that drift -- one sweep more or less -- add a few graphs; a caller whose sequences never repeat stops
             # capturing after MAX_CAPTURES)
             seen = stable_input or key in self._graph_seen
@@ -855,8 +858,9 @@ class CircleFinder:
         """Stream capture of _launch_chain (on a side stream; nothing runs); None if the capture fails -- the graphs
         of this finder are then off for good and the caller launches eagerly."""
         global _CAPTURING
-        if len(self._graphs) >= 8:
-            self._graphs.clear()
+        if len(self._graphs) >= 16:  # the oldest half goes (insertion order)
+            for old_key in list(self._graphs)[:8]:
+                del self._graphs[old_key]
         self.graph_captures += 1
         main = torch.cuda.current_stream()
         if getattr(self, "_cap_stream", None) is None:
