@@ -851,3 +851,29 @@ def test_sink_assay_dataset_roundtrip(tmp_path):
     assert list(back.channel.values) == ["a", "b", "c"] and int(back.time.values[0]) == 1700000000
     empty = _Sink.assay_dataset(np.empty((0, 3), np.int32), {k: v[:0] for k, v in arrays.items()})
     assert empty.roi.shape == (0, c, 1, L, L) and empty.x.shape == (0, 1)
+
+
+def test_squeeze_of_several_dimensions_equals_one_at_a_time():
+    """DataArray.squeeze (one reshape for all listed dimensions, restore_format's use) against dropping the dimensions
+    one at a time with isel: data, dims and the coords that lose a dimension (they stay as lower-dimensional coords)."""
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 100, (1, 3, 1, 4, 1))
+    coords = {"b": mg_dataarray(np.array([10, 20, 30]), ("b",), "b"),
+              "a": mg_dataarray(np.array([7]), ("a",), "a"),
+              "ab": mg_dataarray(rng.random((1, 3)), ("a", "b"), "ab"),
+              "ce": mg_dataarray(np.array([[5.5]]), ("c", "e"), "ce")}
+    v = mg.DataArray(data, ("a", "b", "c", "d", "e"), coords, "v", {"k": 1})
+    for dims in (["a"], ["a", "c"], ["e", "a", "c"], None):
+        got = v.squeeze(dims)
+        want = v
+        for d in (dims if dims is not None else ["a", "c", "e"]):
+            want = want.isel({d: 0})
+        assert got.dims == want.dims and got.name == "v" and got.attrs == {"k": 1}
+        np.testing.assert_array_equal(got.values, want.values)
+        assert set(got.coords) == set(want.coords)
+        for k in got.coords:
+            assert got.coords[k].dims == want.coords[k].dims, k
+            np.testing.assert_array_equal(got.coords[k].values, want.coords[k].values)
+    with pytest.raises(ValueError):
+        v.squeeze("b")
+    assert v.squeeze([]) is v
