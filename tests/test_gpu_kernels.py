@@ -884,3 +884,24 @@ def test_plane_minmax_paths(hp, dtype):
             got = hp.plane_minmax(d[:, ch]).cpu().numpy()
             np.testing.assert_array_equal(got[:, 0], a[:, ch].min(axis=(1, 2)).astype(np.float64))
             np.testing.assert_array_equal(got[:, 1], a[:, ch].max(axis=(1, 2)).astype(np.float64))
+
+
+@pytest.mark.parametrize("dark", [100.0, 99.5])
+def test_flatfield_many_plane_groups(hp, dark):
+    """The correction pass with >= 16 plane groups of 8 (the XCD-aware workgroup order: the plane groups of one image part
+    run back to back on one XCD) and per-assay maxima, integer-valued and fractional dark (integer-domain / float64
+    subtraction), against the oracle: 32 assays x 4 channels, 2 x 2 tiles with overlap."""
+    rng = np.random.default_rng(17)
+    n_t, n_c, ty, tx = 32, 4, 40, 1032
+    tiles = rng.integers(60, 60000, size=(n_t, n_c, 2, 2, ty, tx), dtype=np.uint16)
+    tiles[3] = 100  # an assay at the dark level: maxima 0
+    flat = vignette((ty, tx))
+    for overlap in (0, 8, 16):  # aligned kernel (remapped grid), general kernel, aligned with cropping
+        img, minmax = hp.flatfield_stitch(dev(tiles), overlap, flat, dark, n_groups=n_t)
+        got = img.cpu().numpy()
+        for t in range(n_t):
+            want = rp.stitch(rp.flatfield_correct(tiles[t][None], flat, dark), overlap)[0]
+            np.testing.assert_array_equal(got[t], want, err_msg=f"assay {t} overlap {overlap}")
+            mm = minmax.cpu().numpy().reshape(n_t, n_c, 2)[t]
+            np.testing.assert_array_equal(mm[:, 0], want.min(axis=(-1, -2)))
+            np.testing.assert_array_equal(mm[:, 1], want.max(axis=(-1, -2)))
