@@ -1143,20 +1143,36 @@ __global__ __launch_bounds__(NT) void k_cell_fill_rows(const uint32_t* __restric
     }
     pos = d_starts[(int64_t)plane * n_cells + cell];
   }
+  // The wave's cells are consecutive, so are their runs in the list: ONE contiguous run per wave, starting at the
+  // first cell's start.  A lane puts its row's coordinates at their places in an LDS copy of that run (wave-wide
+  // exclusive scan of the row counts), then the wave stores the run with whole 512-byte instructions (before: every
+  // lane stored its own few entries one after the other -- ~10 partly filled store instructions per wave).
+  constexpr int CH = 512;  // entries staged per trip (a wave of 17 % edge density has ~200; all pixels edges: 1200)
+  __shared__ int2 s_stage[NT / 64][CH];
+  int2* stage = s_stage[threadIdx.x >> 6];
   const int cnt = __popcll(rowbits);
-  int incl = cnt;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(incl, off);
-    if (r >= off) incl += t;  // lane - off belongs to the same cell
-  }
-  pos += incl - cnt;
+  const int incl = mg_wave_scan_incl_i32(cnt);
+  const int total = __shfl(incl, 63);
+  const int lpos = incl - cnt;
+  const int64_t base = __shfl(pos, 0);  // (lane 0: cell wave * cpw, row 0 -- the start of the wave's first cell)
+  const bool any_cell = wave * cpw < n_cells;
   int2* out = reinterpret_cast<int2*>(d_coords + (int64_t)plane * coord_cap * 2);
-  while (rowbits) {
-    const int b = __ffsll((unsigned long long)rowbits) - 1;
-    rowbits &= rowbits - 1;
-    if (pos < coord_cap) out[pos] = make_int2(y, x0 + b);
-    ++pos;
+  for (int c0 = 0; c0 < total; c0 += CH) {  // wave-uniform
+    uint64_t rb = rowbits;
+    int li = lpos - c0;
+    while (rb) {
+      const int b = __ffsll((unsigned long long)rb) - 1;
+      rb &= rb - 1;
+      if (li >= 0 && li < CH) stage[li] = make_int2(y, x0 + b);
+      ++li;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (LDS operations of a wave complete in order)
+    const int n = min(total - c0, CH);
+    for (int i = lane; i < n; i += 64) {
+      const int64_t p = base + c0 + i;
+      if (any_cell && p < coord_cap) out[p] = stage[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
 }
 
