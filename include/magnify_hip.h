@@ -31,6 +31,7 @@ extern "C" {
 #define MG_OK 0
 #define MG_EINVAL (-1)
 #define MG_ELAUNCH (-2)
+#define MG_EIO (-3) /* mg_host_read_runs only */
 
 /* element types of image/tile buffers */
 #define MG_U8 0
@@ -444,9 +445,16 @@ int mg_roi_segment_reduce(const void* d_image, int dtype, int64_t assay_stride, 
                           int n_assays, int m, int roi_len, const int32_t* d_halfwidths, int max_r, void* d_roi,
                           uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream);
 
-/* Masked median (numpy nanmedian semantics: mean of the two middle values) of an already
- * gathered roi (m, C, T, L, L) under mask (m, L, L): d_median double[m][C][T], NaN if the
- * mask is empty.  u16 only (radix select on the 16-bit value). */
+/* Masked median of an already gathered roi (m, C, T, L, L) of element type `dtype` (MG_U8 / U16 / F32 / F64):
+ * roi.where(mask).median(dim=[roi_x, roi_y]) of identify.py:76-80 and filter.py:20-22, 74, 82 with numpy's nanmedian
+ * semantics -- the mean of the two middle values (in float64), pixels outside the mask and NaN pixels ignored, NaN when
+ * nothing is left.  The mask of marker g at timepoint t is the L x L bytes at d_mask + g * mask_stride_m +
+ * t * mask_stride_t (elements; mask_stride_t = 0: one mask for all timepoints, as find_beads replicates its geometry,
+ * find.py:585-586; chips searched at several timesteps have a mask per timepoint, find.py:119-140).
+ * d_median double[m][C][T].  Exact: radix select on the order-preserving bit pattern of the values. */
+int mg_roi_masked_median(const void* d_roi, int dtype, const uint8_t* d_mask, int64_t mask_stride_m,
+                         int64_t mask_stride_t, int m, int n_c, int n_t, int roi_len, double* d_median, void* stream);
+/* The same for uint16 rois under one mask (m, L, L) for all timepoints. */
 int mg_roi_masked_median_u16(const uint16_t* d_roi, const uint8_t* d_mask, int m, int n_c, int n_t, int roi_len,
                              double* d_median, void* stream);
 
@@ -484,6 +492,19 @@ int mg_masked_sums(const void* d_roi, int dtype, const uint8_t* d_fg, const uint
  * words XOR to one particular value -- it keeps the loads alive), mode 2 only writes d_dst.  The caller times it
  * (HIP events). */
 int mg_stream_probe(const void* d_src, void* d_dst, int64_t n_bytes, int mode, uint32_t* d_sink, int blocks, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Host side of the streamed ingest (reader.py:265-292: the reference maps every TIFF
+ * page to its own dask block and tifffile reads it when the block is computed)
+ * ---------------------------------------------------------------------------------- */
+
+/* Positional reads of n byte runs -- run i = nbytes[i] bytes at offsets[i] of the open file fds[i], into dsts[i]
+ * (HOST pointers; page-locked blocks in the product, so the upload that follows is asynchronous) -- by n_threads
+ * threads (1 .. 64) that take runs by ticket.  No GPU work, no stream; the call returns when every run is in place.
+ * Returns MG_OK; MG_EINVAL for a bad argument; MG_EIO when a read failed or met the end of its file: failed[0] = the
+ * run's index, failed[1] = errno (0: end of file).  `failed` may be NULL. */
+int mg_host_read_runs(const int32_t* fds, const int64_t* offsets, const int64_t* nbytes, void* const* dsts, int n,
+                      int n_threads, int64_t* failed);
 
 #ifdef __cplusplus
 }

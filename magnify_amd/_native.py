@@ -70,11 +70,13 @@ PROTOTYPES = {
     "mg_roi_gather_reduce_batched": [_p, _i, _l, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mg_counts_to_offsets": [_p, _i, _i, _p, _p],
     "mg_roi_segment_reduce": [_p, _i, _l, _i, _i, _i, _i, _i, _p, _l, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p],
+    "mg_roi_masked_median": [_p, _i, _p, _l, _l, _i, _i, _i, _i, _p, _p],
     "mg_roi_masked_median_u16": [_p, _p, _i, _i, _i, _i, _p, _p],
     "mg_cluster1d_costs": [_p, _i, _i, _i, _d, _p, _d, _p, _p],
     "mg_button_masks": [_p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p],
     "mg_stream_probe": [_p, _p, _l, _i, _p, _i, _p],
     "mg_masked_sums": [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p],
+    "mg_host_read_runs": [_p, _p, _p, _p, _i, _i, _p],
 }
 
 RETURNS_INT64 = {"mg_scharr_hist_scratch_words", "mg_edge_grid_scan_words", "mg_flatfield_max_scratch_floats"}

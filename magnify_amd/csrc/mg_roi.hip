@@ -485,29 +485,66 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
   }
 }
 
-// ---- masked median (u16): two-level radix select in LDS --------------------------------------------
-__device__ int select_kth_u16(const uint16_t* __restrict__ v, const uint8_t* __restrict__ mask, int n, int k,
-                              uint32_t* hist) {
-  // returns the k-th smallest (0-based) masked value
+// ---- masked median: byte-wise radix select in LDS -------------------------------------------------
+// Keys are the order-preserving unsigned images of the values: an unsigned integer is its own key, an IEEE float has
+// its sign bit flipped (positive) or all bits inverted (negative).  A NaN pixel counts as masked out (nanmedian).
+template <typename T> struct median_key;
+template <> struct median_key<uint8_t> {
+  typedef uint32_t type; static constexpr int LEVELS = 1;
+  __device__ static bool key(uint8_t x, uint32_t* k) { *k = x; return true; }
+  __device__ static double value(uint32_t k) { return (double)k; }
+};
+template <> struct median_key<uint16_t> {
+  typedef uint32_t type; static constexpr int LEVELS = 2;
+  __device__ static bool key(uint16_t x, uint32_t* k) { *k = x; return true; }
+  __device__ static double value(uint32_t k) { return (double)k; }
+};
+template <> struct median_key<float> {
+  typedef uint32_t type; static constexpr int LEVELS = 4;
+  __device__ static bool key(float x, uint32_t* k) {
+    const uint32_t b = __float_as_uint(x);
+    *k = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return x == x;
+  }
+  __device__ static double value(uint32_t k) {
+    return (double)__uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+  }
+};
+template <> struct median_key<double> {
+  typedef uint64_t type; static constexpr int LEVELS = 8;
+  __device__ static bool key(double x, uint64_t* k) {
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    *k = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    return x == x;
+  }
+  __device__ static double value(uint64_t k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+  }
+};
+
+// the k-th smallest (0-based) key among the unmasked, non-NaN values: one 256-bin histogram per key byte, most
+// significant first, only the values that share the prefix found so far take part
+template <typename T>
+__device__ typename median_key<T>::type select_kth(const T* __restrict__ v, const uint8_t* __restrict__ mask, int n,
+                                                   int k, uint32_t* hist) {
+  typedef typename median_key<T>::type K;
+  constexpr int LV = median_key<T>::LEVELS;
   __shared__ int s_bin, s_rank;
-  int prefix_val = 0;
+  K prefix = 0;
   int rank = k;
-  for (int level = 0; level < 2; ++level) {
+  for (int level = 0; level < LV; ++level) {
+    const int shift = 8 * (LV - 1 - level);
     for (int i = threadIdx.x; i < 256; i += NT) hist[i] = 0;
     __syncthreads();
     for (int p = threadIdx.x; p < n; p += NT) {
-      if (!mask[p]) continue;
-      const int x = v[p];
-      if (level == 0) {
-        atomicAdd(&hist[x >> 8], 1u);
-      } else if ((x >> 8) == prefix_val) {
-        atomicAdd(&hist[x & 255], 1u);
-      }
+      K key;
+      if (!mask[p] || !median_key<T>::key(v[p], &key)) continue;
+      if (level == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       int acc = 0, b = 0;
-      for (; b < 256; ++b) {
+      for (; b < 255; ++b) {
         if (acc + (int)hist[b] > rank) break;
         acc += hist[b];
       }
@@ -515,24 +552,28 @@ __device__ int select_kth_u16(const uint16_t* __restrict__ v, const uint8_t* __r
       s_rank = rank - acc;
     }
     __syncthreads();
-    if (level == 0) prefix_val = s_bin;
-    else prefix_val = (prefix_val << 8) | s_bin;
+    prefix = (prefix << 8) | (K)s_bin;
     rank = s_rank;
     __syncthreads();
   }
-  return prefix_val;
+  return prefix;
 }
 
-__global__ __launch_bounds__(NT) void k_masked_median_u16(const uint16_t* __restrict__ d_roi,
-                                                          const uint8_t* __restrict__ d_mask, int n_ct, int n,
-                                                          double* __restrict__ d_median) {
+// one workgroup per (marker, channel-time): mask of marker g at time t = d_mask + g * mask_stride_m + t * mask_stride_t
+template <typename T>
+__global__ __launch_bounds__(NT) void k_masked_median(const T* __restrict__ d_roi, const uint8_t* __restrict__ d_mask,
+                                                      int64_t mask_stride_m, int64_t mask_stride_t, int n_t, int n_ct,
+                                                      int n, double* __restrict__ d_median) {
   __shared__ uint32_t hist[256];
   __shared__ int s_count;
   const int g = blockIdx.x, ct = blockIdx.y;
-  const uint16_t* v = d_roi + ((int64_t)g * n_ct + ct) * n;
-  const uint8_t* mask = d_mask + (int64_t)g * n;
+  const T* v = d_roi + ((int64_t)g * n_ct + ct) * n;
+  const uint8_t* mask = d_mask + (int64_t)g * mask_stride_m + (int64_t)(ct % n_t) * mask_stride_t;
   int c = 0;
-  for (int p = threadIdx.x; p < n; p += NT) c += mask[p] != 0;
+  for (int p = threadIdx.x; p < n; p += NT) {
+    typename median_key<T>::type key;
+    c += mask[p] != 0 && median_key<T>::key(v[p], &key);
+  }
   int total;
   mg_block_exscan(c, &total);
   if (threadIdx.x == 0) s_count = total;
@@ -543,10 +584,20 @@ __global__ __launch_bounds__(NT) void k_masked_median_u16(const uint16_t* __rest
     if (threadIdx.x == 0) *out = __longlong_as_double(0x7FF8000000000000ll);
     return;
   }
-  const int lo = select_kth_u16(v, mask, n, (cnt - 1) / 2, hist);
-  int hi = lo;
-  if ((cnt & 1) == 0) hi = select_kth_u16(v, mask, n, cnt / 2, hist);
-  if (threadIdx.x == 0) *out = ((double)lo + (double)hi) / 2.0;
+  const auto lo = select_kth<T>(v, mask, n, (cnt - 1) / 2, hist);
+  auto hi = lo;
+  if ((cnt & 1) == 0) hi = select_kth<T>(v, mask, n, cnt / 2, hist);
+  // numpy's nanmedian: the mean of the two middle values (here in float64: exact for every type but float64 itself)
+  if (threadIdx.x == 0) *out = (median_key<T>::value(lo) + median_key<T>::value(hi)) / 2.0;
+}
+
+template <typename T>
+int launch_median(const void* d_roi, const uint8_t* d_mask, int64_t sm, int64_t st, int m, int n_c, int n_t, int len,
+                  double* d_median, hipStream_t s) {
+  hipLaunchKernelGGL((k_masked_median<T>), dim3(m, n_c * n_t), dim3(NT), 0, s, (const T*)d_roi, d_mask, sm, st, n_t,
+                     n_c * n_t, len * len, d_median);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
 }
 
 template <typename T, typename ACC>
@@ -724,13 +775,23 @@ extern "C" int mg_roi_gather_reduce(const void* d_image, int dtype, int n_c, int
                                       d_labels, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
 }
 
+extern "C" int mg_roi_masked_median(const void* d_roi, int dtype, const uint8_t* d_mask, int64_t mask_stride_m,
+                                    int64_t mask_stride_t, int m, int n_c, int n_t, int roi_len, double* d_median,
+                                    void* stream) {
+  if (!d_roi || !d_mask || !d_median || m < 0 || n_c <= 0 || n_t <= 0 || roi_len <= 0) return MG_EINVAL;
+  if (mask_stride_m < 0 || mask_stride_t < 0 || (int64_t)n_c * n_t > 65535) return MG_EINVAL;
+  if (m == 0) return MG_OK;
+  hipStream_t s = mg_stream(stream);
+  switch (dtype) {
+    case MG_U8: return launch_median<uint8_t>(d_roi, d_mask, mask_stride_m, mask_stride_t, m, n_c, n_t, roi_len, d_median, s);
+    case MG_U16: return launch_median<uint16_t>(d_roi, d_mask, mask_stride_m, mask_stride_t, m, n_c, n_t, roi_len, d_median, s);
+    case MG_F32: return launch_median<float>(d_roi, d_mask, mask_stride_m, mask_stride_t, m, n_c, n_t, roi_len, d_median, s);
+    case MG_F64: return launch_median<double>(d_roi, d_mask, mask_stride_m, mask_stride_t, m, n_c, n_t, roi_len, d_median, s);
+  }
+  return MG_EINVAL;
+}
+
 extern "C" int mg_roi_masked_median_u16(const uint16_t* d_roi, const uint8_t* d_mask, int m, int n_c, int n_t,
                                         int roi_len, double* d_median, void* stream) {
-  if (!d_roi || !d_mask || !d_median || m < 0 || n_c <= 0 || n_t <= 0 || roi_len <= 0) return MG_EINVAL;
-  if (n_c * n_t > 65535) return MG_EINVAL;
-  if (m == 0) return MG_OK;
-  hipLaunchKernelGGL(k_masked_median_u16, dim3(m, n_c * n_t), dim3(NT), 0, mg_stream(stream), d_roi, d_mask,
-                     n_c * n_t, roi_len * roi_len, d_median);
-  MG_CHECK_LAUNCH();
-  return MG_OK;
+  return mg_roi_masked_median(d_roi, MG_U16, d_mask, (int64_t)roi_len * roi_len, 0, m, n_c, n_t, roi_len, d_median, stream);
 }

@@ -117,6 +117,48 @@ def marker_table(out: dict, assay_offset: int, n_channels: int, device) -> torch
     return tab
 
 
+def stream_series(pattern, chunk, flatfield=1.0, darkfield=0.0, seed=0, sink=None, rank=None, world=None,
+                  pinned=True, workers=None, prefetch=2, on_chunk=None, **stream_kwargs):
+    """Config C5 across GPUs (second partition): ONE time series behind ``pattern`` (tiled or not,
+    ``reader.iter_time_chunks``' grammar), every rank streams its own contiguous block of the time axis
+    (``shard_range``) through its GPU -- files -> page-locked ring -> upload -> stitch + flat-field + detection + ROI
+    reduction, ``stack.process_stream(first_timepoint=lo)`` -- and the run ends with the variable-length all-gather of
+    the marker table (the only exchange; ROI pixels stay with their rank, which persists them through ``sink``:
+    a ``SaveSink`` pattern's ``{index}`` is the GLOBAL timepoint, so the ranks together leave the files of the
+    single-process run).  The reference's unit of work is one TIFF page per dask block (reader.py:265-292) and one
+    assay per loop turn (pipeline.py:18-24): any worker may take any time range.
+
+    ``rank`` / ``world`` default to the process group's (1 rank without one).  ``workers``: reader threads of THIS rank
+    (default: the node's cores divided among its local ranks, at most 16).  ``on_chunk(out)`` sees every chunk's result
+    while its pooled buffers are valid.  Returns ``(table, (lo, hi))``: the marker table of the WHOLE series on every
+    rank -- rows [timepoint, row, col, r, fg_count, bg_count, fg_sum[C], bg_sum[C]] in time order -- and this rank's
+    time range."""
+    from . import reader
+    from .stack import process_stream
+
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    series = pattern if isinstance(pattern, reader.TimeSeries) else reader.TimeSeries(pattern)
+    lo, hi = shard_range(len(series), rank, world)
+    if workers is None:
+        local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        workers = max(2, min(16, (os.cpu_count() or 1) // local))
+    chunks = series.chunks(chunk, time_range=(lo, hi), pinned=pinned and torch.cuda.is_available(), workers=workers,
+                           ring=max(4, int(prefetch) + 2) if pinned and torch.cuda.is_available() else None)
+    n_c = len(series.channels)
+    device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    tables = []
+    for out in process_stream(chunks, flatfield, darkfield, seed=seed, sink=sink, prefetch=prefetch, first_timepoint=lo,
+                              **stream_kwargs):
+        tables.append(marker_table(out, out["first_timepoint"], n_c, device))
+        if on_chunk is not None:
+            on_chunk(out)
+    local_table = torch.cat(tables) if tables else torch.zeros((0, 6 + 2 * n_c), dtype=torch.float64, device=device)
+    return gather_marker_table(local_table), (lo, hi)
+
+
 def broadcast_beads(beads, src: int = 0, device="cpu"):
     """Broadcast a variable-length bead table (M, 3) int32 from rank ``src`` (collective 2:
     in single-assay mode the beads found at time 0 serve every time shard).  ``beads`` is ignored on the

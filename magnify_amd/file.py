@@ -106,13 +106,15 @@ def _take_block(ds: Dataset, dim, lo, hi, first):
 
 def save(file, xp, shard_bytes=None):
     """file.py:6-8.  ``shard_bytes``: write parts whose largest variable stays below it (default: parts only when
-    a variable exceeds NetCDF-3's 4 GiB, then 2 GiB each)."""
+    a variable exceeds NetCDF-3's 4 GiB, then 2 GiB each).  Everything is written under temporary names first and
+    renamed when complete; what an earlier save left under this name (the whole file, or parts -- possibly more of
+    them) is removed only AFTER the new data is in place: a crash or a full disk during the write leaves the old
+    data untouched."""
     ds = xp.unstack() if isinstance(xp, Dataset) else Dataset({xp.name or "data": xp})
     sizes = {k: _nbytes(v) for k, v in list(ds.data_vars.items()) + list(ds.coords.items())}
     biggest = max(sizes.values(), default=0)
-    _remove_stale(file)  # what an earlier save left under this name (the whole file, or parts -- possibly more of them)
     if shard_bytes is None and biggest <= _LIMIT:
-        return _write(file, ds)
+        return _commit(file, [(str(file), ds)])
     limit = int(shard_bytes or _SHARD)
     dim = next((d for d in ("mark", "mark_row", "time") if d in ds.sizes and ds.sizes[d] > 1), None)
     if dim is None:
@@ -128,32 +130,44 @@ def save(file, xp, shard_bytes=None):
         rows -= rows % max(policy)
     n = ds.sizes[dim]
     bounds = list(range(0, n, rows)) + [n]
-    for k, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
-        part = _take_block(ds, dim, lo, hi, k == 0)
-        part.attrs.update(mg_part=k, mg_parts=len(bounds) - 1, mg_split_dim=dim, mg_split_lo=lo)
-        _write(f"{file}.part{k:03d}", part)
+
+    def parts():
+        for k, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+            part = _take_block(ds, dim, lo, hi, k == 0)
+            part.attrs.update(mg_part=k, mg_parts=len(bounds) - 1, mg_split_dim=dim, mg_split_lo=lo)
+            yield f"{file}.part{k:03d}", part
+
+    _commit(file, parts())
 
 
-def _remove_stale(file):
+def _stale(file):
     import glob
     import os
 
-    for old in [str(file)] + glob.glob(glob.escape(str(file)) + ".part[0-9][0-9][0-9]"):
-        if os.path.isfile(old):
-            os.remove(old)
+    return [old for old in [str(file)] + glob.glob(glob.escape(str(file)) + ".part[0-9][0-9][0-9]") if os.path.isfile(old)]
 
 
-def _write(file, ds):
-    """One NetCDF-3 file, written under a temporary name and renamed: a crash leaves no half-written file behind."""
+def _commit(file, named):
+    """Write every (final name, dataset) of ``named`` under a temporary name (one at a time: a part comes to the host
+    when it is written), then rename them all, then remove what an earlier save left that was not replaced."""
     import os
+    import uuid
 
-    tmp = f"{file}.tmp{os.getpid()}"
+    tag = f".tmp{os.getpid()}-{uuid.uuid4().hex[:8]}"
+    written = []
     try:
-        _write_nc(tmp, ds)
-        os.replace(tmp, str(file))
+        for final, ds in named:
+            _write_nc(final + tag, ds)
+            written.append(final)
+        for final in written:
+            os.replace(final + tag, final)
+        for old in _stale(file):
+            if old not in written:
+                os.remove(old)
     finally:
-        if os.path.exists(tmp):
-            os.remove(tmp)
+        for final in written:
+            if os.path.exists(final + tag):
+                os.remove(final + tag)
 
 
 def _write_nc(file, ds):

@@ -1,7 +1,7 @@
 """Marker filters on the device reductions (reference src/magnify/filter.py).
 
 ``filter_expression`` (filter.py:11-37) and ``filter_leaky`` (filter.py:65-94) only need the masked
-medians of the first timestep, which ``mg_roi_masked_median_u16`` computes on the gathered ROIs; the
+medians of the first timestep, which ``mg_roi_masked_median`` computes on the gathered ROIs; the
 thresholding is the reference's own NumPy expression, evaluated on the (mark,) vectors on the host.
 ``filter_nonround`` (filter.py:40-62) measures contours with cv.findContours / cv.arcLength: restated here
 as Moore border tracing of every connected component of the small fg masks, on the host.
@@ -15,9 +15,10 @@ from .utils import to_list
 
 
 def _first_step_medians(assay):
-    """fg and bg median of every (mark, channel) at time 0 as float64 numpy arrays."""
-    fg = reduce.masked_median(assay, "fg").transpose("mark", "channel", "time").data[:, :, 0].cpu().numpy()
-    bg = reduce.masked_median(assay, "bg").transpose("mark", "channel", "time").data[:, :, 0].cpu().numpy()
+    """fg and bg median of every (mark, channel) at time 0 as float64 numpy arrays: ``assay.isel(time=0)`` first,
+    then the medians (filter.py:20-22, 69-75) -- the masks of time 0, whatever the later timepoints hold."""
+    fg = reduce.masked_median(assay, "fg", time=0).data[:, :, 0].cpu().numpy()
+    bg = reduce.masked_median(assay, "bg", time=0).data[:, :, 0].cpu().numpy()
     return fg, bg
 
 

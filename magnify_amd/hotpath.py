@@ -509,6 +509,7 @@ class CircleFinder:
             need_cap = max(1, int(n_edges.max()))
             if self.coords is None or self.coords.shape[1] < need_cap:
                 self.coords = torch.empty((P, int(need_cap * 1.25) + 1, 2), dtype=torch.int32, device=self.dev)
+                self._drop_graphs()
             self._edge_grid(2)
         self.coord_cap = self.coords.shape[1]
         if self.keep_debug_maps:
@@ -555,6 +556,7 @@ class CircleFinder:
         P = self.P
         if self.hist_win is None:
             self.hist_win = torch.zeros((P, FINE_BINS), dtype=torch.int32, device=self.dev)
+            self._drop_graphs()
         else:
             self.hist_win.zero_()
         _call("mg_scharr_hist", self.blur.data_ptr(), P, self.h, self.w, 1, self.hist_base.data_ptr(), self.hist_win.data_ptr(),
@@ -663,6 +665,7 @@ class CircleFinder:
         if need > self._out_cap:
             self._out_cap = int(need * 1.25) + 16
             self._out_sets = [None, None]
+            self._drop_graphs()  # (captured for the old sets: their addresses may be handed out again)
         self._out_turn ^= 1
         if self._out_sets[self._out_turn] is None:
             P, cap = self.P, self._out_cap
@@ -670,6 +673,12 @@ class CircleFinder:
                                               torch.empty((P, cap), dtype=torch.float32, device=self.dev),
                                               torch.empty((P, 3 * cap), dtype=torch.int32, device=self.dev))
         return self._out_sets[self._out_turn]
+
+    def _drop_graphs(self):
+        """Forget every captured chain: a buffer its launches have baked in was made anew."""
+        if self._graphs:
+            self._graphs.clear()
+        self._graph_seen.clear()
 
     def _collect(self, bufs, min_dist, cleared=False):
         """``cleared``: the status block (num_out) has been cleared since the last gather (the optimistic chain)."""
@@ -691,9 +700,11 @@ class CircleFinder:
             self.nms_grid = torch.empty((self.P, grid_cap), dtype=torch.int64, device=self.dev)
             self.nms_grid.fill_(-1)  # once: every call restores the cells it touched (mg_nms_cleanup)
             self.state.zero_()
+            self._drop_graphs()
         if getattr(self, "_nms_dist", None) != min_dist:
             self._nms_ring = torch.from_numpy(nat.circle_points(min_dist, True)).to(self.dev)
             self._nms_dist = min_dist
+            self._drop_graphs()
 
     def _nms_rounds(self, min_dist, first, count, out_cap, cleared=False):
         """Suppression rounds; round k of this group counts what it left undecided in self.undecided[k] (``cleared``:
@@ -823,9 +834,18 @@ class CircleFinder:
         bufs = self._out_buffers(self._out_cap)
         ready = ((self.nms_grid is not None or min_dist <= 0) and (self.hist_win is not None or win == 0)
                  and (min_dist <= 0 or getattr(self, "_nms_dist", None) == min_dist))  # nothing left to allocate / upload
+        # EVERY buffer whose address or size is baked into the captured kernel arguments and that may be made anew
+        # between two calls belongs to the key (the caching allocator can hand a regrown output set the
+        # address of a dropped one -- a graph captured for the old capacity would then gather with the old stride):
+        # the three tensors of the output set and its capacity, the coordinate list, the claim grid and ring, the
+        # window histogram; and the switches that select other kernels.
         key = (planes.data_ptr(), planes.stride(0), planes.stride(1), planes.dtype, passthrough_u8, float(low_q), float(high_q),
                float(min_roundness), int(min_dist), win, sweeps, rounds, self.coords.data_ptr(), self.coords.shape[1],
-               bufs[0].data_ptr(), self.nms_grid.data_ptr() if self.nms_grid is not None else 0)
+               bufs[0].data_ptr(), bufs[0].shape[1], bufs[1].data_ptr(), bufs[2].data_ptr(),
+               self.nms_grid.data_ptr() if self.nms_grid is not None else 0,
+               self.nms_grid.shape[1] if self.nms_grid is not None else 0,
+               self._nms_ring.data_ptr() if min_dist > 0 and getattr(self, "_nms_ring", None) is not None else 0,
+               self.hist_win.data_ptr() if self.hist_win is not None else 0, bool(self.keyed), bool(self.keyed_score))
         entry = self._graphs.get(key)
         if entry is None and ready and self.graph_captures < self.MAX_CAPTURES + self.calls["optimistic"] // 64:
             # (hints that drift -- one sweep more or less -- add a few graphs; a caller whose sequences never repeat stops
@@ -1225,13 +1245,37 @@ def marker_table(out: dict, assay_offset: int, n_channels: int) -> torch.Tensor:
     return tab
 
 
+def masked_median(roi: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """nanmedian of roi (M, C, T, L, L) -- uint8, uint16, float32 or float64 -- under mask (M, L, L) (one mask for all
+    timepoints) or (M, T, L, L) (a mask per timepoint; a broadcast view with time stride 0 is read in place)
+    -> (M, C, T) float64 (identify.py:76-80, filter.py:20-22)."""
+    require_gpu()
+    m, c, t, L, _ = roi.shape
+    roi = roi.contiguous()
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    if mask.dim() == 3:
+        mask = mask.contiguous()
+        sm, st = L * L, 0
+    else:
+        if mask.shape[1] not in (1, t):
+            raise ValueError(f"masked_median: {mask.shape[1]} mask timepoints for {t} roi timepoints")
+        if mask.stride(3) != 1 or mask.stride(2) != L or (m > 1 and mask.stride(0) < L * L):
+            mask = mask.contiguous()
+        sm, st = (mask.stride(0) if m > 1 else L * L), (mask.stride(1) if mask.shape[1] == t and t > 1 else 0)
+    out = torch.empty((m, c, t), dtype=torch.float64, device=roi.device)
+    _call("mg_roi_masked_median", roi.data_ptr(), nat.dtype_code(roi.dtype), mask.data_ptr(), sm, st, m, c, t, L,
+          out.data_ptr(), _stream())
+    return out
+
+
 def masked_median_u16(roi: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """nanmedian of roi (M, C, T, L, L) uint16 under mask (M, L, L) -> (M, C, T) float64."""
     require_gpu()
     m, c, t, L, _ = roi.shape
     out = torch.empty((m, c, t), dtype=torch.float64, device=roi.device)
     _call("mg_roi_masked_median_u16", roi.contiguous().data_ptr(), mask.contiguous().data_ptr(), m, c, t, L,
-                                                 out.data_ptr(), _stream())
+          out.data_ptr(), _stream())
     return out
 
 

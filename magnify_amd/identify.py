@@ -63,7 +63,7 @@ def identify_mrbles(assay, spectra, codes, reference="eu", decode=True):
     names = [str(c) for c in np.asarray(assay.coords["channel"].values).tolist()]
     use = [i for i, c in enumerate(names) if c in table.columns]
     sp = table[[names[i] for i in use]].to_numpy(dtype=np.float64)  # (lanthanide, channel)
-    inten = reduce.fg_mean_minus_bg_median(assay).transpose("mark", "channel", "time").data
+    inten = reduce.fg_mean_minus_bg_median(assay, time=0).data  # `assay.roi.isel(time=0)` first (identify.py:76)
     inten = inten[:, use, 0].cpu().numpy()  # (mark, channel) at time 0
     volumes = np.linalg.lstsq(sp.T, inten.T, rcond=None)[0].T
     with np.errstate(invalid="ignore", divide="ignore"):

@@ -199,15 +199,188 @@ class Reader:
         return Reader()
 
 
-_PINNED_RING = {}
+class _BlockPool:
+    """Free host blocks by (shape, dtype, pinned), kept by the module so that a second pass over a series pins nothing
+    new (pinning a fresh 1.3 GB block per chunk cost 0.2 s, six times the reading).  A block belongs to ONE live
+    iterator at a time: ``take`` removes it from the pool, the iterator gives it back when it ends."""
+
+    def __init__(self):
+        import threading
+
+        self._free, self._lock = collections.defaultdict(list), threading.Lock()
+
+    def take(self, shape, dtype, pinned):
+        key = (tuple(shape), str(dtype), bool(pinned))
+        with self._lock:
+            if self._free[key]:
+                return self._free[key].pop()
+        if pinned:
+            import torch
+
+            return torch.empty(shape, dtype=torch.from_numpy(np.empty(0, dtype)).dtype).pin_memory()
+        return np.empty(shape, dtype=dtype)
+
+    def give(self, block, pinned):
+        key = (tuple(block.shape), str(block.numpy().dtype if pinned else block.dtype), bool(pinned))
+        with self._lock:
+            self._free[key].append(block)
+
+    def clear(self):
+        with self._lock:
+            self._free.clear()
+
+
+_POOL = _BlockPool()
 
 
 def release_pinned():
-    """Give the page-locked blocks of ``iter_time_chunks(pinned=True)`` back (they are kept for the next series)."""
-    _PINNED_RING.clear()
+    """Drop the host blocks ``iter_time_chunks`` keeps for the next series (page-locked ones included)."""
+    _POOL.clear()
 
 
-def iter_time_chunks(pattern, chunk: int, pinned: bool = False, workers: int | None = None, ring: int = 4):
+class TimeSeries:
+    """What ``iter_time_chunks`` learns from a pattern before it reads a pixel: the files, the axes inside them, the
+    timepoints and channels.  One assay per pattern.  ``len(series)`` = timepoints; ``series.chunks(...)`` streams
+    them (any contiguous range of them: the reference's unit is one dask block per TIFF page, reader.py:265-292, and
+    one assay per loop turn, pipeline.py:18-24, so any consumer -- a rank of a multi-GPU run -- can take any time
+    range)."""
+
+    def __init__(self, pattern):
+        self.pattern = os.fspath(pattern)
+        path_dict, _ = extract_paths(self.pattern, assay="str", channel="str", time="time", row="int", col="int")
+        if len(path_dict) == 0:
+            raise FileNotFoundError(f"The pattern {pattern} did not lead to any files.")
+        if len({k[0] for k in path_dict}) > 1:
+            raise ValueError("iter_time_chunks streams one assay per pattern")
+        self.path_dict = path_dict
+        self.path_dims = {"channel": any(k[1] is not None for k in path_dict), "time": any(k[2] is not None for k in path_dict)}
+        lay = series_layout(next(iter(path_dict.values())), need_times=not self.path_dims["time"],
+                            need_channels=not self.path_dims["channel"])
+        self.in_file, self.inner, self.page_shape, self.dtype = lay["dims"], lay["inner"], lay["page"], lay["dtype"]
+        for d in self.in_file:
+            if self.path_dims[d]:
+                raise ValueError("Dimensions specified in the path names and inside the tiff file overlap.")
+        if not self.path_dims["time"] and "time" not in self.in_file:
+            raise ValueError("the pattern needs a (time) group, or files with a time axis")
+        self.tiled = any(k[3] is not None or k[4] is not None for k in path_dict)
+        self.rows = sorted({k[3] for k in path_dict}, key=lambda v: (v is None, v))
+        self.cols = sorted({k[4] for k in path_dict}, key=lambda v: (v is None, v))
+        in_file, inner = self.in_file, self.inner
+        n_t_file = inner[in_file.index("time")] if "time" in in_file else 1
+        n_c_file = inner[in_file.index("channel")] if "channel" in in_file else 1
+        # page index inside a file: C order over the in-file axes, whichever of time / channel comes first
+        self.stride = {d: int(np.prod(inner[in_file.index(d) + 1:], dtype=np.int64)) for d in in_file}
+        self.channels = (sorted({k[1] for k in path_dict}, key=lambda c: (c is None, c)) if self.path_dims["channel"]
+                         else list(range(n_c_file)))
+        self.times = sorted({k[2] for k in path_dict}) if self.path_dims["time"] else list(range(n_t_file))
+        use_file_times = not (self.path_dims["time"] or lay["times"] is None or len(lay["times"]) != n_t_file)
+        self.time_values = lay["times"] if use_file_times else self.times
+        use_file_names = not (self.path_dims["channel"] or lay["channels"] is None or len(lay["channels"]) != n_c_file)
+        self.channel_names = list(lay["channels"] if use_file_names else self.channels)
+        self.assay = next(iter(path_dict))[0]
+
+    def __len__(self):
+        return len(self.times)
+
+    def block_shape(self, n_t):
+        return (n_t, len(self.channels)) + ((len(self.rows), len(self.cols)) if self.tiled else ()) + tuple(self.page_shape)
+
+    def page_of(self, t, c, r, cc):
+        """-> (path, page index inside the file) of timepoint value ``t``, channel value ``c``, tile (r, cc)."""
+        key = (self.assay, c if self.path_dims["channel"] else None, t if self.path_dims["time"] else None, r, cc)
+        if key not in self.path_dict:
+            raise FileNotFoundError(f"no file for channel {c!r}, time {t}, tile ({r}, {cc})")
+        index = ((0 if self.path_dims["time"] else t * self.stride.get("time", 0))
+                 + (0 if self.path_dims["channel"] else c * self.stride.get("channel", 0)))
+        return self.path_dict[key], index
+
+    def chunks(self, chunk, time_range=None, pinned=False, workers=None, ring=None):
+        return _ChunkIter(self, chunk, time_range, pinned, workers, ring)
+
+
+class _ChunkIter:
+    """Iterator behind ``iter_time_chunks``.  ``.first_timepoint`` = the global index of the first timepoint it yields
+    (what ``stack.process_stream(first_timepoint=...)`` needs to number assays and seeds as the unsharded run does),
+    ``.ring`` = how many blocks it cycles through (None: a fresh block per chunk)."""
+
+    def __init__(self, series, chunk, time_range, pinned, workers, ring):
+        self.series, self.chunk, self.pinned = series, int(chunk), bool(pinned)
+        if self.chunk < 1:
+            raise ValueError("chunk must be at least one timepoint")
+        lo, hi = (0, len(series)) if time_range is None else (int(time_range[0]), int(time_range[1]))
+        if not 0 <= lo <= hi <= len(series):
+            raise ValueError(f"time_range {time_range} outside the series' {len(series)} timepoints")
+        self.lo, self.hi, self.first_timepoint = lo, hi, lo
+        if ring is None:
+            ring = 4 if pinned else None  # a fresh pageable block per chunk unless asked otherwise
+        if ring is not None and int(ring) < 1:
+            raise ValueError("ring must be at least 1")
+        self.ring = None if ring is None else int(ring)
+        if workers is None:
+            workers = min(16, os.cpu_count() or 1)
+        self.workers = max(1, int(workers))
+        self._gen = self._run()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return next(self._gen)
+
+    def close(self):
+        self._gen.close()
+
+    def _run(self):
+        from . import tiff
+
+        ser = self.series
+        open_files, blocks = {}, []  # path -> TiffFile, kept open across chunks; the blocks this iterator holds
+
+        def opened(path):
+            tif = open_files.get(path)
+            if tif is None:
+                if len(open_files) >= 256:
+                    open_files.pop(next(iter(open_files))).close()
+                tif = open_files[path] = tiff.TiffFile(path)
+            return tif
+
+        try:
+            n_yielded = 0
+            for lo in range(self.lo, self.hi, self.chunk):
+                part = ser.times[lo: min(lo + self.chunk, self.hi)]
+                shape = ser.block_shape(len(part))
+                if self.ring is None:
+                    block_t = np.empty(shape, dtype=ser.dtype)
+                else:
+                    slot = n_yielded % self.ring
+                    if slot < len(blocks) and tuple(blocks[slot].shape) != shape:  # the shorter last chunk
+                        _POOL.give(blocks[slot], self.pinned)
+                        blocks[slot] = _POOL.take(shape, ser.dtype, self.pinned)
+                    elif slot >= len(blocks):
+                        blocks.append(_POOL.take(shape, ser.dtype, self.pinned))
+                    block_t = blocks[slot]
+                block = block_t.numpy() if self.pinned else block_t
+                n_yielded += 1
+                pages = []  # (TiffFile, page index, destination)
+                for i, t in enumerate(part):
+                    for j, c in enumerate(ser.channels):
+                        for a, r in enumerate(ser.rows):
+                            for b, cc in enumerate(ser.cols):
+                                path, index = ser.page_of(t, c, r, cc)
+                                pages.append((opened(path), index, block[i, j, a, b] if ser.tiled else block[i, j]))
+                tiff.read_pages(pages, self.workers)
+                stamps = [int(t.timestamp()) if isinstance(t, datetime.datetime) else t
+                          for t in ser.time_values[lo: lo + len(part)]]
+                yield stamps, list(ser.channel_names), block_t
+        finally:
+            for tif in open_files.values():
+                tif.close()
+            for blk in blocks:
+                _POOL.give(blk, self.pinned)
+
+
+def iter_time_chunks(pattern, chunk: int, pinned: bool = False, workers: int | None = None, ring: int | None = None,
+                     time_range=None, rank: int | None = None, world: int | None = None):
     """Streamed ingest of a time series too large to hold: the files behind
     ``pattern`` are read ``chunk`` timepoints at a time, in time order, page by page, never all at once.
     Groups as in ``extract_paths``: ``(channel)``, ``(time|format)``, and for tiled acquisitions ``(row)`` /
@@ -217,94 +390,25 @@ def iter_time_chunks(pattern, chunk: int, pinned: bool = False, workers: int | N
     Yields ``(time_values, channels, block)`` with ``block`` (T_chunk, C, H, W) -- tiled series:
     (T_chunk, C, rows, cols, tile_y, tile_x), stitched later on the device (``stack.process_stream(overlap=...)``)
     -- of the files' dtype: a NumPy array, or with ``pinned`` a page-locked torch tensor ready for an
-    asynchronous upload.  ``workers`` threads read a chunk's pages side by side (positional reads straight into the
-    block: one thread copies ~6 GB/s out of the page cache, a tile series is 16+ files).  Page-locked blocks come from
-    a ring of ``ring`` buffers (pinning a fresh 1.3 GB block per chunk cost 0.2 s, six times the reading): a yielded
-    block is overwritten once ``ring - 1`` further chunks have been yielded -- ``stack.process_stream`` with its default
-    ``prefetch=2`` holds at most three.  One assay per pattern."""
-    path_dict, _ = extract_paths(os.fspath(pattern), assay="str", channel="str", time="time", row="int", col="int")
-    if len(path_dict) == 0:
-        raise FileNotFoundError(f"The pattern {pattern} did not lead to any files.")
-    if len({k[0] for k in path_dict}) > 1:
-        raise ValueError("iter_time_chunks streams one assay per pattern")
-    path_dims = {"channel": any(k[1] is not None for k in path_dict), "time": any(k[2] is not None for k in path_dict)}
-    lay = series_layout(next(iter(path_dict.values())), need_times=not path_dims["time"], need_channels=not path_dims["channel"])
-    in_file, inner, (h, w), dtype = lay["dims"], lay["inner"], lay["page"], lay["dtype"]
-    for d in in_file:
-        if path_dims[d]:
-            raise ValueError("Dimensions specified in the path names and inside the tiff file overlap.")
-    if not path_dims["time"] and "time" not in in_file:
-        raise ValueError("the pattern needs a (time) group, or files with a time axis")
-    tiled = any(k[3] is not None or k[4] is not None for k in path_dict)
-    rows = sorted({k[3] for k in path_dict}, key=lambda v: (v is None, v))
-    cols = sorted({k[4] for k in path_dict}, key=lambda v: (v is None, v))
-    n_t_file = inner[in_file.index("time")] if "time" in in_file else 1
-    n_c_file = inner[in_file.index("channel")] if "channel" in in_file else 1
-    # page index inside a file: C order over the in-file axes, whichever of time / channel comes first
-    stride = {d: int(np.prod(inner[in_file.index(d) + 1:], dtype=np.int64)) for d in in_file}
-    channels = sorted({k[1] for k in path_dict}, key=lambda c: (c is None, c)) if path_dims["channel"] else list(range(n_c_file))
-    times = sorted({k[2] for k in path_dict}) if path_dims["time"] else list(range(n_t_file))
-    time_values = times if path_dims["time"] or lay["times"] is None or len(lay["times"]) != n_t_file else lay["times"]
-    channel_names = channels if path_dims["channel"] or lay["channels"] is None or len(lay["channels"]) != n_c_file else lay["channels"]
-    assay = next(iter(path_dict))[0]
-    open_files = {}  # path -> TiffFile, kept open across pages (a chunk touches each of its files many times)
-    import threading
-    from concurrent.futures import ThreadPoolExecutor
+    asynchronous upload.
 
-    files_lock = threading.Lock()
-    if workers is None:
-        workers = min(16, os.cpu_count() or 1)
-    pool = ThreadPoolExecutor(max_workers=max(1, int(workers))) if workers and workers > 1 else None
+    ``time_range=(lo, hi)`` (or ``rank`` / ``world``: this rank's ``distributed.shard_range`` block) restricts the
+    stream to the timepoints [lo, hi) of the series -- config C5 across GPUs: every rank streams its own contiguous
+    block of the time axis; the returned iterator's ``first_timepoint`` (= lo) goes to
+    ``stack.process_stream(first_timepoint=...)`` so that assay indices, seeds and file names are those of the
+    unsharded run.
 
-    def read_page(path, index, out):
-        from . import tiff
+    A chunk's pages are read by ``workers`` threads side by side, outside the interpreter (``mg_host_read_runs``:
+    positional reads straight into the block) when the pages are stored uncompressed in one piece -- what acquisition
+    software writes --, page by page through ``TiffFile.read_page_into`` otherwise.  Page-locked blocks come from a
+    ring of ``ring`` buffers (default 4) that belongs to THIS iterator: a yielded block is overwritten once ``ring - 1``
+    further chunks have been yielded -- ``stack.process_stream`` holds at most ``prefetch + 2`` and checks --; without
+    ``pinned`` every chunk is a fresh array unless ``ring`` is given.  One assay per pattern."""
+    series = pattern if isinstance(pattern, TimeSeries) else TimeSeries(pattern)
+    if rank is not None or world is not None:
+        if time_range is not None:
+            raise ValueError("iter_time_chunks: time_range or rank / world, not both")
+        from .distributed import shard_range
 
-        with files_lock:
-            tif = open_files.get(path)
-            if tif is None:
-                if len(open_files) >= 256:  # (files dropped here are closed by the garbage collector, not under a reader)
-                    open_files.pop(next(iter(open_files)))
-                tif = open_files[path] = tiff.TiffFile(path)
-        tif.read_page_into(index, out)
-
-    def page_of(t, c, r, cc):  # -> (path, page index inside the file)
-        key = (assay, c if path_dims["channel"] else None, t if path_dims["time"] else None, r, cc)
-        if key not in path_dict:
-            raise FileNotFoundError(f"no file for channel {c!r}, time {t}, tile ({r}, {cc})")
-        index = (0 if path_dims["time"] else t * stride.get("time", 0)) + (0 if path_dims["channel"] else c * stride.get("channel", 0))
-        return path_dict[key], index
-
-    pinned_ring, n_yielded = _PINNED_RING, 0  # (kept by the module: a second pass over a series pins nothing new)
-    for lo in range(0, len(times), int(chunk)):
-        part = times[lo: lo + int(chunk)]
-        shape = (len(part), len(channels)) + ((len(rows), len(cols)) if tiled else ()) + (h, w)
-        if pinned:
-            import torch
-
-            slot = (n_yielded % max(int(ring), 1), shape, str(dtype))
-            block_t = pinned_ring.get(slot)
-            if block_t is None:
-                block_t = pinned_ring[slot] = torch.empty(shape, dtype=torch.from_numpy(np.empty(0, dtype)).dtype).pin_memory()
-            block = block_t.numpy()
-            n_yielded += 1
-        else:
-            block = np.empty(shape, dtype=dtype)
-        jobs = []
-        for i, t in enumerate(part):
-            for j, c in enumerate(channels):
-                for a, r in enumerate(rows):
-                    for b, cc in enumerate(cols):
-                        path, index = page_of(t, c, r, cc)
-                        dst = block[i, j, a, b] if tiled else block[i, j]
-                        if pool is None:
-                            read_page(path, index, dst)
-                        else:
-                            jobs.append(pool.submit(read_page, path, index, dst))
-        for job in jobs:
-            job.result()  # (re-raises what a reader thread met)
-        stamps = [int(t.timestamp()) if isinstance(t, datetime.datetime) else t for t in time_values[lo: lo + int(chunk)]]
-        yield stamps, list(channel_names), (block_t if pinned else block)
-    if pool is not None:
-        pool.shutdown()
-    for tif in open_files.values():
-        tif.close()
+        time_range = shard_range(len(series), int(rank or 0), int(world or 1))
+    return series.chunks(chunk, time_range=time_range, pinned=pinned, workers=workers, ring=ring)

@@ -70,18 +70,29 @@ def masked_mean(xp, mask="fg"):
     return DataArray(s / n, ("mark", "channel", "time"))
 
 
-def masked_median(xp, mask="bg"):
-    """roi.where(mask).median(dim=[roi_y, roi_x]) with numpy nanmedian semantics (uint16 rois)."""
+def masked_median(xp, mask="bg", time=None):
+    """roi.where(mask).median(dim=[roi_y, roi_x]) with numpy nanmedian semantics -> (mark, channel, time) float64.
+    Any roi dtype the hot path carries (uint8, uint16, float32, float64); the masks may differ between timepoints (a
+    chip searched at several timesteps, find.py:119-140).  ``time=k``: of timepoint ``k`` only, selected BEFORE the
+    reduction as ``assay.isel(time=0)`` does in filter.py:20-22, 69-75 and identify.py:76 -- the other timepoints are
+    neither read nor reduced; the result keeps a time axis of length 1."""
     roi = xp.data_vars["roi"].transpose("mark", "channel", "time", "roi_y", "roi_x").data
-    if not isinstance(roi, torch.Tensor) or roi.dtype != torch.uint16:
-        raise TypeError("the device median kernel handles uint16 rois")
+    if not isinstance(roi, torch.Tensor):
+        roi = np.ascontiguousarray(roi)
+        if roi.dtype.byteorder not in ("=", "|"):
+            roi = roi.astype(roi.dtype.newbyteorder("="))
+        roi = torch.from_numpy(roi)
+    hotpath.nat.dtype_code(roi.dtype)  # TypeError for anything but uint8 / uint16 / float32 / float64
     m = _masks(xp, mask)
-    if m.shape[1] != 1 and not bool((m == m[:, :1]).all()):
-        raise NotImplementedError("time-varying masks: call per timestep")
-    return DataArray(hotpath.masked_median_u16(roi.cuda().contiguous(), m[:, 0].to(torch.uint8).contiguous()),
-                     ("mark", "channel", "time"))
+    if time is not None:
+        roi = roi[:, :, time:time + 1] if time != -1 else roi[:, :, -1:]
+        m = m[:, time:time + 1] if m.shape[1] != 1 else m
+    return DataArray(hotpath.masked_median(roi.cuda(), m.cuda()), ("mark", "channel", "time"))
 
 
-def fg_mean_minus_bg_median(xp):
-    """identify.py:76-80."""
-    return DataArray(masked_mean(xp, "fg").data - masked_median(xp, "bg").data, ("mark", "channel", "time"))
+def fg_mean_minus_bg_median(xp, time=None):
+    """identify.py:76-80 (``time=0``: ``assay.roi.isel(time=0)`` first, as the reference does)."""
+    mean = masked_mean(xp, "fg").data
+    if time is not None:
+        mean = mean[:, :, time:time + 1]
+    return DataArray(mean - masked_median(xp, "bg", time=time).data, ("mark", "channel", "time"))

@@ -12,10 +12,18 @@ timepoint (= assay, mode P), a Dataset with the reference's schema (find.py:503-
 
   * ``HostSink``: keeps the assays in host memory (``.assays``), optionally without ROI pixels.
   * ``SaveSink(pattern)``: writes every assay with ``mg.save`` as soon as its copy has landed (``pattern`` takes
-    ``{index}`` = global timepoint index; a rank of a multi-GPU run passes a pattern of its own) and keeps only the
-    file names: nothing accumulates, a terabyte-scale series leaves a directory of NetCDF files that ``mg.load`` reads.
+    ``{index}`` = GLOBAL timepoint index: the ranks of a multi-GPU run, each streaming its block of the time axis with
+    ``process_stream(first_timepoint=lo)``, share one pattern and leave exactly the files of the single-process run)
+    and keeps only the file names: nothing accumulates, a terabyte-scale series leaves a directory of NetCDF files that
+    ``mg.load`` reads.
+
+The copies land in a ring of page-locked staging blocks and a WRITER THREAD turns them into Datasets / files: the thread
+that feeds the GPU queues the copy and goes on (it waits only when ``depth`` chunks are already on their way).
 """
 from __future__ import annotations
+
+import queue
+import threading
 
 import numpy as np
 import torch
@@ -24,50 +32,115 @@ from . import file as mgfile
 from .xr_lite import DataArray, Dataset
 
 
+class _Staging:
+    """Page-locked byte blocks for the device-to-host copies of the sink, reused from chunk to chunk (pinning a fresh
+    block per chunk and key costs ~0.15 s per GB -- more than the copy).  A block is handed out at least as large as
+    asked for (a chunk's marker count varies) and comes back when the writer thread is done with the chunk."""
+
+    def __init__(self):
+        self._free, self._lock = [], threading.Lock()
+
+    def take(self, nbytes):
+        with self._lock:
+            fit = [b for b in self._free if b.numel() >= nbytes]
+            if fit:
+                best = min(fit, key=lambda b: b.numel())
+                self._free.remove(best)
+                return best
+            if self._free:  # the largest free block is too small: it makes room for a larger one
+                self._free.remove(max(self._free, key=lambda b: b.numel()))
+        return torch.empty((max(int(nbytes * 1.25), 1 << 20),), dtype=torch.uint8).pin_memory()
+
+    def give(self, blocks):
+        with self._lock:
+            self._free.extend(blocks)
+
+
 class _Sink:
-    def __init__(self, want_roi=True, want_masks=True):
+    """``depth``: how many chunks may be on their way (copy in flight / being written) before ``__call__`` waits for
+    the writer -- the GPU feed never waits for a file while the writer keeps up."""
+
+    copy_out = False  # True: the assays outlive the staging blocks (HostSink keeps them): copied out of them
+
+    def __init__(self, want_roi=True, want_masks=True, depth=3):
         self.want_roi, self.want_masks = want_roi, want_masks
         self._side = None
-        self._pending = None  # (event, host tensors, meta) of the chunk whose copy is in flight
+        self._staging = _Staging()
+        self._slots = threading.Semaphore(max(1, int(depth)))
+        self._jobs = queue.Queue()
+        self._writer = None
+        self._error = None
 
     # -- called by process_stream ---------------------------------------------------------------------------------
     def __call__(self, out):
-        """Queue the device-to-host copy of this chunk's outputs (side stream, page-locked destination) and finish
-        the chunk before it."""
+        """Queue the device-to-host copy of this chunk's outputs (side stream, page-locked staging blocks) and hand the
+        chunk to the writer thread, which waits for the copy, builds the assays' Datasets and ``take``s them."""
+        self._raise_writer_error()
         dev_keys = [k for k in ("sums", "counts") + (("roi",) if self.want_roi else ()) + (("fg", "bg") if self.want_masks else ())
                     if out.get(k) is not None]
+        self._slots.acquire()
+        if self._writer is None:
+            self._writer = threading.Thread(target=self._write_loop, daemon=True)
+            self._writer.start()
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
         ready = torch.cuda.Event()
         ready.record(main)
-        host = {}
+        host, blocks = {}, []
         self._side.wait_event(ready)
         with torch.cuda.stream(self._side):
             for k in dev_keys:
                 src = out[k]
-                dst = torch.empty(src.shape, dtype=src.dtype).pin_memory() if src.numel() else torch.empty(src.shape, dtype=src.dtype)
-                dst.copy_(src, non_blocking=True)
-                src.record_stream(self._side)
+                if src.numel():
+                    block = self._staging.take(src.numel() * src.element_size())
+                    blocks.append(block)
+                    dst = block[: src.numel() * src.element_size()].view(src.dtype).view(src.shape)
+                    dst.copy_(src, non_blocking=True)
+                    src.record_stream(self._side)
+                else:
+                    dst = torch.empty(src.shape, dtype=src.dtype)
                 host[k] = dst
             done = torch.cuda.Event()
             done.record(self._side)
         meta = {"beads": [np.asarray(b) for b in out["beads"]], "offsets": np.asarray(out["offsets"]),
                 "first": int(out.get("first_timepoint", 0)), "time": out.get("time"), "channel": out.get("channel")}
-        previous, self._pending = self._pending, (done, host, meta)
-        if previous is not None:
-            self._finish(*previous)
+        self._jobs.put((done, host, meta, blocks))
         return done  # process_stream makes the chunk after next wait for it (that one reuses these device buffers)
 
     def close(self):
-        if self._pending is not None:
-            previous, self._pending = self._pending, None
-            self._finish(*previous)
+        """Finish what is on its way (also when the stream broke off) and stop the writer; re-raises its error."""
+        if self._writer is not None:
+            self._jobs.put(None)
+            self._writer.join()
+            self._writer = None
+        self._raise_writer_error()
+
+    def _raise_writer_error(self):
+        if self._error is not None:
+            err, self._error = self._error, None
+            raise err
+
+    def _write_loop(self):
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            done, host, meta, blocks = job
+            try:
+                if self._error is None:  # (after an error the remaining chunks are only released)
+                    self._finish(done, host, meta)
+            except BaseException as exc:
+                self._error = exc
+            finally:
+                done.synchronize()  # (a block must not go back while its copy is in flight)
+                self._staging.give(blocks)
+                self._slots.release()
 
     # -- per assay ---------------------------------------------------------------------------------------------------
     def _finish(self, done, host, meta):
         done.synchronize()
-        arrays = {k: v.numpy() for k, v in host.items()}
+        arrays = {k: (np.array(v.numpy()) if self.copy_out else v.numpy()) for k, v in host.items()}
         off = meta["offsets"]
         for a, beads in enumerate(meta["beads"]):
             lo, hi = int(off[a]), int(off[a + 1])
@@ -111,8 +184,10 @@ class _Sink:
 class HostSink(_Sink):
     """Every assay (timepoint) of the stream as a Dataset in host memory: ``sink.assays[index]``."""
 
-    def __init__(self, want_roi=True, want_masks=True):
-        super().__init__(want_roi, want_masks)
+    copy_out = True
+
+    def __init__(self, want_roi=True, want_masks=True, depth=3):
+        super().__init__(want_roi, want_masks, depth)
         self.assays = {}
 
     def take(self, index, ds):
@@ -122,8 +197,8 @@ class HostSink(_Sink):
 class SaveSink(_Sink):
     """Every assay written with ``mg.save`` to ``pattern.format(index=...)`` as soon as it is on the host."""
 
-    def __init__(self, pattern, want_roi=True, want_masks=True, shard_bytes=None):
-        super().__init__(want_roi, want_masks)
+    def __init__(self, pattern, want_roi=True, want_masks=True, shard_bytes=None, depth=3):
+        super().__init__(want_roi, want_masks, depth)
         if "{index" not in pattern:
             raise ValueError("SaveSink: the file pattern needs an {index} field")
         self.pattern, self.shard_bytes, self.files = pattern, shard_bytes, {}

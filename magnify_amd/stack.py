@@ -229,7 +229,7 @@ def stitched_shape(rows, cols, tile_y, tile_x, overlap):
 
 
 def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False, prefetch=2, overlap=0, sink=None,
-                   **processor_kwargs):
+                   first_timepoint=None, **processor_kwargs):
     """Mode-P processing of a time series that arrives chunk by chunk (config C5: ``reader.iter_time_chunks``
     or any iterator of (T_chunk, C, H, W) blocks -- or TILED blocks (T_chunk, C, rows, cols, tile_y, tile_x), which the
     flat-field pass crops and joins with ``overlap`` on the device, so the stitched assay never exists on the host --
@@ -238,66 +238,98 @@ def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False,
     before; inside a chunk the upload overlaps compute when ``n_streams > 1`` is passed on.  Every
     timepoint is its own assay, and its RNG stream only depends on its global index: the results equal
     those of the whole stack in one ``StackProcessor`` call, whatever the chunk size.
+
+    ``first_timepoint``: the global index of the first timepoint of ``chunks`` (default: the iterator's own
+    ``first_timepoint`` -- ``iter_time_chunks(time_range=...)`` carries it -- else 0).  A rank of a multi-GPU run streams
+    its block [lo, hi) of the time axis with ``first_timepoint=lo``: assay indices, seeds (``seed + 1000003 index``) and
+    the sink's file names are then those of the unsharded run, and the union of the ranks' results IS that run's result
+    (the reference's unit is one assay per loop turn, pipeline.py:18-24, any of which any worker may take).
+
     Yields one result dict per chunk (as ``StackProcessor.__call__``, plus ``first_timepoint``); ROI pixel
     stacks / masks (``want_roi``) are views of pooled buffers that the chunk after next overwrites (two sets in turn).
     ``sink`` (``magnify_amd.sink.HostSink`` / ``SaveSink``): called with every chunk's result while its buffers are
     valid -- it copies what it keeps to the host beside the next chunk's kernels and turns every timepoint into a
     Dataset with the reference's schema (kept in memory or saved with ``mg.save``): the streamed results persist,
-    as the reference's do through ``Dataset.mg.cache`` (accessor.py:18-35, find.py:604)."""
+    as the reference's do through ``Dataset.mg.cache`` (accessor.py:18-35, find.py:604).  The sink is closed (its
+    pending chunk finished, its writer joined) however the stream ends -- exhausted, abandoned by the consumer or
+    broken by an error."""
     import queue
     import threading
 
-    q = queue.Queue(maxsize=max(1, int(prefetch)))
-    stop = object()
+    prefetch = max(1, int(prefetch))
+    ring = getattr(chunks, "ring", None)
+    if ring is not None and ring < prefetch + 2:
+        # live blocks: one with the consumer, `prefetch` queued, one the reader holds while the queue is full
+        raise ValueError(f"process_stream(prefetch={prefetch}) holds up to {prefetch + 2} blocks, the reader cycles "
+                         f"through {ring}: pass ring >= {prefetch + 2} to iter_time_chunks")
+    if first_timepoint is None:
+        first_timepoint = int(getattr(chunks, "first_timepoint", 0))
+    q = queue.Queue(maxsize=prefetch)
+    stop, cancelled = object(), threading.Event()
 
     def produce():
         try:
             for item in chunks:
-                q.put(item)
-            q.put(stop)
+                while not cancelled.is_set():
+                    try:
+                        q.put(item, timeout=0.2)
+                        break
+                    except queue.Full:
+                        continue
+                if cancelled.is_set():
+                    break
+            else:
+                q.put(stop)
         except BaseException as exc:  # surfaces in the consumer
             q.put(exc)
+        finally:
+            if cancelled.is_set() and hasattr(chunks, "close"):
+                chunks.close()  # (the reader's files and blocks; a generator may only be closed by the thread that runs it)
 
-    threading.Thread(target=produce, daemon=True).start()
-    procs, done, n_chunk, copied = {}, 0, 0, [None, None]
-    while True:
-        item = q.get()
-        if item is stop:
+    producer = threading.Thread(target=produce, daemon=True)
+    producer.start()
+    procs, done, n_chunk, copied = {}, int(first_timepoint), 0, [None, None]
+    try:
+        while True:
+            item = q.get()
+            if item is stop:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            block = item[-1] if isinstance(item, tuple) else item
+            if not isinstance(block, torch.Tensor):
+                block = torch.from_numpy(np.ascontiguousarray(block))
+            key = (tuple(block.shape), block.dtype)
+            if key not in procs:  # a shorter last chunk gets its own workspaces
+                if block.dim() == 6:  # (T, C, rows, cols, tile_y, tile_x): stitched by the flat-field pass
+                    t, c = block.shape[:2]
+                    h, w = stitched_shape(*block.shape[2:], overlap)
+                    procs[key] = StackProcessor(t, c, h, w, dtype=block.dtype, mode="P", tile_grid=tuple(block.shape[2:]),
+                                                overlap=overlap, **processor_kwargs)
+                else:
+                    t, c, h, w = block.shape
+                    procs[key] = StackProcessor(t, c, h, w, dtype=block.dtype, mode="P", **processor_kwargs)
+            t = block.shape[0]
+            parity = n_chunk & 1
+            if copied[parity] is not None:  # the sink's host copy of the chunk that last wrote this buffer set
+                torch.cuda.current_stream().wait_event(copied[parity])
+            procs[key].pool_tag = f"#{parity}"
+            out = procs[key](block, flatfield, darkfield, seed=(seed + 1000003 * done) & 0xFFFFFFFFFFFFFFFF, want_roi=want_roi)
+            out["first_timepoint"] = done
+            for k in ("sums", "counts"):  # small; the pooled buffers behind them are reused by the next chunk
+                if out.get(k) is not None:
+                    out[k] = out[k].clone()
+            if isinstance(item, tuple) and len(item) == 3:
+                out["time"], out["channel"] = item[0], item[1]
             if sink is not None:
-                sink.close()
-            return
-        if isinstance(item, BaseException):
-            raise item
-        block = item[-1] if isinstance(item, tuple) else item
-        if not isinstance(block, torch.Tensor):
-            block = torch.from_numpy(np.ascontiguousarray(block))
-        key = (tuple(block.shape), block.dtype)
-        if key not in procs:  # a shorter last chunk gets its own workspaces
-            if block.dim() == 6:  # (T, C, rows, cols, tile_y, tile_x): stitched by the flat-field pass
-                t, c = block.shape[:2]
-                h, w = stitched_shape(*block.shape[2:], overlap)
-                procs[key] = StackProcessor(t, c, h, w, dtype=block.dtype, mode="P", tile_grid=tuple(block.shape[2:]),
-                                            overlap=overlap, **processor_kwargs)
-            else:
-                t, c, h, w = block.shape
-                procs[key] = StackProcessor(t, c, h, w, dtype=block.dtype, mode="P", **processor_kwargs)
-        t = block.shape[0]
-        parity = n_chunk & 1
-        if copied[parity] is not None:  # the sink's host copy of the chunk that last wrote this buffer set
-            torch.cuda.current_stream().wait_event(copied[parity])
-        procs[key].pool_tag = f"#{parity}"
-        out = procs[key](block, flatfield, darkfield, seed=(seed + 1000003 * done) & 0xFFFFFFFFFFFFFFFF, want_roi=want_roi)
-        out["first_timepoint"] = done
-        for k in ("sums", "counts"):  # small; the pooled buffers behind them are reused by the next chunk
-            if out.get(k) is not None:
-                out[k] = out[k].clone()
-        if isinstance(item, tuple) and len(item) == 3:
-            out["time"], out["channel"] = item[0], item[1]
+                copied[parity] = sink(out)
+            done += t
+            n_chunk += 1
+            yield out
+    finally:
+        cancelled.set()
         if sink is not None:
-            copied[parity] = sink(out)
-        done += t
-        n_chunk += 1
-        yield out
+            sink.close()
 
 
 def dedup_against(seen: np.ndarray, new: np.ndarray, radius: float) -> np.ndarray:

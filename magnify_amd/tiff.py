@@ -374,9 +374,67 @@ class TiffFile:
                 out[r0: r0 + rows, c0: c0 + cols] = block[:rows, :cols]
         return out
 
+    def page_run(self, index, out):
+        """(offset, nbytes) if page ``index`` can be read into ``out`` by ONE positional read (uncompressed, strips back
+        to back, native byte order), else None.  Checks ``out`` like ``read_page_into``."""
+        page = self.page(index)
+        if out.shape != page.shape or out.dtype != page.dtype.newbyteorder("=") or not out.flags.c_contiguous:
+            raise TiffError(f"{self.path}: page {index} is {page.shape} {page.dtype}, the buffer {out.shape} {out.dtype}")
+        if page.dtype.byteorder not in ("=", "|") and page.dtype != page.dtype.newbyteorder("="):
+            return None
+        run = page.contiguous
+        if run is not None and run[0] + run[1] > self._size:
+            raise TiffError(f"{self.path}: page {index} reaches beyond the end of the file")
+        return run
+
+    def fileno(self):
+        return self._fh.fileno()
+
     def asarray(self, index=0):
         page = self.page(index)
         return self.read_page_into(index, np.empty(page.shape, dtype=page.dtype.newbyteorder("=")))
+
+
+def read_pages(pages, workers=1):
+    """Decode many pages side by side: ``pages`` = [(TiffFile, page index, out array)].  Pages that are one byte run
+    in their file (``TiffFile.page_run``) are read by ``mg_host_read_runs`` -- ``workers`` native threads, positional
+    reads straight into the destinations, no interpreter between two pages --; the others (compressed, tiled, foreign
+    byte order) go page by page through ``read_page_into`` on a thread pool."""
+    runs, slow = [], []
+    for tif, index, out in pages:
+        run = tif.page_run(index, out)
+        if run is None:
+            slow.append((tif, index, out))
+        else:
+            runs.append((tif, run[0], run[1], out))
+    if runs:
+        import ctypes
+
+        from . import _native
+
+        n = len(runs)
+        fds = np.fromiter((r[0].fileno() for r in runs), dtype=np.int32, count=n)
+        offs = np.fromiter((r[1] for r in runs), dtype=np.int64, count=n)
+        lens = np.fromiter((r[2] for r in runs), dtype=np.int64, count=n)
+        dsts = np.fromiter((r[3].ctypes.data for r in runs), dtype=np.uint64, count=n)
+        failed = (ctypes.c_int64 * 2)(-1, 0)
+        rc = _native.lib().mg_host_read_runs(fds.ctypes.data, offs.ctypes.data, lens.ctypes.data, dsts.ctypes.data, n,
+                                             max(1, min(int(workers), 64)), ctypes.addressof(failed))
+        if rc == -3:
+            tif, off, nbytes, _ = runs[int(failed[0])]
+            why = os.strerror(int(failed[1])) if failed[1] else "short read"
+            raise TiffError(f"{tif.path}: {why} in the {nbytes} bytes at {off}")
+        _native.check(rc, "mg_host_read_runs")
+    if slow:
+        if workers > 1 and len(slow) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(max_workers=int(workers)) as pool:
+                for job in [pool.submit(tif.read_page_into, index, out) for tif, index, out in slow]:
+                    job.result()  # (re-raises what a reader thread met)
+        else:
+            for tif, index, out in slow:
+                tif.read_page_into(index, out)
 
 
 def _unpredict(block, predictor):
@@ -430,6 +488,7 @@ def _unlzw(data):
         while nbits >= width:
             code = (bits >> (nbits - width)) & ((1 << width) - 1)
             nbits -= width
+            bits &= (1 << nbits) - 1  # keep only what has not been consumed (else every shift is O(strip))
             if code == 256:
                 del table[258:]
                 width, prev = 9, None

@@ -670,7 +670,11 @@ class _Accessor:
                 else:
                     root = str(spill)
                     os.makedirs(root, exist_ok=True)
-                path = os.path.join(root, f"{id(self._ds):x}_{n}.npy")
+                import uuid
+
+                # (a name of its own: `id(ds)` comes back after a dataset is collected -- "w+" on a recycled name would
+                # truncate a file an older array still has memory-mapped)
+                path = os.path.join(root, f"{uuid.uuid4().hex}_{n}.npy")
                 host = _to_numpy(data)
                 mm = np.lib.format.open_memmap(path, mode="w+", dtype=host.dtype, shape=host.shape)
                 mm[...] = host

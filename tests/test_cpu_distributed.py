@@ -89,3 +89,72 @@ def test_self_launcher(capsys):
     env = launch.rank_env(1, 4, 1234, share_gpu=True, base={})
     assert env["RANK"] == "1" and env["WORLD_SIZE"] == "4" and env["MG_SHARE_GPU"] == "1" and env["MG_DIST_BACKEND"] == "gloo"
     assert launch.launched_by_torchrun({"RANK": "0", "WORLD_SIZE": "2"}) and not launch.launched_by_torchrun({})
+
+
+def _write_tiled_series(root, n_t, n_c, rows, cols, ty, tx, seed=3):
+    """config C5's file shape: one OME-BigTIFF per tile position holding (time, channel) pages."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tiffwrite import ome_xml, write_tiff
+
+    rng = np.random.default_rng(seed)
+    data = rng.integers(0, 65535, (n_t, n_c, rows, cols, ty, tx)).astype(np.uint16)
+    for r in range(rows):
+        for c in range(cols):
+            pages = [data[t, ch, r, c] for t in range(n_t) for ch in range(n_c)]
+            write_tiff(os.path.join(root, f"acq_r{r}_c{c}.ome.tif"), pages, bigtiff=True,
+                       description=ome_xml(size_c=n_c, size_t=n_t, size_y=ty, size_x=tx, channel_names=["a", "b"][:n_c]))
+    return data, os.path.join(root, "acq_r(row)_c(col).ome.tif")
+
+
+def _stream_worker(rank, world, port, pattern, chunk, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from magnify_amd import distributed as mgd
+    from magnify_amd import reader
+
+    r, w, _ = mgd.init_from_env(backend="gloo")
+    it = reader.iter_time_chunks(pattern, chunk, rank=r, world=w, workers=2)
+    rows, blocks, t = [], [], it.first_timepoint
+    for stamps, channels, block in it:
+        for i in range(block.shape[0]):  # one "marker" row per timepoint: [global timepoint, checksum, rank]
+            rows.append([t, float(block[i].astype(np.uint64).sum()), r])
+            t += 1
+        blocks.append(block.copy())
+    table = mgd.gather_marker_table(torch.tensor(rows, dtype=torch.float64).reshape(-1, 3))
+    ret[rank] = (table.numpy().copy(), np.concatenate(blocks), it.first_timepoint, (it.lo, it.hi))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_streamed_series_partition(tmp_path):
+    """Config C5 across ranks: two gloo ranks stream the two halves of ONE tiled OME-BigTIFF series
+    (reader.iter_time_chunks(rank=, world=)); the blocks they read are the series' own timepoints, numbered globally,
+    and the gathered table equals the single-process stream's, row for row."""
+    from magnify_amd import reader
+
+    n_t, chunk = 7, 2
+    data, pattern = _write_tiled_series(str(tmp_path), n_t, 2, 2, 3, 24, 40)
+    world, port = 2, _free_port()
+    manager = mp.get_context("spawn").Manager()
+    ret = manager.dict()
+    mp.spawn(_stream_worker, args=(world, port, pattern, chunk, ret), nprocs=world, join=True)
+    whole = np.concatenate([b for _, _, b in reader.iter_time_chunks(pattern, chunk)])
+    np.testing.assert_array_equal(whole, data)
+    want = np.array([[t, float(data[t].astype(np.uint64).sum())] for t in range(n_t)])
+    for rank in range(world):
+        table, blocks, first, (lo, hi) = ret[rank]
+        assert (lo, hi) == ((0, 4), (4, 7))[rank] and first == lo
+        np.testing.assert_array_equal(blocks, data[lo:hi])
+        np.testing.assert_array_equal(table[:, :2], want)  # every rank holds the whole series' table, in time order
+        assert table[:, 2].tolist() == [0.0] * 4 + [1.0] * 3
+    # an explicit range, and the refusals
+    it = reader.iter_time_chunks(pattern, 3, time_range=(2, 6))
+    got = list(it)
+    assert it.first_timepoint == 2 and [len(g[0]) for g in got] == [3, 1] and got[0][0] == [2, 3, 4]
+    np.testing.assert_array_equal(np.concatenate([g[2] for g in got]), data[2:6])
+    assert list(reader.iter_time_chunks(pattern, 3, time_range=(5, 5))) == []
+    with pytest.raises(ValueError):
+        reader.iter_time_chunks(pattern, 3, time_range=(2, 9))
+    with pytest.raises(ValueError):
+        reader.iter_time_chunks(pattern, 3, time_range=(0, 2), rank=0, world=2)

@@ -877,3 +877,223 @@ def test_squeeze_of_several_dimensions_equals_one_at_a_time():
     with pytest.raises(ValueError):
         v.squeeze("b")
     assert v.squeeze([]) is v
+
+
+def test_process_stream_numbers_a_shard_globally(tmp_path, monkeypatch):
+    """stack.process_stream(first_timepoint=lo) (config C5 across ranks): assay indices, seeds and the first_timepoint
+    of every chunk are those of the unsharded run; the reader's ring is checked against the prefetch depth; the sink is
+    closed however the stream ends.  (StackProcessor needs a GPU: a stand-in records what it is called with.)"""
+    import torch
+
+    from magnify_amd import stack
+
+    calls = []
+
+    class Fake:
+        def __init__(self, t, c, h, w, **kw):
+            self.shape, self.pool_tag = (t, c, h, w), ""
+
+        def __call__(self, block, flatfield, darkfield, seed=0, want_roi=False):
+            calls.append((int(block[0, 0, 0, 0]), seed, self.pool_tag))
+            return {"beads": [np.zeros((0, 3), np.int32)] * block.shape[0], "sums": None, "counts": None}
+
+    monkeypatch.setattr(stack, "StackProcessor", Fake)
+    series = np.arange(10, dtype=np.uint16).reshape(10, 1, 1, 1) * np.ones((10, 2, 4, 4), dtype=np.uint16)
+
+    class Chunks:  # an iterator that carries what reader._ChunkIter carries
+        def __init__(self, lo, hi, step, ring=None):
+            self.first_timepoint, self.ring, self._it, self.closed = lo, ring, iter(range(lo, hi, step)), False
+            self.hi, self.step = hi, step
+
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            t = next(self._it)
+            return torch.from_numpy(series[t: min(t + self.step, self.hi)].copy())
+
+        def close(self):
+            self.closed = True
+
+    class Sink:
+        closed = 0
+
+        def __call__(self, out):
+            return None
+
+        def close(self):
+            Sink.closed += 1
+
+    whole = [o["first_timepoint"] for o in stack.process_stream(Chunks(0, 10, 3), seed=11)]
+    whole_calls, calls[:] = list(calls), []
+    assert whole == [0, 3, 6, 9] and [c[1] for c in whole_calls] == [11 + 1000003 * t for t in whole]
+    part = [o["first_timepoint"] for o in stack.process_stream(Chunks(6, 10, 3), seed=11, sink=Sink())]
+    assert part == [6, 9] and calls == [(6, 11 + 1000003 * 6, "#0"), (9, 11 + 1000003 * 9, "#1")] and Sink.closed == 1
+    assert [c[:2] for c in calls] == [c[:2] for c in whole_calls[2:]]  # the shard's calls ARE the whole run's
+    # an explicit first_timepoint wins over the iterator's
+    assert [o["first_timepoint"] for o in stack.process_stream(Chunks(6, 10, 3), first_timepoint=100)] == [100, 103]
+    # a ring smaller than what the stream holds is refused before anything is read
+    with pytest.raises(ValueError, match="ring"):
+        next(stack.process_stream(Chunks(0, 10, 3, ring=3), prefetch=2))
+    next(stack.process_stream(Chunks(0, 10, 3, ring=4), prefetch=2))
+    # the consumer walks away after one chunk: the sink is closed, the reader's iterator too
+    src, before = Chunks(0, 10, 1), Sink.closed
+    gen = stack.process_stream(src, sink=Sink(), prefetch=1)
+    next(gen)
+    gen.close()
+    assert Sink.closed == before + 1
+    for _ in range(100):
+        if src.closed:
+            break
+        import time
+        time.sleep(0.05)
+    assert src.closed
+    # an error inside a chunk: the sink is still closed
+    before = Sink.closed
+
+    def bad():
+        yield torch.from_numpy(series[:2].copy())
+        raise OSError("disk gone")
+
+    with pytest.raises(OSError):
+        list(stack.process_stream(bad(), sink=Sink()))
+    assert Sink.closed == before + 1
+
+
+def test_reader_ring_belongs_to_one_iterator(tmp_path):
+    """blocks of iter_time_chunks(ring=...) are owned by ONE live iterator -- two iterators over same-shape
+    series never share a block; a block comes back after ``ring`` chunks, not earlier; the pool takes the blocks back
+    when an iterator ends (also early)."""
+    from PIL import Image
+
+    from magnify_amd import reader
+
+    rng = np.random.default_rng(0)
+    data = rng.integers(0, 60000, (6, 2, 16, 24)).astype(np.uint16)
+    for t in range(6):
+        for c in range(2):
+            Image.fromarray(data[t, c]).save(tmp_path / f"s_c{c}_2024010{t + 1}.tif")
+    pattern = str(tmp_path / "s_c(channel)_(time|%Y%m%d).tif")
+    reader.release_pinned()
+    a, b = reader.iter_time_chunks(pattern, 1, ring=3), reader.iter_time_chunks(pattern, 1, ring=3)
+    seen_a, seen_b = [], []
+    for k in range(6):
+        ba, bb = next(a)[2], next(b)[2]
+        np.testing.assert_array_equal(ba, data[k: k + 1])
+        np.testing.assert_array_equal(bb, data[k: k + 1])
+        seen_a.append(ba.ctypes.data)
+        seen_b.append(bb.ctypes.data)
+    assert not set(seen_a) & set(seen_b)
+    assert len(set(seen_a)) == 3 and seen_a[:3] == seen_a[3:]  # overwritten after `ring` further chunks, not before
+    with pytest.raises(StopIteration):
+        next(a)
+    c = reader.iter_time_chunks(pattern, 1, ring=3)  # a's blocks are free again: c pins nothing new
+    assert next(c)[2].ctypes.data in set(seen_a)
+    c.close()
+    b.close()
+    assert sum(len(v) for v in reader._POOL._free.values()) == 6
+    reader.release_pinned()
+    # without a ring every chunk is a fresh array (list() of the iterator holds distinct blocks)
+    blocks = [blk for _, _, blk in reader.iter_time_chunks(pattern, 2)]
+    np.testing.assert_array_equal(np.concatenate(blocks), data)
+
+
+def test_host_read_runs(tmp_path):
+    """mg_host_read_runs (the native reader threads of the streamed ingest): byte runs of several files land where
+    they should, whatever the thread count; the end of a file and a bad descriptor are reported, not ignored."""
+    import ctypes
+
+    from magnify_amd import _native
+
+    rng = np.random.default_rng(1)
+    blobs = [rng.integers(0, 256, n, dtype=np.uint8) for n in (100_000, 20_000_000, 7)]
+    fds = []
+    for i, b in enumerate(blobs):
+        (tmp_path / f"f{i}.bin").write_bytes(b.tobytes())
+        fds.append(os.open(tmp_path / f"f{i}.bin", os.O_RDONLY))
+    runs = [(0, 0, 100_000), (1, 5, 19_999_990), (2, 0, 7), (1, 12_345, 1_000_001), (0, 99_999, 1), (2, 3, 0)]
+    for threads in (1, 3, 16):
+        outs = [np.zeros(n, dtype=np.uint8) for _, _, n in runs]
+        fd = np.array([fds[f] for f, _, _ in runs], dtype=np.int32)
+        off = np.array([o for _, o, _ in runs], dtype=np.int64)
+        nb = np.array([n for _, _, n in runs], dtype=np.int64)
+        dst = np.array([o.ctypes.data for o in outs], dtype=np.uint64)
+        assert _native.lib().mg_host_read_runs(fd.ctypes.data, off.ctypes.data, nb.ctypes.data, dst.ctypes.data, len(runs),
+                                               threads, None) == 0
+        for (f, o, n), got in zip(runs, outs):
+            np.testing.assert_array_equal(got, blobs[f][o: o + n])
+    failed = (ctypes.c_int64 * 2)(-1, -1)
+    nb[2] = 8  # one byte beyond the end of the 7-byte file
+    outs[2] = np.zeros(8, dtype=np.uint8)
+    dst[2] = outs[2].ctypes.data
+    assert _native.lib().mg_host_read_runs(fd.ctypes.data, off.ctypes.data, nb.ctypes.data, dst.ctypes.data, len(runs), 2,
+                                           ctypes.addressof(failed)) == -3
+    assert failed[0] == 2 and failed[1] == 0
+    assert _native.lib().mg_host_read_runs(fd.ctypes.data, off.ctypes.data, nb.ctypes.data, dst.ctypes.data, len(runs), 0, None) == -1
+    for f in fds:
+        os.close(f)
+    # through the TIFF layer: a truncated file is an error with the file's name in it
+    from tiffwrite import write_tiff
+
+    from magnify_amd import tiff
+
+    page = rng.integers(0, 60000, (64, 64)).astype(np.uint16)
+    write_tiff(tmp_path / "ok.tif", [page, page + 1])
+    with tiff.TiffFile(tmp_path / "ok.tif") as tif:
+        a, b = np.empty((64, 64), np.uint16), np.empty((64, 64), np.uint16)
+        tiff.read_pages([(tif, 0, a), (tif, 1, b)], workers=4)
+        np.testing.assert_array_equal(a, page)
+        np.testing.assert_array_equal(b, page + 1)
+        with pytest.raises(tiff.TiffError):
+            tiff.read_pages([(tif, 0, np.empty((64, 65), np.uint16))], workers=1)
+
+
+def test_lzw_megabyte_strip(tmp_path):
+    """the LZW decoder's bit accumulator is cut back after every code -- a strip of a megabyte decodes in
+    seconds (it was quadratic in the strip length)."""
+    import time
+
+    from PIL import Image
+
+    from magnify_amd import tiff
+
+    rng = np.random.default_rng(2)
+    img = (rng.integers(0, 4, (1024, 1024)) * 60).astype(np.uint8)  # compressible: long codes, frequent table resets
+    Image.fromarray(img).save(tmp_path / "lzw.tif", compression="tiff_lzw", tiffinfo={278: 1024})
+    with tiff.TiffFile(tmp_path / "lzw.tif") as tif:
+        assert tif.page(0).compression == 5 and max(tif.page(0).counts) > 100_000
+        t0 = time.perf_counter()
+        got = tif.asarray(0)
+        assert time.perf_counter() - t0 < 60
+    np.testing.assert_array_equal(got, img)
+
+
+def test_save_keeps_the_old_data_until_the_new_is_written(tmp_path, monkeypatch):
+    """mg.save writes everything under temporary names and removes what an earlier save left only after the
+    renames -- a failure in the middle of a multi-part save leaves the old file readable and no debris."""
+    import magnify_amd as mg
+    from magnify_amd import file as mgfile
+
+    old = mg.Dataset({"roi": mg.DataArray(np.arange(24, dtype=np.uint16).reshape(6, 4), ("mark", "x"))})
+    target = tmp_path / "res.nc"
+    mg.save(target, old)
+    new = mg.Dataset({"roi": mg.DataArray(np.arange(64, dtype=np.uint16).reshape(16, 4) + 100, ("mark", "x"))})
+    real, n = mgfile._write_nc, [0]
+
+    def failing(path, ds):
+        n[0] += 1
+        if n[0] == 3:
+            raise OSError("No space left on device")
+        real(path, ds)
+
+    monkeypatch.setattr(mgfile, "_write_nc", failing)
+    with pytest.raises(OSError):
+        mg.save(target, new, shard_bytes=32)  # four parts; the third fails
+    monkeypatch.setattr(mgfile, "_write_nc", real)
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["res.nc"]
+    np.testing.assert_array_equal(mg.load(target)["roi"].values, old["roi"].values)
+    mg.save(target, new, shard_bytes=32)
+    assert sorted(p.name for p in tmp_path.iterdir()) == [f"res.nc.part{k:03d}" for k in range(4)]
+    np.testing.assert_array_equal(mg.load(target)["roi"].values, new["roi"].values)
+    mg.save(target, old)  # back to one file: the parts go
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["res.nc"]

@@ -326,3 +326,53 @@ def test_beads_multichannel_subset_only(mg):
     xp = mg.beads(data=arr(mg, data, ("channel", "y", "x"), channel=["red", "green"]), min_bead_diameter=16,
                   max_bead_diameter=24, overlap=0, num_iter=1000, search_channel="red")
     assert isinstance(xp, mg.Dataset) and xp.roi.sizes["mark"] == 0
+
+
+def test_mrbles_front_half_on_float32_input(mg, tmp_path):
+    """identify.py:76-80 works on whatever dtype the images have (tests/test_beads.py:235-247 runs the
+    finder on float32).  mg.mrbles on float32 input: fg mean - bg median of time 0 from the device reductions (float32
+    medians by radix select on the bit pattern) equal the oracle's on the returned arrays; also with a second
+    timepoint whose pixels differ, which the result must not depend on (``assay.roi.isel(time=0)`` comes first)."""
+    rng = np.random.default_rng(6)
+    spectra = np.array([[1.0, 0.2], [0.1, 1.0]])  # (lanthanide, channel)
+    chans = ["c620", "c572"]
+    pos = [[120, 120], [120, 360], [360, 120], [360, 360]]
+    vols = rng.uniform(200, 900, size=(len(pos), 2))
+    data = np.zeros((2, 480, 480), dtype=np.float32)
+    for c in range(2):
+        inten = (vols @ spectra[:, c]).round().astype(int)
+        data[c] = draw_beads((480, 480), pos, 20, inten).astype(np.float32) + np.float32(100.25)
+    data += rng.normal(0, 0.5, size=data.shape).astype(np.float32)  # fractional values: the medians are no integers
+    sp_csv, codes_csv = tmp_path / "spectra.csv", tmp_path / "codes.csv"
+    sp_csv.write_text("name," + ",".join(chans) + "\n" + "eu," + ",".join(map(str, spectra[0])) + "\n" +
+                      "dy," + ",".join(map(str, spectra[1])) + "\n")
+    codes_csv.write_text("name,eu,dy\ncode0,1,0.5\ncode1,1,1.0\n")
+    kw = dict(spectra=str(sp_csv), codes=str(codes_csv), min_bead_diameter=16, max_bead_diameter=24, overlap=0, num_iter=20000)
+    pipe = mg.mrbles_pipe(**kw)
+    pipe.remove_pipe("restore_format")
+    mg.seed(77)
+    xp = pipe(arr(mg, data, ("channel", "y", "x"), channel=chans))
+    assert xp.roi.dtype == np.float32 and xp.roi.sizes["mark"] == len(pos)
+    roi = xp.roi.transpose("mark", "channel", "time", "roi_y", "roi_x").values
+    fg = xp.fg.transpose("mark", "time", "roi_y", "roi_x").values
+    bg = xp.bg.transpose("mark", "time", "roi_y", "roi_x").values
+    red = rp.roi_reduce(roi, fg, bg)
+    from magnify_amd import reduce
+
+    np.testing.assert_array_equal(reduce.masked_median(xp, "bg").data.cpu().numpy(), red["bg_median"])
+    np.testing.assert_array_equal(reduce.masked_median(xp, "fg").data.cpu().numpy(), red["fg_median"])
+    # the float sums of the masked-sum kernel are float64 accumulations of float32 pixels: the mean within 1e-12 relative
+    inten = (red["fg_mean"] - red["bg_median"])[:, :, 0]
+    want = np.linalg.lstsq(spectra.T, inten.T, rcond=None)[0].T
+    np.testing.assert_allclose(xp.ln_vol.values, want, rtol=1e-9)
+    # two timepoints, the second one different: same volumes as the first timepoint alone
+    two = np.stack([data, data[:, ::-1] * np.float32(0.5)], axis=1)  # (channel, time, y, x)
+    pipe = mg.mrbles_pipe(**kw)
+    pipe.remove_pipe("restore_format")
+    mg.seed(77)  # the same RNG stream: the same beads
+    xq = pipe(arr(mg, two, ("channel", "time", "y", "x"), channel=chans))
+    mg.seed(4321)
+    assert xq.sizes["time"] == 2 and xq.roi.sizes["mark"] == len(pos)
+    order_p = np.lexsort((xp.x.values[:, 0], xp.y.values[:, 0]))
+    order_q = np.lexsort((xq.x.values[:, 0], xq.y.values[:, 0]))
+    np.testing.assert_allclose(xq.ln_vol.values[order_q], xp.ln_vol.values[order_p], rtol=1e-9)

@@ -905,3 +905,87 @@ def test_flatfield_many_plane_groups(hp, dark):
             mm = minmax.cpu().numpy().reshape(n_t, n_c, 2)[t]
             np.testing.assert_array_equal(mm[:, 0], want.min(axis=(-1, -2)))
             np.testing.assert_array_equal(mm[:, 1], want.max(axis=(-1, -2)))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32, np.float64])
+def test_masked_median_types_and_time_masks(hp, dtype):
+    """mg_roi_masked_median (identify.py:76-80, filter.py:20-22, 74, 82): every roi dtype the path carries, a mask per
+    timepoint (a chip searched at several timesteps), one mask for all, a broadcast view -- against numpy's nanmedian on
+    the oracle's float64 copy (rp.roi_reduce), exactly.  Floats: negative values, +-0, infinities, NaN pixels (ignored,
+    as nanmedian ignores them), near-ties that differ in the last bit; even and odd counts; empty masks -> NaN."""
+    rng = np.random.default_rng(11)
+    m, c, t, L = 9, 3, 4, 17
+    if np.dtype(dtype).kind == "f":
+        roi = rng.normal(0, 50, size=(m, c, t, L, L)).astype(dtype)
+        roi[0] = np.where(rng.random((c, t, L, L)) < 0.5, dtype(7.25), np.nextafter(dtype(7.25), dtype(8)))  # one ulp apart
+        roi[1, :, :, ::3] = np.nan
+        roi[2, 0, 0, :4, :4] = [[-0.0, 0.0, np.inf, -np.inf]] * 4
+        roi[3] = np.abs(roi[3]) * 1e30 if dtype == np.float32 else np.abs(roi[3]) * 1e300
+        roi[4] = -np.abs(roi[4])
+    else:
+        hi = 255 if dtype == np.uint8 else 65535
+        roi = rng.integers(0, hi + 1, size=(m, c, t, L, L)).astype(dtype)
+        roi[0] = rng.integers(100, 103, size=(c, t, L, L))  # many ties
+        roi[3] = hi
+        roi[4] = 0
+    fg = rng.random((m, t, L, L)) < 0.4
+    bg = ~fg & (rng.random((m, t, L, L)) < 0.5)
+    fg[5] = False                       # empty masks
+    bg[5, 1] = False
+    fg[6, :, :, :] = False
+    fg[6, :, 3, 3] = True               # a single pixel
+    fg[7, 2] = False
+    fg[7, 2, :2, :1] = True             # two pixels: the mean of both
+    red = rp.roi_reduce(roi, fg, bg)
+    d_roi = dev(roi)
+    for name, mask in (("fg", fg), ("bg", bg)):
+        got = hp.masked_median(d_roi, dev(mask.view(np.uint8))).cpu().numpy()
+        np.testing.assert_array_equal(got, red[f"{name}_median"], err_msg=f"{name} per-time masks")
+    # one mask for all timepoints: as a 3-D mask, as (m, 1, L, L) and as an expanded (stride-0) view
+    one = fg[:, :1]
+    want = rp.roi_reduce(roi, np.broadcast_to(one, fg.shape), bg, medians=True)["fg_median"]
+    d_one = dev(one.view(np.uint8))
+    for mask in (d_one[:, 0], d_one, d_one.expand(m, t, L, L), d_one.bool()):
+        np.testing.assert_array_equal(hp.masked_median(d_roi, mask).cpu().numpy(), want)
+    if dtype == np.uint16:  # the round-1 entry point is the same kernel
+        np.testing.assert_array_equal(hp.masked_median_u16(d_roi, d_one[:, 0].contiguous()).cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        hp.masked_median(d_roi, dev(fg[:, :2].view(np.uint8)))
+    assert hp.masked_median(d_roi[:0], dev(fg[:0].view(np.uint8))).shape == (0, c, t)
+
+
+def test_graph_survives_regrown_buffers(hp):
+    """a captured chain bakes in the addresses AND the capacity of the output set, the claim ring, the
+    window histogram.  When one of them is made anew between two calls (more circles than the set holds; another
+    suppression distance) no old graph may be replayed -- whatever address the allocator hands the new buffer.
+    Compared call by call with a finder that launches eagerly."""
+    shape = (320, 384)
+    images = [np.stack([noisy_bead_image(900 + 10 * n + j, shape, 6)[0] for j in range(2)]) for n in range(12)]
+    buf = torch.empty((2,) + shape, dtype=torch.uint16, device="cuda")
+    cf = hp.CircleFinder(2, shape[0], shape[1], 5, 21, 60000)
+    ref = hp.CircleFinder(2, shape[0], shape[1], 5, 21, 60000)
+    ref._graphs = None
+    min_dist = 5
+    for n, planes in enumerate(images):
+        buf.copy_(dev(planes))
+        if n > 0:
+            cf._recent_sweeps[:], cf._recent_rounds[:] = [12], [12]
+            if cf.coords.shape[1] < 80000:
+                cf.coords = torch.empty((2, 80000, 2), dtype=torch.int32, device="cuda")
+        if n == 5:  # the output sets are dropped and made anew, larger (what a call with more circles does) ...
+            captured = cf.graph_captures
+            assert cf._graphs, "nothing was captured before the regrow"
+            old_cap = cf._out_cap
+            cf._out_buffers(3 * cf._out_cap)
+            assert cf._out_cap > old_cap and not cf._graphs  # ... and every graph went with them
+            torch.cuda.empty_cache()  # the freed sets' addresses are up for grabs
+        if n == 9:
+            min_dist = 7  # another claim ring: uploaded anew
+        seeds = [8000 + 2 * n, 8001 + 2 * n]
+        got, _ = cf.find(buf, None, 0.1, 0.9, 0.3, min_dist, seeds, stable_input=True)
+        want, _ = ref.find(buf, None, 0.1, 0.9, 0.3, min_dist, seeds)
+        for p in range(2):
+            np.testing.assert_array_equal(got[p][0], want[p][0], err_msg=f"call {n} plane {p}")
+            np.testing.assert_array_equal(got[p][1], want[p][1], err_msg=f"call {n} plane {p}")
+    assert "graph_error" not in cf.stats, cf.stats.get("graph_error")
+    assert cf.graph_captures > captured and cf.graph_replays >= 4, (cf.graph_captures, cf.graph_replays, cf.calls)
