@@ -10,6 +10,7 @@
 // Roofline: gather/latency bound (random reads of the angle map from L2 / Infinity Cache);
 // reported separately from the HBM-streaming stages.
 #include <math.h>
+#include <stdlib.h>
 
 #include "mg_common.h"
 
@@ -160,6 +161,138 @@ __global__ __launch_bounds__(NT) void k_candidates(const int32_t* __restrict__ d
   }
 }
 
+// ---- K7b: the same candidates, cheaper (round 4) ------------------------------------------------
+// What the iteration of k_candidates spends its vector instructions on, and what is done about it here:
+//  * p1 and p2 come from p0's grid cell, so (d_row, d_col) of a picked point relative to p0 is one of (2 grid - 1)^2
+//    integer pairs: the bisector's slope m = -d_col / (d_row + eps) and intercept b = d_row / 2 - m d_col / 2
+//    (utils.py:326-334) are TABLE ENTRIES -- computed once per workgroup with the reference's own float64 operations
+//    (the same division instruction sequence, so the same bits) and kept in LDS: two of the three float64 divisions
+//    and six float64 multiplies / subtracts per iteration become two 16-byte LDS reads;
+//  * the third division (the intersection, general operands) keeps the hardware's reciprocal / Newton / residual
+//    sequence but drops its range scaling (v_div_scale / v_div_fixup): the operands here lie within 2^+-140, where the
+//    scaling is the identity and the remaining operations are instruction for instruction those of `/`;
+//    a zero, infinite or NaN divisor takes `/` itself;
+//  * the stratum bounds floor(it E / K), floor((it + 1) E / K) are carried from iteration to iteration as
+//    (quotient, remainder) pairs -- integer adds and compares instead of two float64 quotients with corrections;
+//  * when the stratum holds one edge (E <= K: the usual case) p0 IS that edge and the first hash is not drawn at all
+//    (its product with a width of 1 is 0 whatever the hash).
+// Bit-identical to k_candidates<true> (tests/test_gpu_kernels.py compares the raw float32 triples with the oracle's,
+// NaN / inf included, and both kernels with each other).
+constexpr int CT = 1024;
+constexpr int MAX_TAB_GRID = 32;  // (2 * 32 - 1)^2 * 16 B = 63.5 KB of LDS
+
+__device__ __forceinline__ double div_unscaled(double num, double den) {
+  if (!(fabs(den) > 0.0 && fabs(den) < 1.0e300)) return num / den;  // 0, inf, NaN: the full sequence
+  double y = __builtin_amdgcn_rcp(den);
+  double e = fma(-den, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-den, y, 1.0);
+  y = fma(y, e, y);
+  double q = num * y;
+  const double r = fma(-den, q, num);
+  return fma(r, y, q);
+}
+
+__global__ __launch_bounds__(CT) void k_candidates_tab(const int32_t* __restrict__ d_coords, int64_t coord_cap,
+                                                       const int32_t* __restrict__ d_starts,
+                                                       const int32_t* __restrict__ d_counts,
+                                                       const int32_t* __restrict__ d_num_edges, int h, int w, int grid,
+                                                       int gc, int n_cells, const uint64_t* __restrict__ d_seeds,
+                                                       uint32_t num_iter, int min_r, int max_r,
+                                                       float* __restrict__ d_raw, uint32_t* __restrict__ d_keys) {
+  extern __shared__ double2 s_tab[];  // [(2 grid - 1)^2]: (m, b) of the bisector of p0 and p0 + (d_row, d_col)
+  const int plane = blockIdx.y;
+  const uint32_t n_edges = (uint32_t)d_num_edges[plane];
+  if (n_edges == 0) return;
+  const double eps = (double)1e-20f;
+  const int g1 = grid - 1, span = 2 * grid - 1;
+  for (int i = threadIdx.x; i < span * span; i += CT) {
+    const int dr = i / span - g1, dc = i - (i / span) * span - g1;
+    const double m = (double)(-dc) / ((double)dr + eps);
+    const double b = 0.5 * (double)dr - m * (0.5 * (double)dc);
+    s_tab[i] = make_double2(m, b);
+  }
+  __syncthreads();
+  const int32_t* coords = d_coords + (int64_t)plane * coord_cap * 2;
+  const int32_t* starts = d_starts + (int64_t)plane * n_cells;
+  const int32_t* counts = d_counts + (int64_t)plane * n_cells;
+  const uint64_t seed = d_seeds[plane];
+  const int ntc = (w + 2 * max_r + 63) >> 6;
+  uint32_t* keys = d_keys ? d_keys + (int64_t)plane * num_iter : nullptr;
+  const uint32_t K = num_iter;
+  const uint32_t it0 = blockIdx.x * CT + threadIdx.x, stride = gridDim.x * CT;
+  if (it0 >= K) return;
+  // E = eq K + er;  it E = sa K + rem  with  sa = it eq + floor(it er / K),  rem = (it er) mod K
+  const uint32_t eq = n_edges / K, er = n_edges - eq * K;
+  const double inv_k = 1.0 / (double)K;
+  const uint64_t x0 = (uint64_t)it0 * er;                     // < K E < 2^52 (launcher)
+  const uint64_t q0 = div_u64(x0, K, inv_k);
+  uint32_t sa = it0 * eq + (uint32_t)q0, rem = (uint32_t)(x0 - q0 * K);
+  const uint64_t xs = (uint64_t)stride * er;                  // < 2^20 K
+  const uint64_t qs = div_u64(xs, K, inv_k);
+  const uint32_t sa_step = stride * eq + (uint32_t)qs, rem_step = (uint32_t)(xs - qs * K);
+  uint64_t zbase = seed + ((uint64_t)it0 * 3ull + 1ull) * GOLDEN;
+  const uint64_t zstep = (uint64_t)stride * 3ull * GOLDEN;
+  const uint32_t gmagic = 0xFFFFFFFFu / (uint32_t)grid + 1u;  // exact for operands < 2^16
+  for (uint32_t it = it0; it < K; it += stride, zbase += zstep) {
+    // jittered stratified p0: iteration it owns the slice [sa, sb) of the cell-major edge list
+    const uint32_t sb = sa + eq + (rem + er >= K ? 1u : 0u);  // (rem, er < K < 2^31: no wrap)
+    uint32_t u0 = sa;
+    if (sb > sa + 1u) u0 = sa + __umulhi(mix_top32(zbase), sb - sa);
+    {  // the next iteration's (sa, rem)
+      const uint32_t t = rem + rem_step;
+      const bool carry = t >= K;
+      sa += sa_step + (carry ? 1u : 0u);
+      rem = carry ? t - K : t;
+    }
+    const int2 p0 = reinterpret_cast<const int2*>(coords)[u0];
+    const int p0r = p0.x, p0c = p0.y;
+    const int cell = (int)(__umulhi((uint32_t)p0r, gmagic) * (uint32_t)gc + __umulhi((uint32_t)p0c, gmagic));
+    const uint32_t cnt = (uint32_t)counts[cell];
+    const uint32_t base = (uint32_t)starts[cell];
+    const uint32_t i1 = base + __umulhi(mix_top32(zbase + GOLDEN), cnt);
+    const uint32_t i2 = base + __umulhi(mix_top32(zbase + 2ull * GOLDEN), cnt);
+    const int2 p1 = reinterpret_cast<const int2*>(coords)[i1], p2 = reinterpret_cast<const int2*>(coords)[i2];
+    const int d1r = p1.x - p0r, d1c = p1.y - p0c, d2r = p2.x - p0r, d2c = p2.y - p0c;
+    double m1, b1, m2, b2;
+    if ((uint32_t)(d1r + g1) < (uint32_t)span && (uint32_t)(d1c + g1) < (uint32_t)span &&
+        (uint32_t)(d2r + g1) < (uint32_t)span && (uint32_t)(d2c + g1) < (uint32_t)span) {
+      const double2 t1 = s_tab[(d1r + g1) * span + d1c + g1], t2 = s_tab[(d2r + g1) * span + d2c + g1];
+      m1 = t1.x, b1 = t1.y, m2 = t2.x, b2 = t2.y;
+    } else {  // (cannot happen with a cell-major list made by mg_edge_grid; kept so that no list can index beyond the table)
+      m1 = (double)(-d1c) / ((double)d1r + eps);
+      m2 = (double)(-d2c) / ((double)d2r + eps);
+      b1 = 0.5 * (double)d1r - m1 * (0.5 * (double)d1c);
+      b2 = 0.5 * (double)d2r - m2 * (0.5 * (double)d2c);
+    }
+    // intersection, each store rounds to float32 (utils.py:337-342)
+    const float c_col = (float)div_unscaled(b1 - b2, m2 - m1 + eps);
+    const float c_row = (float)(m1 * (double)c_col + b1);
+    const float rad = sqrtf(c_row * c_row + c_col * c_col);
+    const float f_row = (float)((double)c_row + (double)p0r);
+    const float f_col = (float)((double)c_col + (double)p0c);
+    if (d_raw) {
+      float* o = d_raw + ((int64_t)plane * num_iter + it) * 3;
+      o[0] = f_row;
+      o[1] = f_col;
+      o[2] = rad;
+    }
+    // filter_circles step 4 (utils.py:157-166)
+    uint32_t key = MG_NO_KEY;
+    do {
+      if (!(rad >= (float)min_r && rad <= (float)max_r)) break;
+      const float rr = rintf(f_row), rc = rintf(f_col);
+      if (!(fabsf(rr) < 1.0e9f && fabsf(rc) < 1.0e9f)) break;  // cannot be on the image (and NaN)
+      const int ir = (int)rr, ic = (int)rc, irad = (int)rintf(rad);
+      if (ir + irad < 0 || ic + irad < 0 || ir - irad >= h || ic - irad >= w) break;
+      const int pr = ir + max_r, pc = ic + max_r;
+      const int tile = (pr >> 6) * ntc + (pc >> 6);
+      key = ((uint32_t)tile << 17) | ((uint32_t)(irad - min_r) << 12) | (uint32_t)(((pr & 63) << 6) + (pc & 63));
+    } while (false);
+    if (keys) keys[it] = key;
+  }
+}
+
 // ---- K8: bitmap -> ordered unique circle list ---------------------------------------------------
 // One wave per 4096-bit layer (= one radius of one 64 x 64 centre tile): lane l owns tile row l
 // (64 bits).  Emission order = (tile_row, tile_col, r, row, col): the build's canonical order.
@@ -188,6 +321,7 @@ __global__ __launch_bounds__(NT) void k_layer_count(const uint32_t* __restrict__
 // the 6.1 ms candidates kernel.)
 constexpr int MAX_RANGES = 64;
 constexpr int DEDUP_TX = 2;
+constexpr int MG_DEDUP_DEFAULT = 12;  // TY * 10 + TX of the de-duplication's tile groups (mg_keys_to_circles)
 
 // TX = adjacent tiles of one tile row handled by a workgroup: the scanned cell ranges of neighbours
 // overlap by 2 * (max_r + 2) pixels, so wider groups read every key fewer times.
@@ -314,6 +448,143 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
     if (!bits) continue;
     const int t = wd / words;  // tile of the group; (wd - t * words) * 32 + bit = the key's low 17 bits
     const uint32_t hi = ((uint32_t)(tile0 + t) << 17) | ((uint32_t)(wd - t * words) << 5);
+    while (bits) {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      if (pos < circle_cap) out[pos] = hi | (uint32_t)b;
+      ++pos;
+    }
+  }
+}
+
+// The same de-duplication on SUPER-TILES of TY x TX centre tiles with NTH threads (round 4): the key ranges a group
+// scans cover its tiles plus the reach of a circle on every side, rounded to grid cells -- for 64 x 128 positions
+// (k_tile_dedup<2>) and a reach of 27 that is 140 x 220 pixels of cells, every key is looked at ~3.8 times; for 128 x 256
+// positions it is 200 x 320: ~1.95 times.  LDS: TY TX nr layers of 512 B (2 x 4 tiles, 21 radii: 86 KB, one
+// workgroup of 1024 per CU).  Tile slices, per-(tile, radius) starts and key order as k_tile_dedup.
+template <int TY, int TX, int NTH>
+__global__ __launch_bounds__(NTH) void k_tile_dedup_st(const uint32_t* __restrict__ d_keys, int64_t num_iter,
+                                                       const int32_t* __restrict__ d_starts,
+                                                       const int32_t* __restrict__ d_counts,
+                                                       const int32_t* __restrict__ d_num_edges, int h, int w, int grid,
+                                                       int gr, int gc, int ntr, int ntc, int nr, int max_r,
+                                                       uint32_t* __restrict__ d_ukeys, int64_t circle_cap,
+                                                       int32_t* __restrict__ d_tile_ranges, int n_tiles,
+                                                       int32_t* __restrict__ d_num_circles,
+                                                       int32_t* __restrict__ d_layer_starts) {
+  extern __shared__ uint32_t lbits[];  // [TY][TX][nr][LAYER_WORDS]
+  __shared__ long long s_lo[MAX_RANGES];
+  __shared__ int s_pre[MAX_RANGES + 1];
+  __shared__ int s_cnt[TY * TX * 32 + 1];  // circles per (tile, layer), then their exclusive prefix (nr <= 32)
+  __shared__ int s_base;
+  const int plane = blockIdx.z, tr0 = blockIdx.y * TY, tc0 = blockIdx.x * TX;
+  const int nty = min(TY, ntr - tr0), ntx = min(TX, ntc - tc0);  // tiles of this group that exist
+  const int tile0 = tr0 * ntc + tc0;
+  const int words = nr * LAYER_WORDS;  // per tile
+  for (int i = threadIdx.x; i < TY * TX * words; i += NTH) lbits[i] = 0u;
+  const long long n_edges = d_num_edges[plane];
+  const int reach = max_r + 2;  // p0 lies on the circle: within max_r + 1 of the rounded centre (one more for safety)
+  const int y0 = max(tr0 * TS - max_r - reach, 0), y1 = min((tr0 + nty) * TS - 1 - max_r + reach, h - 1);
+  const int x0 = max(tc0 * TS - max_r - reach, 0), x1 = min((tc0 + ntx) * TS - 1 - max_r + reach, w - 1);
+  int n_ranges = 0;
+  if (n_edges > 0 && y0 <= y1 && x0 <= x1) {
+    const int cr0 = y0 / grid, cr1 = y1 / grid, cc0 = x0 / grid, cc1 = x1 / grid;
+    n_ranges = cr1 - cr0 + 1;  // <= MAX_RANGES (checked by the launcher)
+    if ((int)threadIdx.x < n_ranges) {
+      const int32_t* starts = d_starts + (int64_t)plane * gr * gc;
+      const int32_t* counts = d_counts + (int64_t)plane * gr * gc;
+      const int cr = cr0 + threadIdx.x;
+      const long long ea = starts[cr * gc + cc0], eb = (long long)starts[cr * gc + cc1] + counts[cr * gc + cc1];
+      long long lo = 0, hi = 0;
+      if (eb > ea) {  // a conservative superset of the iterations whose stratum can touch [ea, eb)
+        const double kpe = (double)num_iter / (double)n_edges;
+        hi = min((long long)((double)eb * kpe) + 3, (long long)num_iter);
+        lo = min(max((long long)((double)ea * kpe) - 2, 0ll), hi);
+      }
+      s_lo[threadIdx.x] = lo;
+      s_pre[threadIdx.x + 1] = (int)(hi - lo);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_pre[0] = 0;
+    for (int r = 0; r < n_ranges; ++r) s_pre[r + 1] += s_pre[r];
+  }
+  __syncthreads();
+  const uint32_t* keys = d_keys + (int64_t)plane * num_iter;
+  constexpr int KB = 8;
+  for (int r = 0; r < n_ranges; ++r) {
+    const uint32_t* kr = keys + s_lo[r];
+    const int len = s_pre[r + 1] - s_pre[r];
+    for (int base = threadIdx.x; base < len; base += NTH * KB) {
+      uint32_t kv[KB];
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const int i = base + u * NTH;
+        kv[u] = i < len ? kr[i] : MG_NO_KEY;
+      }
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const uint32_t key = kv[u];
+        const uint32_t d = (key >> 17) - (uint32_t)tile0;  // wraps for keys of tiles before the group (and rejected ones)
+#pragma unroll
+        for (int ty = 0; ty < TY; ++ty) {
+          const uint32_t e = d - (uint32_t)(ty * ntc);     // column of the key's tile in tile row ty of the group
+          if (e < (uint32_t)ntx && ty < nty)
+            atomicOr(&lbits[(ty * TX + e) * words + ((key & 0x1FFFFu) >> 5)], 1u << (key & 31u));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ordered emission straight from LDS, as k_tile_dedup (slot lt = ty * TX + tx; slots of tiles beyond the image stay empty)
+  constexpr int n_slots = TY * TX;
+  const int n_li = n_slots * nr;
+  const int n_words = n_li * LAYER_WORDS;
+  const int per = (n_words + NTH - 1) / NTH;
+  const int w0 = min((int)threadIdx.x * per, n_words), w1 = min(w0 + per, n_words);
+  int mine = 0;
+  for (int wd = w0; wd < w1; ++wd) mine += __popc(lbits[wd]);
+  int n_unique;
+  const int ex = mg_block_exscan(mine, &n_unique);
+  {
+    int run = ex;
+    for (int wd = w0; wd < w1; ++wd) {
+      if ((wd & (LAYER_WORDS - 1)) == 0) s_cnt[wd / LAYER_WORDS] = run;  // first word of a layer
+      run += __popc(lbits[wd]);
+    }
+  }
+  if (threadIdx.x == 0) {
+    s_cnt[n_li] = n_unique;
+    s_base = n_unique ? atomicAdd(&d_num_circles[plane], n_unique) : 0;
+  }
+  __syncthreads();
+  const int64_t base = s_base;
+  if ((int)threadIdx.x < n_slots) {
+    const int ty = threadIdx.x / TX, tx = threadIdx.x - ty * TX;
+    if (ty < nty && tx < ntx) {
+      int32_t* tr2 = d_tile_ranges + ((int64_t)plane * n_tiles + tile0 + ty * ntc + tx) * 2;
+      tr2[0] = (int32_t)min(base + s_cnt[threadIdx.x * nr], circle_cap);
+      tr2[1] = s_cnt[(threadIdx.x + 1) * nr] - s_cnt[threadIdx.x * nr];
+    }
+  }
+  if (d_layer_starts) {
+    for (int i = threadIdx.x; i < n_slots * (nr + 1); i += NTH) {
+      const int lt = i / (nr + 1), ri = i - lt * (nr + 1);
+      const int ty = lt / TX, tx = lt - ty * TX;
+      if (ty < nty && tx < ntx)
+        d_layer_starts[((int64_t)plane * n_tiles + tile0 + ty * ntc + tx) * (nr + 1) + ri] =
+            (int32_t)min(base + s_cnt[lt * nr + ri], circle_cap);
+    }
+  }
+  uint32_t* out = d_ukeys + (int64_t)plane * circle_cap;
+  int64_t pos = base + ex;
+  for (int wd = w0; wd < w1; ++wd) {
+    uint32_t bits = lbits[wd];
+    if (!bits) continue;
+    const int lt = wd / words;
+    const int ty = lt / TX, tx = lt - ty * TX;
+    const uint32_t hi = ((uint32_t)(tile0 + ty * ntc + tx) << 17) | ((uint32_t)(wd - lt * words) << 5);
     while (bits) {
       const int b = __ffs(bits) - 1;
       bits &= bits - 1;
@@ -976,6 +1247,29 @@ int launch_candidates(const int32_t* d_coords, int64_t coord_cap, const int32_t*
   if (n_planes == 0 || num_iter == 0) return MG_OK;
   const int gr = (h + grid - 1) / grid, gc = (w + grid - 1) / grid;
   const bool fast = num_iter < (1ll << 31) && grid > 1 && h <= 65536 && w <= 65536;
+  // keys from the table kernel (round 4) unless MG_CANDIDATES_V1 is set (the tests compare the two) or the shape is
+  // outside its ranges: a grid cell above 32 (table size), a coordinate list of 2^31 entries
+  static const bool v1 = getenv("MG_CANDIDATES_V1") != nullptr;
+  if (fast && !v1 && d_keys && !d_bitmap && grid <= MAX_TAB_GRID && coord_cap < (1ll << 31)) {
+    // workgroups of 1024 that run ~32 iterations per lane (the table costs each lane 1.5 entries once), but at least
+    // ~1024 of them over all planes so that a single plane still fills the chip
+    const int64_t per_plane = (num_iter + CT - 1) / CT;
+    int64_t blocks = std::max<int64_t>((num_iter + 32 * CT - 1) / (32 * CT), (1024 + n_planes - 1) / n_planes);
+    blocks = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(blocks, per_plane), 1024));
+    const int span = 2 * grid - 1;
+    static bool tab_attr = false;
+    if (!tab_attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_candidates_tab), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (2 * MAX_TAB_GRID - 1) * (2 * MAX_TAB_GRID - 1) * (int)sizeof(double2)) != hipSuccess)
+        return MG_ELAUNCH;
+      tab_attr = true;
+    }
+    hipLaunchKernelGGL(k_candidates_tab, dim3((unsigned)blocks, n_planes), dim3(CT), (size_t)span * span * sizeof(double2),
+                       mg_stream(stream), d_coords, coord_cap, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gc,
+                       gr * gc, d_seeds, (uint32_t)num_iter, min_r, max_r, d_raw, d_keys);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+  }
   hipLaunchKernelGGL(fast ? k_candidates<true> : k_candidates<false>, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((num_iter + NT - 1) / NT, 2048)), n_planes), dim3(NT), 0,
                      mg_stream(stream), d_coords,
                      coord_cap, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gc, gr * gc, d_seeds, num_iter,
@@ -1058,6 +1352,32 @@ extern "C" int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, cons
   hipStream_t s = mg_stream(stream);
   if (ntr > 65535) return MG_EINVAL;
   if (!counters_clear && mg_zero_async(d_num_circles, (size_t)n_planes * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
+  // super-tiles (round 4): MG_DEDUP_SHAPE = 2x4 (128 x 256 positions, 1024 threads), 2x2 (512 threads), 1x2 (the round-1
+  // kernel: 64 x 128, 256 threads); whatever does not fit the LDS or the range table falls back to 1x2
+  static const char* shape_env = getenv("MG_DEDUP_SHAPE");
+  const int shape = shape_env ? (shape_env[0] - '0') * 10 + (shape_env[2] - '0') : MG_DEDUP_DEFAULT;
+  const size_t layer_bytes = (size_t)nr * LAYER_WORDS * 4;
+  static bool st_attr[2] = {false, false};
+  if ((shape == 24 || shape == 22) && !st_attr[shape == 24]) {  // dynamic LDS beyond the default limit
+    const void* fn = shape == 24 ? reinterpret_cast<const void*>(k_tile_dedup_st<2, 4, 1024>)
+                                 : reinterpret_cast<const void*>(k_tile_dedup_st<2, 2, 512>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess) return MG_ELAUNCH;
+    st_attr[shape == 24] = true;
+  }
+  if (shape == 24 && 8 * layer_bytes <= 120 * 1024 && (2 * TS + 2 * (max_r + 2)) / grid + 2 <= MAX_RANGES) {
+    hipLaunchKernelGGL((k_tile_dedup_st<2, 4, 1024>), dim3((ntc + 3) / 4, (ntr + 1) / 2, n_planes), dim3(1024), 8 * layer_bytes, s,
+                       d_keys, num_iter, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gr, gc, ntr, ntc, nr, max_r,
+                       d_unique_keys, circle_cap, d_tile_ranges, ntr * ntc, d_num_circles, d_layer_starts);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+  }
+  if (shape == 22 && 4 * layer_bytes <= 120 * 1024 && (2 * TS + 2 * (max_r + 2)) / grid + 2 <= MAX_RANGES) {
+    hipLaunchKernelGGL((k_tile_dedup_st<2, 2, 512>), dim3((ntc + 1) / 2, (ntr + 1) / 2, n_planes), dim3(512), 4 * layer_bytes, s,
+                       d_keys, num_iter, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gr, gc, ntr, ntc, nr, max_r,
+                       d_unique_keys, circle_cap, d_tile_ranges, ntr * ntc, d_num_circles, d_layer_starts);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+  }
   const int tx = DEDUP_TX;  // 1 / 2 / 4 measured: 4.4 / 4.1 / 5.4 ms per step for the whole compaction
   hipLaunchKernelGGL(k_tile_dedup<DEDUP_TX>,
                      dim3((ntc + tx - 1) / tx, ntr, n_planes), dim3(NT), (size_t)tx * nr * LAYER_WORDS * 4, s, d_keys,

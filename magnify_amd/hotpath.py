@@ -372,7 +372,7 @@ class CircleFinder:
         # hipGraphs of the optimistic chain (_optimistic_chain), by launch-sequence key
         self._graphs = None if os.environ.get("MG_NO_GRAPH") else {}
         self.graph_replays, self.graph_captures = 0, 0
-        self._graph_seen, self._in_stage = set(), None
+        self._graph_seen, self._in_stage, self._retired_graphs = set(), None, []
         self._round_spare = 0
         self._mm = torch.empty((P, 2), dtype=torch.float64, device=dev)
         self.words = 2 * ((h * w + 63) // 64) + 2  # bitmap words per plane (even, one spare)
@@ -677,7 +677,14 @@ class CircleFinder:
     def _drop_graphs(self):
         """Forget every captured chain: a buffer its launches have baked in was made anew."""
         if self._graphs:
-            self._graphs.clear()
+            if os.environ.get("MG_GRAPH_DESTROY"):
+                self._graphs.clear()
+            else:
+                # the forgotten graphs are kept alive until the finder goes (a handful over a finder's life: buffers
+                # regrow rarely): destroying a hipGraphExec between a replay and the next capture aborted the process
+                # on ROCm 7.2
+                self._retired_graphs.extend(self._graphs.values())
+                self._graphs.clear()
         self._graph_seen.clear()
 
     def _collect(self, bufs, min_dist, cleared=False):

@@ -42,13 +42,11 @@ class _Staging:
 
     def take(self, nbytes):
         with self._lock:
-            fit = [b for b in self._free if b.numel() >= nbytes]
+            fit = [i for i, b in enumerate(self._free) if b.numel() >= nbytes]
             if fit:
-                best = min(fit, key=lambda b: b.numel())
-                self._free.remove(best)
-                return best
+                return self._free.pop(min(fit, key=lambda i: self._free[i].numel()))
             if self._free:  # the largest free block is too small: it makes room for a larger one
-                self._free.remove(max(self._free, key=lambda b: b.numel()))
+                self._free.pop(max(range(len(self._free)), key=lambda i: self._free[i].numel()))
         return torch.empty((max(int(nbytes * 1.25), 1 << 20),), dtype=torch.uint8).pin_memory()
 
     def give(self, blocks):

@@ -364,7 +364,7 @@ def test_filters_on_a_chip_searched_at_two_timesteps(mg):
     from magnify_amd import reduce
 
     a = draw_chip((3, 3), 20)
-    b = draw_chip((3, 3), 20, offset=(10, 10))
+    b = draw_chip((3, 3), 28, offset=(10, 10))  # moved AND grown: other windows, other fg disks at time 1
     a[a > 0] = 3000
     rng = np.random.default_rng(8)
     data = (np.stack([a, b]).astype(np.int64) + rng.integers(90, 120, size=(2,) + a.shape)).astype(np.uint16)

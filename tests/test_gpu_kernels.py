@@ -989,3 +989,71 @@ def test_graph_survives_regrown_buffers(hp):
             np.testing.assert_array_equal(got[p][1], want[p][1], err_msg=f"call {n} plane {p}")
     assert "graph_error" not in cf.stats, cf.stats.get("graph_error")
     assert cf.graph_captures > captured and cf.graph_replays >= 4, (cf.graph_captures, cf.graph_replays, cf.calls)
+
+
+@pytest.mark.parametrize("num_iter", [3000, 200000])
+def test_candidates_degenerate_triplets(hp, num_iter):
+    """mg_candidate_keys on edge maps made of exactly the triplets that stress its arithmetic (VERDICT r3 item 3a;
+    utils.py:319-342): lone pixels (p1 = p2 = p0: 0 / eps), horizontal runs (d_row = 0: slopes of 1e20), vertical runs
+    (both slopes 0: the divisor is eps itself), diagonals (collinear: equal slopes, centres at 1e20 and beyond float32),
+    two-pixel cells, and a dense block where general triplets mix with all of these.  The round-4 kernel reads slope
+    and intercept from a per-workgroup LDS table and divides without range scaling; the raw float32 triples must equal
+    the oracle's BIT FOR BIT, NaN and infinities included, with fewer edges than iterations (strata of one edge: the
+    first hash is never drawn) and with more (num_iter 3000 < edges), and the keys must be those of the triples."""
+    from magnify_amd import _native as nat
+
+    h, w, grid, min_r, max_r = 200, 260, 20, 5, 14
+    e = np.zeros((3, h, w), dtype=np.uint8)
+    e[0, 10::40, 10::40] = 1                      # lone pixels
+    e[0, 5, 60:80] = 1                            # a horizontal run inside one cell row
+    e[0, 40:60, 7] = 1                            # a vertical run
+    e[0, np.arange(100, 120), np.arange(100, 120)] = 1   # a diagonal: collinear triplets
+    e[0, np.arange(140, 160), np.arange(59, 39, -1)] = 1  # the other diagonal
+    e[0, 181, 181] = e[0, 183, 190] = 1           # two pixels in a cell
+    rng = np.random.default_rng(5)
+    e[1] = rng.random((h, w)) < 0.2               # dense: general triplets (and every coincidence among them)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for cy, cx, r in ((60, 70, 9), (120, 180, 12), (150, 60, 6)):
+        e[2] |= (np.abs(np.hypot(yy - cy, xx - cx) - r) < 0.6).astype(np.uint8)  # true circles
+    e[2, 0, :] = e[2, :, 0] = e[2, h - 1, :] = e[2, :, w - 1] = 1  # the frame: centres off the image
+    P = e.shape[0]
+    gr, gc = -(-h // grid), -(-w // grid)
+    lists = [rn.grid_array(e[k], grid) for k in range(P)]
+    cap = max(len(c) for c, _, _ in lists)
+    coords = np.zeros((P, cap, 2), dtype=np.int32)
+    starts = np.zeros((P, gr, gc), dtype=np.int32)
+    counts = np.zeros((P, gr, gc), dtype=np.int32)
+    for k, (c, s, n) in enumerate(lists):
+        coords[k, : len(c)], starts[k], counts[k] = c, s, n
+    n_edges = np.array([len(c) for c, _, _ in lists], dtype=np.int32)
+    seeds = np.array([101, 102, 103], dtype=np.uint64)
+    d = {k: dev(v) for k, v in dict(coords=coords, starts=starts, counts=counts, n_edges=n_edges).items()}
+    d_seeds = torch.from_numpy(seeds.view(np.int64)).cuda()
+    keys = torch.empty((P, num_iter), dtype=torch.int32, device="cuda")
+    raw = torch.empty((P, num_iter, 3), dtype=torch.float32, device="cuda")
+    nat.check(nat.lib().mg_candidate_keys(d["coords"].data_ptr(), cap, d["starts"].data_ptr(), d["counts"].data_ptr(),
+                                          d["n_edges"].data_ptr(), P, h, w, grid, d_seeds.data_ptr(), num_iter, min_r, max_r,
+                                          keys.data_ptr(), raw.data_ptr(), torch.cuda.current_stream().cuda_stream),
+              "mg_candidate_keys")
+    got, got_keys = raw.cpu().numpy(), keys.cpu().numpy().view(np.uint32)
+    ntc = (w + 2 * max_r + 63) // 64
+    kinds = set()
+    for k in range(P):
+        picks = rn.draw_picks(int(seeds[k]), num_iter, e[k], grid)
+        want = rn.candidate_circles_from_picks(e[k], grid, *picks)
+        np.testing.assert_array_equal(got[k].view(np.uint32), want.view(np.uint32), err_msg=f"plane {k}")
+        kinds |= {"nan"} if np.isnan(want).any() else set()
+        kinds |= {"inf"} if np.isinf(want).any() else set()
+        kinds |= {"zero radius"} if (want[:, 2] == 0).any() else set()
+        kinds |= {"huge"} if (np.abs(want[np.isfinite(want).all(axis=1)]) > 1e15).any() else set()
+        # the keys: the reference's radius / on-image filter (utils.py:157-166) on the rounded triples
+        with np.errstate(invalid="ignore"):
+            ok = (want[:, 2] >= min_r) & (want[:, 2] <= max_r) & (np.abs(np.round(want[:, 0])) < 1e9) & (np.abs(np.round(want[:, 1])) < 1e9)
+            c = np.where(ok[:, None], np.round(want), 0).astype(np.int64)
+        ok &= (c[:, 0] + c[:, 2] >= 0) & (c[:, 1] + c[:, 2] >= 0) & (c[:, 0] - c[:, 2] < h) & (c[:, 1] - c[:, 2] < w)
+        pr, pc = c[:, 0] + max_r, c[:, 1] + max_r
+        key = (((pr >> 6) * ntc + (pc >> 6)) << 17) | ((c[:, 2] - min_r) << 12) | ((pr & 63) << 6) | (pc & 63)
+        np.testing.assert_array_equal(got_keys[k], np.where(ok, key, 0xFFFFFFFF).astype(np.uint32), err_msg=f"keys of plane {k}")
+        if k == 2:
+            assert ok.sum() > num_iter // 50  # the circles are found
+    assert {"zero radius", "huge"} <= kinds and ("nan" in kinds or "inf" in kinds), kinds
