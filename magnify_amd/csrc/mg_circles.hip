@@ -321,7 +321,6 @@ __global__ __launch_bounds__(NT) void k_layer_count(const uint32_t* __restrict__
 // the 6.1 ms candidates kernel.)
 constexpr int MAX_RANGES = 64;
 constexpr int DEDUP_TX = 2;
-constexpr int MG_DEDUP_DEFAULT = 12;  // TY * 10 + TX of the de-duplication's tile groups (mg_keys_to_circles)
 
 // TX = adjacent tiles of one tile row handled by a workgroup: the scanned cell ranges of neighbours
 // overlap by 2 * (max_r + 2) pixels, so wider groups read every key fewer times.
@@ -448,143 +447,6 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
     if (!bits) continue;
     const int t = wd / words;  // tile of the group; (wd - t * words) * 32 + bit = the key's low 17 bits
     const uint32_t hi = ((uint32_t)(tile0 + t) << 17) | ((uint32_t)(wd - t * words) << 5);
-    while (bits) {
-      const int b = __ffs(bits) - 1;
-      bits &= bits - 1;
-      if (pos < circle_cap) out[pos] = hi | (uint32_t)b;
-      ++pos;
-    }
-  }
-}
-
-// The same de-duplication on SUPER-TILES of TY x TX centre tiles with NTH threads (round 4): the key ranges a group
-// scans cover its tiles plus the reach of a circle on every side, rounded to grid cells -- for 64 x 128 positions
-// (k_tile_dedup<2>) and a reach of 27 that is 140 x 220 pixels of cells, every key is looked at ~3.8 times; for 128 x 256
-// positions it is 200 x 320: ~1.95 times.  LDS: TY TX nr layers of 512 B (2 x 4 tiles, 21 radii: 86 KB, one
-// workgroup of 1024 per CU).  Tile slices, per-(tile, radius) starts and key order as k_tile_dedup.
-template <int TY, int TX, int NTH>
-__global__ __launch_bounds__(NTH) void k_tile_dedup_st(const uint32_t* __restrict__ d_keys, int64_t num_iter,
-                                                       const int32_t* __restrict__ d_starts,
-                                                       const int32_t* __restrict__ d_counts,
-                                                       const int32_t* __restrict__ d_num_edges, int h, int w, int grid,
-                                                       int gr, int gc, int ntr, int ntc, int nr, int max_r,
-                                                       uint32_t* __restrict__ d_ukeys, int64_t circle_cap,
-                                                       int32_t* __restrict__ d_tile_ranges, int n_tiles,
-                                                       int32_t* __restrict__ d_num_circles,
-                                                       int32_t* __restrict__ d_layer_starts) {
-  extern __shared__ uint32_t lbits[];  // [TY][TX][nr][LAYER_WORDS]
-  __shared__ long long s_lo[MAX_RANGES];
-  __shared__ int s_pre[MAX_RANGES + 1];
-  __shared__ int s_cnt[TY * TX * 32 + 1];  // circles per (tile, layer), then their exclusive prefix (nr <= 32)
-  __shared__ int s_base;
-  const int plane = blockIdx.z, tr0 = blockIdx.y * TY, tc0 = blockIdx.x * TX;
-  const int nty = min(TY, ntr - tr0), ntx = min(TX, ntc - tc0);  // tiles of this group that exist
-  const int tile0 = tr0 * ntc + tc0;
-  const int words = nr * LAYER_WORDS;  // per tile
-  for (int i = threadIdx.x; i < TY * TX * words; i += NTH) lbits[i] = 0u;
-  const long long n_edges = d_num_edges[plane];
-  const int reach = max_r + 2;  // p0 lies on the circle: within max_r + 1 of the rounded centre (one more for safety)
-  const int y0 = max(tr0 * TS - max_r - reach, 0), y1 = min((tr0 + nty) * TS - 1 - max_r + reach, h - 1);
-  const int x0 = max(tc0 * TS - max_r - reach, 0), x1 = min((tc0 + ntx) * TS - 1 - max_r + reach, w - 1);
-  int n_ranges = 0;
-  if (n_edges > 0 && y0 <= y1 && x0 <= x1) {
-    const int cr0 = y0 / grid, cr1 = y1 / grid, cc0 = x0 / grid, cc1 = x1 / grid;
-    n_ranges = cr1 - cr0 + 1;  // <= MAX_RANGES (checked by the launcher)
-    if ((int)threadIdx.x < n_ranges) {
-      const int32_t* starts = d_starts + (int64_t)plane * gr * gc;
-      const int32_t* counts = d_counts + (int64_t)plane * gr * gc;
-      const int cr = cr0 + threadIdx.x;
-      const long long ea = starts[cr * gc + cc0], eb = (long long)starts[cr * gc + cc1] + counts[cr * gc + cc1];
-      long long lo = 0, hi = 0;
-      if (eb > ea) {  // a conservative superset of the iterations whose stratum can touch [ea, eb)
-        const double kpe = (double)num_iter / (double)n_edges;
-        hi = min((long long)((double)eb * kpe) + 3, (long long)num_iter);
-        lo = min(max((long long)((double)ea * kpe) - 2, 0ll), hi);
-      }
-      s_lo[threadIdx.x] = lo;
-      s_pre[threadIdx.x + 1] = (int)(hi - lo);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    s_pre[0] = 0;
-    for (int r = 0; r < n_ranges; ++r) s_pre[r + 1] += s_pre[r];
-  }
-  __syncthreads();
-  const uint32_t* keys = d_keys + (int64_t)plane * num_iter;
-  constexpr int KB = 8;
-  for (int r = 0; r < n_ranges; ++r) {
-    const uint32_t* kr = keys + s_lo[r];
-    const int len = s_pre[r + 1] - s_pre[r];
-    for (int base = threadIdx.x; base < len; base += NTH * KB) {
-      uint32_t kv[KB];
-#pragma unroll
-      for (int u = 0; u < KB; ++u) {
-        const int i = base + u * NTH;
-        kv[u] = i < len ? kr[i] : MG_NO_KEY;
-      }
-#pragma unroll
-      for (int u = 0; u < KB; ++u) {
-        const uint32_t key = kv[u];
-        const uint32_t d = (key >> 17) - (uint32_t)tile0;  // wraps for keys of tiles before the group (and rejected ones)
-#pragma unroll
-        for (int ty = 0; ty < TY; ++ty) {
-          const uint32_t e = d - (uint32_t)(ty * ntc);     // column of the key's tile in tile row ty of the group
-          if (e < (uint32_t)ntx && ty < nty)
-            atomicOr(&lbits[(ty * TX + e) * words + ((key & 0x1FFFFu) >> 5)], 1u << (key & 31u));
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // ordered emission straight from LDS, as k_tile_dedup (slot lt = ty * TX + tx; slots of tiles beyond the image stay empty)
-  constexpr int n_slots = TY * TX;
-  const int n_li = n_slots * nr;
-  const int n_words = n_li * LAYER_WORDS;
-  const int per = (n_words + NTH - 1) / NTH;
-  const int w0 = min((int)threadIdx.x * per, n_words), w1 = min(w0 + per, n_words);
-  int mine = 0;
-  for (int wd = w0; wd < w1; ++wd) mine += __popc(lbits[wd]);
-  int n_unique;
-  const int ex = mg_block_exscan(mine, &n_unique);
-  {
-    int run = ex;
-    for (int wd = w0; wd < w1; ++wd) {
-      if ((wd & (LAYER_WORDS - 1)) == 0) s_cnt[wd / LAYER_WORDS] = run;  // first word of a layer
-      run += __popc(lbits[wd]);
-    }
-  }
-  if (threadIdx.x == 0) {
-    s_cnt[n_li] = n_unique;
-    s_base = n_unique ? atomicAdd(&d_num_circles[plane], n_unique) : 0;
-  }
-  __syncthreads();
-  const int64_t base = s_base;
-  if ((int)threadIdx.x < n_slots) {
-    const int ty = threadIdx.x / TX, tx = threadIdx.x - ty * TX;
-    if (ty < nty && tx < ntx) {
-      int32_t* tr2 = d_tile_ranges + ((int64_t)plane * n_tiles + tile0 + ty * ntc + tx) * 2;
-      tr2[0] = (int32_t)min(base + s_cnt[threadIdx.x * nr], circle_cap);
-      tr2[1] = s_cnt[(threadIdx.x + 1) * nr] - s_cnt[threadIdx.x * nr];
-    }
-  }
-  if (d_layer_starts) {
-    for (int i = threadIdx.x; i < n_slots * (nr + 1); i += NTH) {
-      const int lt = i / (nr + 1), ri = i - lt * (nr + 1);
-      const int ty = lt / TX, tx = lt - ty * TX;
-      if (ty < nty && tx < ntx)
-        d_layer_starts[((int64_t)plane * n_tiles + tile0 + ty * ntc + tx) * (nr + 1) + ri] =
-            (int32_t)min(base + s_cnt[lt * nr + ri], circle_cap);
-    }
-  }
-  uint32_t* out = d_ukeys + (int64_t)plane * circle_cap;
-  int64_t pos = base + ex;
-  for (int wd = w0; wd < w1; ++wd) {
-    uint32_t bits = lbits[wd];
-    if (!bits) continue;
-    const int lt = wd / words;
-    const int ty = lt / TX, tx = lt - ty * TX;
-    const uint32_t hi = ((uint32_t)(tile0 + ty * ntc + tx) << 17) | ((uint32_t)(wd - lt * words) << 5);
     while (bits) {
       const int b = __ffs(bits) - 1;
       bits &= bits - 1;
@@ -1352,32 +1214,9 @@ extern "C" int mg_keys_to_circles(const uint32_t* d_keys, int64_t num_iter, cons
   hipStream_t s = mg_stream(stream);
   if (ntr > 65535) return MG_EINVAL;
   if (!counters_clear && mg_zero_async(d_num_circles, (size_t)n_planes * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
-  // super-tiles (round 4): MG_DEDUP_SHAPE = 2x4 (128 x 256 positions, 1024 threads), 2x2 (512 threads), 1x2 (the round-1
-  // kernel: 64 x 128, 256 threads); whatever does not fit the LDS or the range table falls back to 1x2
-  static const char* shape_env = getenv("MG_DEDUP_SHAPE");
-  const int shape = shape_env ? (shape_env[0] - '0') * 10 + (shape_env[2] - '0') : MG_DEDUP_DEFAULT;
-  const size_t layer_bytes = (size_t)nr * LAYER_WORDS * 4;
-  static bool st_attr[2] = {false, false};
-  if ((shape == 24 || shape == 22) && !st_attr[shape == 24]) {  // dynamic LDS beyond the default limit
-    const void* fn = shape == 24 ? reinterpret_cast<const void*>(k_tile_dedup_st<2, 4, 1024>)
-                                 : reinterpret_cast<const void*>(k_tile_dedup_st<2, 2, 512>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess) return MG_ELAUNCH;
-    st_attr[shape == 24] = true;
-  }
-  if (shape == 24 && 8 * layer_bytes <= 120 * 1024 && (2 * TS + 2 * (max_r + 2)) / grid + 2 <= MAX_RANGES) {
-    hipLaunchKernelGGL((k_tile_dedup_st<2, 4, 1024>), dim3((ntc + 3) / 4, (ntr + 1) / 2, n_planes), dim3(1024), 8 * layer_bytes, s,
-                       d_keys, num_iter, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gr, gc, ntr, ntc, nr, max_r,
-                       d_unique_keys, circle_cap, d_tile_ranges, ntr * ntc, d_num_circles, d_layer_starts);
-    MG_CHECK_LAUNCH();
-    return MG_OK;
-  }
-  if (shape == 22 && 4 * layer_bytes <= 120 * 1024 && (2 * TS + 2 * (max_r + 2)) / grid + 2 <= MAX_RANGES) {
-    hipLaunchKernelGGL((k_tile_dedup_st<2, 2, 512>), dim3((ntc + 1) / 2, (ntr + 1) / 2, n_planes), dim3(512), 4 * layer_bytes, s,
-                       d_keys, num_iter, d_cell_starts, d_cell_counts, d_num_edges, h, w, grid, gr, gc, ntr, ntc, nr, max_r,
-                       d_unique_keys, circle_cap, d_tile_ranges, ntr * ntc, d_num_circles, d_layer_starts);
-    MG_CHECK_LAUNCH();
-    return MG_OK;
-  }
+  // (round 4: super-tiles of 2 x 2 / 2 x 4 tiles on 512 / 1024 threads read every key 2.4 / 1.95 times instead of 3.8 and
+  // ran 2.81 / 4.12 ms against 1.90: with 43 / 86 KB of layers a CU holds two / one workgroup, and clearing, counting and
+  // emitting the layers -- not the key scan -- is where this kernel's instructions go; removed)
   const int tx = DEDUP_TX;  // 1 / 2 / 4 measured: 4.4 / 4.1 / 5.4 ms per step for the whole compaction
   hipLaunchKernelGGL(k_tile_dedup<DEDUP_TX>,
                      dim3((ntc + tx - 1) / tx, ntr, n_planes), dim3(NT), (size_t)tx * nr * LAYER_WORDS * 4, s, d_keys,

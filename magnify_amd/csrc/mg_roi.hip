@@ -42,7 +42,10 @@ __global__ __launch_bounds__(NT) void k_circle_labels(const int32_t* __restrict_
 
 // ---- ROI gather + masks + sums ------------------------------------------------------------------
 __device__ __forceinline__ void window(int c, int len, int size, int& lo) {
-  // utils.py:64-79 with an integer centre
+  // utils.py:64-79 with an integer centre.  Whatever the table holds, the window stays inside the image: a centre
+  // beyond +-2^28 (nothing an image can hold; what a NaN turns into when it is cast) is pulled in before the sums below
+  // could wrap.
+  c = min(max(c, -(1 << 28)), 1 << 28);
   int a = c - len / 2, b = c + (len - len / 2);
   if (a < 0) {
     b -= a;

@@ -246,8 +246,14 @@ def chamber_seeds(seed: int, m: int, k: int) -> np.ndarray:
 def _rounded_centres(y, x):
     """(m, 2) int32 [row, col] = round-half-to-even of the float positions, as Python's ``round`` gives them
     (find.py:316-317)."""
-    return np.stack([np.rint(np.asarray(y, dtype=np.float64).reshape(-1)), np.rint(np.asarray(x, dtype=np.float64).reshape(-1))],
-                    axis=1).astype(np.int32)
+    pos = np.stack([np.rint(np.asarray(y, dtype=np.float64).reshape(-1)), np.rint(np.asarray(x, dtype=np.float64).reshape(-1))], axis=1)
+    # a grid fit that degenerated (no circles, clusters without points: NaN slopes) ends here in the reference too:
+    # ``round(x[i, j])`` raises for NaN / infinity (find.py:326-327)
+    if np.isnan(pos).any():
+        raise ValueError("cannot convert float NaN to integer")
+    if np.isinf(pos).any() or (np.abs(pos) >= 2.0**30).any():
+        raise OverflowError("cannot convert float infinity to integer")
+    return pos.astype(np.int32)
 
 
 def _window_origin(c, L, size):

@@ -90,6 +90,7 @@ def set_timer(timer):
 _NO_TIMER = TIMER
 
 
+_SYNC_EVERY_CALL = bool(os.environ.get("MG_SYNC_CALLS"))
 _CAPTURING = False  # inside a stream capture (CircleFinder._capture_chain): no timing events
 
 
@@ -99,6 +100,11 @@ def _call(name, *args, stage=None):
         rc = getattr(nat.lib(), name)(*args)
         if rc:
             nat.check(rc, name)
+        if _SYNC_EVERY_CALL and not _CAPTURING:  # MG_SYNC_CALLS=1: a kernel that faults is named by the call it came from
+            import sys
+
+            print(f"[mg] {name}", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
         return
     with TIMER.stage(stage or name):
         nat.check(getattr(nat.lib(), name)(*args), name)
@@ -1271,6 +1277,8 @@ def masked_median(roi: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
             mask = mask.contiguous()
         sm, st = (mask.stride(0) if m > 1 else L * L), (mask.stride(1) if mask.shape[1] == t and t > 1 else 0)
     out = torch.empty((m, c, t), dtype=torch.float64, device=roi.device)
+    if m == 0:
+        return out
     _call("mg_roi_masked_median", roi.data_ptr(), nat.dtype_code(roi.dtype), mask.data_ptr(), sm, st, m, c, t, L,
           out.data_ptr(), _stream())
     return out

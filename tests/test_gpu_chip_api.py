@@ -364,7 +364,7 @@ def test_filters_on_a_chip_searched_at_two_timesteps(mg):
     from magnify_amd import reduce
 
     a = draw_chip((3, 3), 20)
-    b = draw_chip((3, 3), 28, offset=(10, 10))  # moved AND grown: other windows, other fg disks at time 1
+    b = draw_chip((3, 3), 24, offset=(10, 10))  # moved AND grown: other windows, other fg disks at time 1
     a[a > 0] = 3000
     rng = np.random.default_rng(8)
     data = (np.stack([a, b]).astype(np.int64) + rng.integers(90, 120, size=(2,) + a.shape)).astype(np.uint16)
@@ -426,3 +426,26 @@ def test_filters_on_a_chip_searched_at_two_timesteps(mg):
             want[i] &= empty[i + 1]
     np.testing.assert_array_equal(out.valid.values.reshape(9, -1)[:, 0], want)
     assert not want[0] and want[2] and not want[5] and not want[7] and want[4] and want[8]
+
+
+def test_degenerate_grid_fit_raises_like_the_reference(mg):
+    """A timestep on which no button is found (noise only) leaves the grid fit with NaN lines; the reference then fails
+    in ``round(x[i, j])`` (find.py:326-327: ValueError "cannot convert float NaN to integer").  So does this build --
+    before any window is gathered (a NaN cast to an integer centre once sent the gather kernel out of bounds)."""
+    rng = np.random.default_rng(8)
+    a = draw_chip((3, 3), 20)
+    data = (np.stack([a, np.zeros_like(a)]).astype(np.int64) + rng.integers(90, 120, size=(2,) + a.shape)).astype(np.uint16)
+    with pytest.raises(ValueError, match="NaN"):
+        mg.microfluidic_chip(data=chip(mg, data, ("time", "y", "x"), time=[0, 1]), shape=(3, 3), num_iter=5000,
+                             search_timestep=[0, 1], **KW)
+    # the kernel itself keeps any centre inside the image: rows of INT_MIN / INT_MAX (what a NaN or an infinity casts to)
+    import torch
+
+    from magnify_amd import hotpath
+
+    img = torch.from_numpy(rng.integers(0, 60000, size=(1, 1, 1, 200, 300)).astype(np.uint16)).cuda()
+    centres = np.array([[-2**31, 5], [2**31 - 1, 2**31 - 1], [100, -2**31], [0, 0], [199, 299]], dtype=np.int64).astype(np.int32)
+    out = hotpath.roi_gather_reduce(img, [centres], 72, None, want_masks=False, want_sums=False)["roi"].cpu().numpy()
+    host = img.cpu().numpy()[0, 0, 0]
+    for k, (top, left) in enumerate(((0, 0), (128, 228), (64, 0), (0, 0), (128, 228))):
+        np.testing.assert_array_equal(out[k, 0, 0], host[top: top + 72, left: left + 72])

@@ -1045,7 +1045,7 @@ def test_candidates_degenerate_triplets(hp, num_iter):
         kinds |= {"nan"} if np.isnan(want).any() else set()
         kinds |= {"inf"} if np.isinf(want).any() else set()
         kinds |= {"zero radius"} if (want[:, 2] == 0).any() else set()
-        kinds |= {"huge"} if (np.abs(want[np.isfinite(want).all(axis=1)]) > 1e15).any() else set()
+        kinds |= {"huge"} if (np.abs(want[np.isfinite(want)]) > 1e15).any() else set()  # centres of collinear triplets
         # the keys: the reference's radius / on-image filter (utils.py:157-166) on the rounded triples
         with np.errstate(invalid="ignore"):
             ok = (want[:, 2] >= min_r) & (want[:, 2] <= max_r) & (np.abs(np.round(want[:, 0])) < 1e9) & (np.abs(np.round(want[:, 1])) < 1e9)
