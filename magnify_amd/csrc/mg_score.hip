@@ -24,13 +24,10 @@
 //                its pass are not needed) --, a lane per survivor adds them in order with the reference-exact early
 //                exit; score stored float32; circles that pass go to d_alive.
 #include <math.h>
-#include <stdlib.h>
 
 #include <algorithm>
-#include <utility>
 
 #include "mg_common.h"
-#include "mg_pairs.h"
 
 namespace {
 
@@ -58,64 +55,50 @@ __device__ __forceinline__ uint32_t bits_at(const uint32_t* __restrict__ bits, i
   return n >= 32 ? v : (v & ((1u << n) - 1u));
 }
 
-// The pairs of opposite perimeter points of radius R, their table order and the plan of the run reads: mg_pairs.h.
+// First point (dr, dc) of every pair of opposite perimeter points of radius R, in the order of
+// mg_score_pair_table (mg_tables.hip: score_pairs) -- the reference's midpoint walk, utils.py:433-465.
+template <int R>
+struct Pairs {
+  int n;
+  int dr[MAXP], dc[MAXP];
+  constexpr Pairs() : n(0), dr{}, dc{} {
+    put(0, -R);
+    put(-R, 0);
+    int x = 1, y = -R;
+    while (x < -y) {
+      put(x, y);
+      put(y, x);
+      put(-x, y);
+      put(-y, x);
+      if (x * x + y * y - R * R <= 0) {
+        ++x;
+      } else {
+        ++y;
+        ++x;
+      }
+    }
+    if (y == -x) {
+      put(x, y);
+      put(-x, y);
+    }
+  }
+  constexpr void put(int a, int b) {
+    dr[n] = a;
+    dc[n] = b;
+    ++n;
+  }
+};
+
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
-// Adjacency (round 4): the points of the top and bottom arcs of a perimeter (|d_row| > |d_col|: half of all points)
-// lie in horizontal runs of consecutive bytes of one window row -- 3 in the outermost rows, up to 8 in the next ones.
-// A run is fetched by (unaligned) 4-byte LDS reads instead of one ds_read_u8 per point; a pair's two bytes then sit
-// in two registers T (the stretch holding its first point) and B (the stretch holding the opposite point, mirrored),
-// and ONE v_perm_b32 gathers the bytes of two pairs into the selector [t_j, t_j', b_j, b_j'] -- the table look-up of
-// pair j adds bytes 0 and 2 of its result, that of pair j' bytes 1 and 3.  The plan (mg_pairs.h) is evaluated at
-// compile time per radius; the table is stored in the plan's order, so a group's entries are consecutive scalar loads.
-template <int R, int SG>
-__device__ __forceinline__ void adj_group(const uint8_t* lds, int vaddr, const uint2* __restrict__ tabs, int& sum) {
-  constexpr MgPairPlan H(R);
-  constexpr int n = H.sg_n[SG], k0 = H.sg_first[SG];
-  const uint32_t T = reinterpret_cast<const MgUnaligned32*>(lds + vaddr + (BIAS + H.sg_trow[SG] * WSTR + H.sg_tcol[SG]))->v;
-  const uint32_t B = reinterpret_cast<const MgUnaligned32*>(lds + vaddr + (BIAS + H.sg_urow[SG] * WSTR + H.sg_ucol[SG]))->v;
-  {
-    constexpr int k1 = n > 1 ? k0 + 1 : k0;
-    // selector bytes [t(k0), t(k1), b(k0), b(k1)]: v_perm's source bytes 0-3 = T, 4-7 = B
-    constexpr uint32_t pick = (uint32_t)H.tb[k0] | ((uint32_t)H.tb[k1] << 8) | ((uint32_t)(4 + H.ub[k0]) << 16) |
-                              ((uint32_t)(4 + H.ub[k1]) << 24);
-    const uint32_t sel = __builtin_amdgcn_perm(B, T, pick);
-    const uint2 t0 = tabs[R * MAXP + k0];
-    sum = __builtin_amdgcn_sdot4((int)__builtin_amdgcn_perm(t0.y, t0.x, sel), 0x00010001, sum, false);
-    if constexpr (n > 1) {
-      const uint2 t1 = tabs[R * MAXP + k1];
-      sum = __builtin_amdgcn_sdot4((int)__builtin_amdgcn_perm(t1.y, t1.x, sel), 0x01000100, sum, false);
-    }
-  }
-  if constexpr (n > 2) {
-    constexpr int k2 = k0 + 2, k3 = n > 3 ? k0 + 3 : k2;
-    constexpr uint32_t pick = (uint32_t)H.tb[k2] | ((uint32_t)H.tb[k3] << 8) | ((uint32_t)(4 + H.ub[k2]) << 16) |
-                              ((uint32_t)(4 + H.ub[k3]) << 24);
-    const uint32_t sel = __builtin_amdgcn_perm(B, T, pick);
-    const uint2 t2 = tabs[R * MAXP + k2];
-    sum = __builtin_amdgcn_sdot4((int)__builtin_amdgcn_perm(t2.y, t2.x, sel), 0x00010001, sum, false);
-    if constexpr (n > 3) {
-      const uint2 t3 = tabs[R * MAXP + k3];
-      sum = __builtin_amdgcn_sdot4((int)__builtin_amdgcn_perm(t3.y, t3.x, sel), 0x01000100, sum, false);
-    }
-  }
-}
-
-template <int R, int... SG>
-__device__ __forceinline__ void adj_groups(const uint8_t* lds, int vaddr, const uint2* __restrict__ tabs, int& sum,
-                                           std::integer_sequence<int, SG...>) {
-  (adj_group<R, SG>(lds, vaddr, tabs, sum), ...);
-}
-
 // Sum of the bounds over the perimeter of the circle whose centre byte sits at lds[vaddr + BIAS].
-template <int R, bool ADJ>
+template <int R>
 __device__ __forceinline__ int score_r(const uint8_t* lds, int vaddr, const uint2* __restrict__ tabs) {
-  constexpr MgPairPlan P(R);
+  constexpr Pairs<R> P{};
   static_assert(P.n <= MAXP, "perimeter too long");
   int sum = 0;
-  if constexpr (ADJ) adj_groups<R>(lds, vaddr, tabs, sum, std::make_integer_sequence<int, P.n_sg>{});
 #pragma unroll
-  for (int k = ADJ ? P.n_h : 0; k < P.n; ++k) {
+  for (int k = 0; k < P.n; ++k) {
     const uint2 t = tabs[R * MAXP + k];  // uniform address: scalar loads
     const int off = P.dr[k] * WSTR + P.dc[k];
     us2 s;
@@ -138,8 +121,6 @@ static_assert((NSUB * SEGW + SEGW + 32 + 8) * 4 <= SURV_OFF, "small tables");
 // bits 0..3 of x -> bit 0 of bytes 0..3
 __device__ __forceinline__ uint32_t spread4(uint32_t x) { return ((x & 0xFu) * 0x00204081u) & 0x01010101u; }
 
-// (6 waves per SIMD = two workgroups per CU: the register budget the scheduler must keep to when it hoists the run reads)
-template <bool ADJ>
 __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d_bits, const uint32_t* __restrict__ d_class,
                                                   int64_t words_per_plane, int h, int w,
                                                   const uint32_t* __restrict__ d_ukeys, int64_t circle_cap,
@@ -287,7 +268,7 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
       const int vaddr = WBASE + wrow * WSTR + wcol - BIAS;
       int sum = 0;
       switch (rho + min_r) {
-#define MG_CASE(R) case R: sum = score_r<R, ADJ>(lds, vaddr, d_tabs); break;
+#define MG_CASE(R) case R: sum = score_r<R>(lds, vaddr, d_tabs); break;
           MG_CASE(2) MG_CASE(3) MG_CASE(4) MG_CASE(5) MG_CASE(6) MG_CASE(7) MG_CASE(8) MG_CASE(9) MG_CASE(10)
           MG_CASE(11) MG_CASE(12) MG_CASE(13) MG_CASE(14) MG_CASE(15) MG_CASE(16) MG_CASE(17) MG_CASE(18)
           MG_CASE(19) MG_CASE(20) MG_CASE(21) MG_CASE(22) MG_CASE(23) MG_CASE(24) MG_CASE(25) MG_CASE(26)
@@ -537,23 +518,19 @@ extern "C" int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angl
   if (!counters_clear && mg_zero_async(d_num_surv, (size_t)std::max(n_planes, 1) * sizeof(int32_t), s) != hipSuccess)
     return MG_ELAUNCH;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
-  const size_t lds_bytes = (size_t)WBASE + (size_t)(STY + 2 * max_r) * WSTR + 16;  // (+ 16: a 4-byte run read may end past the last row)
+  const size_t lds_bytes = (size_t)WBASE + (size_t)(STY + 2 * max_r) * WSTR;
   const int nsr = (ntr + SUBY - 1) / SUBY, nsc = (ntc + SUBX - 1) / SUBX, n_st = nsr * nsc;
   const int64_t total_st = (int64_t)n_st * n_planes;
-  // MG_PREFILTER_ADJ=0: one ds_read_u8 per perimeter point (rounds 2-3); default: the runs of the top / bottom arcs by
-  // 4-byte reads (round 4)
-  static const bool adj = !(getenv("MG_PREFILTER_ADJ") && getenv("MG_PREFILTER_ADJ")[0] == '0');
-  const auto kernel = adj ? k_prefilter<true> : k_prefilter<false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[adj]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(WBASE + (STY + 2 * MAXR) * WSTR + 16)) != hipSuccess)
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_prefilter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(WBASE + (STY + 2 * MAXR) * WSTR)) != hipSuccess)
       return MG_ELAUNCH;
-    attr_set[adj] = true;
+    attr_set = true;
   }
   // persistent blocks, super-tiles dealt round-robin (neighbouring super-tiles run at the same time)
   const int blocks = (int)std::min<int64_t>(total_st, 256 * 2 * 8);
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(NP), lds_bytes, s, d_edge_bits, d_class_bits, words_per_plane, h, w,
+  hipLaunchKernelGGL(k_prefilter, dim3(blocks), dim3(NP), lds_bytes, s, d_edge_bits, d_class_bits, words_per_plane, h, w,
                      d_unique_keys, circle_cap, d_layer_starts, ntr * ntc, ntr, ntc, nsc, n_st, total_st, min_r, max_r, nr,
                      reinterpret_cast<const uint2*>(d_pair_table), d_per_starts, min_roundness, write_skipped, d_scores,
                      d_surv_list, surv_cap, d_num_surv);

@@ -7,7 +7,6 @@
 #include <vector>
 
 #include "mg_common.h"
-#include "mg_pairs.h"
 
 namespace {
 
@@ -132,12 +131,29 @@ extern "C" int mg_perimeter_table(int min_r, int max_r, int32_t* out_rc, double*
 // rounding of the reference's angle (<= 2 ulp of pi) and a bin assignment made on the exact integer gradient.
 // -48 <= q <= 64.
 namespace {
-void score_pairs(int r, std::vector<int32_t>& out) {  // first point (dr, dc) of every pair, in table order (mg_pairs.h)
-  if (r > MG_SCORE_MAX_R) return;
-  const MgPairPlan plan(r);
-  for (int k = 0; k < plan.n && k < MG_SCORE_MAX_PAIRS; ++k) {
-    out.push_back(plan.dr[k]);
-    out.push_back(plan.dc[k]);
+void score_pairs(int r, std::vector<int32_t>& out) {  // first point (dr, dc) of every pair
+  auto put = [&](int a, int b) {
+    out.push_back(a);
+    out.push_back(b);
+  };
+  put(0, -r);
+  put(-r, 0);
+  int x = 1, y = -r;
+  while (x < -y) {
+    put(x, y);
+    put(y, x);
+    put(-x, y);
+    put(-y, x);
+    if (x * x + y * y - r * r <= 0) {
+      ++x;
+    } else {
+      ++y;
+      ++x;
+    }
+  }
+  if (y == -x) {
+    put(x, y);
+    put(-x, y);
   }
 }
 }  // namespace
