@@ -505,6 +505,12 @@ int mg_stream_probe(const void* d_src, void* d_dst, int64_t n_bytes, int mode, u
  * run's index, failed[1] = errno (0: end of file).  `failed` may be NULL. */
 int mg_host_read_runs(const int32_t* fds, const int64_t* offsets, const int64_t* nbytes, void* const* dsts, int n,
                       int n_threads, int64_t* failed);
+/* The mirror image for the results of a streamed run (accessor.py:18-35: the reference spills every assay's roi / fg / bg
+ * to a zarr store; here mg.save's NetCDF writer puts a variable's bytes -- already big-endian, swapped on the device --
+ * where the header says): run i = nbytes[i] bytes from srcs[i] (HOST pointers) to offsets[i] of the open file fds[i].
+ * Same threads, return values and `failed` as mg_host_read_runs. */
+int mg_host_write_runs(const int32_t* fds, const int64_t* offsets, const int64_t* nbytes, void* const* srcs, int n,
+                       int n_threads, int64_t* failed);
 
 #ifdef __cplusplus
 }

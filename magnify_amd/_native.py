@@ -77,6 +77,7 @@ PROTOTYPES = {
     "mg_stream_probe": [_p, _p, _l, _i, _p, _i, _p],
     "mg_masked_sums": [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p],
     "mg_host_read_runs": [_p, _p, _p, _p, _i, _i, _p],
+    "mg_host_write_runs": [_p, _p, _p, _p, _i, _i, _p],
 }
 
 RETURNS_INT64 = {"mg_scharr_hist_scratch_words", "mg_edge_grid_scan_words", "mg_flatfield_max_scratch_floats"}

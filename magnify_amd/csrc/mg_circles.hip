@@ -32,14 +32,17 @@ __device__ __forceinline__ uint32_t draw32(uint64_t seed, uint64_t it, uint32_t 
 // The finaliser alone: draw32(seed, it, k) == mix_top32(seed + (3 it + k + 1) * golden).
 constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ull;
 constexpr uint32_t MG_NO_KEY = 0xFFFFFFFFu;  // candidate rejected by the radius / on-image filter
-__device__ __forceinline__ uint32_t mix_top32(uint64_t z) {
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
   z ^= z >> 30;
   z *= 0xBF58476D1CE4E5B9ull;
   z ^= z >> 27;
   z *= 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 32);
+  return z ^ (z >> 31);
 }
+__device__ __forceinline__ uint32_t mix_top32(uint64_t z) { return (uint32_t)(mix64(z) >> 32); }
+// The three uniforms of iteration `it` (oracle/ref_numeric.py draw_uniform32): u0 = top half of mix64(seed + (3 it + 1) golden),
+// u1 and u2 = top and BOTTOM half of mix64(seed + (3 it + 2) golden) -- round 4: one finaliser for the two picks inside
+// p0's cell (the finaliser's 64-bit multiplies were a quarter of the candidate kernel's vector time).
 
 // floor(x / d) for an integer-valued double 0 <= x < 2^52 and d < 2^31 with floor(x / d) < 2^32:
 // float64 only (full rate), no 64-bit integer multiply.  r = x - q d is exact (a small integer).
@@ -114,8 +117,9 @@ __global__ __launch_bounds__(NT) void k_candidates(const int32_t* __restrict__ d
                            : (p0r / grid) * gc + (p0c / grid);
     const uint32_t cnt = (uint32_t)counts[cell];
     const int64_t base = starts[cell];
-    const int64_t i1 = base + (int64_t)__umulhi(mix_top32(zbase + GOLDEN), cnt);
-    const int64_t i2 = base + (int64_t)__umulhi(mix_top32(zbase + 2ull * GOLDEN), cnt);
+    const uint64_t z12 = mix64(zbase + GOLDEN);
+    const int64_t i1 = base + (int64_t)__umulhi((uint32_t)(z12 >> 32), cnt);
+    const int64_t i2 = base + (int64_t)__umulhi((uint32_t)z12, cnt);
     // p0-centred integer coordinates (utils.py:319-321); the slope numerator is negated as an
     // integer (as the reference does), so a zero stays +0.0
     const int d1r = coords[2 * i1] - p0r, d1c = coords[2 * i1 + 1] - p0c;
@@ -250,8 +254,9 @@ __global__ __launch_bounds__(CT) void k_candidates_tab(const int32_t* __restrict
     const int cell = (int)(__umulhi((uint32_t)p0r, gmagic) * (uint32_t)gc + __umulhi((uint32_t)p0c, gmagic));
     const uint32_t cnt = (uint32_t)counts[cell];
     const uint32_t base = (uint32_t)starts[cell];
-    const uint32_t i1 = base + __umulhi(mix_top32(zbase + GOLDEN), cnt);
-    const uint32_t i2 = base + __umulhi(mix_top32(zbase + 2ull * GOLDEN), cnt);
+    const uint64_t z12 = mix64(zbase + GOLDEN);
+    const uint32_t i1 = base + __umulhi((uint32_t)(z12 >> 32), cnt);
+    const uint32_t i2 = base + __umulhi((uint32_t)z12, cnt);
     const int2 p1 = reinterpret_cast<const int2*>(coords)[i1], p2 = reinterpret_cast<const int2*>(coords)[i2];
     const int d1r = p1.x - p0r, d1c = p1.y - p0c, d2r = p2.x - p0r, d2c = p2.y - p0c;
     double m1, b1, m2, b2;

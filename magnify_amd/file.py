@@ -17,6 +17,9 @@ restacked on load.
 """
 from __future__ import annotations
 
+import struct as _struct
+import sys as _sys
+
 import numpy as np
 
 from .xr_lite import DataArray, Dataset
@@ -34,8 +37,9 @@ def _encode(name, arr: np.ndarray):
         signed = {1: np.int8, 2: np.int16, 4: np.int32}.get(arr.dtype.itemsize)
         if signed is None:
             raise TypeError(f"{name}: uint64 cannot be stored in NetCDF-3")
-        arr, attrs["_Unsigned"] = arr.view(signed), "true"
-    elif arr.dtype == np.int64:
+        # (the byte order stays: a sink's block may already be big-endian, swapped on the device)
+        arr, attrs["_Unsigned"] = arr.view(np.dtype(signed).newbyteorder(arr.dtype.byteorder)), "true"
+    elif arr.dtype.kind == "i" and arr.dtype.itemsize == 8:
         if arr.size and (arr.min() < -(2**31) or arr.max() >= 2**31):
             raise ValueError(f"{name}: int64 values do not fit the int32 of NetCDF-3")
         arr = arr.astype(np.int32)
@@ -170,44 +174,159 @@ def _commit(file, named):
                 os.remove(final + tag)
 
 
-def _write_nc(file, ds):
-    from scipy.io import netcdf_file
+_NC_TYPE = {"i1": 1, "S1": 2, "i2": 3, "i4": 4, "f4": 5, "f8": 6}  # NC_BYTE, NC_CHAR, NC_SHORT, NC_INT, NC_FLOAT, NC_DOUBLE
+
+
+def _pad4(raw: bytes) -> bytes:
+    return raw + b"\x00" * (-len(raw) % 4)
+
+
+def _nc_name(name: str) -> bytes:
+    raw = name.encode("utf-8")
+    return _struct.pack(">i", len(raw)) + _pad4(raw)
+
+
+def _nc_attrs(attrs: dict) -> bytes:
+    """att_list: strings as NC_CHAR, Python / NumPy integers as NC_INT, floats as NC_DOUBLE (what scipy and xarray's
+    scipy engine write for them)."""
+    items = [(k, v) for k, v in attrs.items() if isinstance(v, (str, bytes, int, float, np.integer, np.floating))]
+    if not items:
+        return _struct.pack(">ii", 0, 0)  # ABSENT
+    out = [_struct.pack(">ii", 0x0C, len(items))]
+    for k, v in items:
+        out.append(_nc_name(k))
+        if isinstance(v, (str, bytes)):
+            raw = v.encode("utf-8") if isinstance(v, str) else v
+            out.append(_struct.pack(">ii", 2, len(raw)) + _pad4(raw))
+        elif isinstance(v, (bool, int, np.integer)):
+            out.append(_struct.pack(">iii", 4, 1, int(v)))
+        else:
+            out.append(_struct.pack(">iid", 6, 1, float(v)))
+    return b"".join(out)
+
+
+def _write_nc(file, ds, threads=None):
+    """One NetCDF-3 file (64-bit offsets, no record dimension), written directly: the header from the classic format's
+    grammar, then every variable's bytes at the offset the header names -- big-endian, as the format wants them.  An
+    array that already IS big-endian (``dtype.byteorder == '>'``: a sink's staging block whose bytes were swapped on the
+    device) or has one-byte items is written as it lies, in pieces, by the library's writer threads
+    (``mg_host_write_runs``); anything else is swapped into a scratch buffer chunk by chunk.  ``mg.load`` (scipy's
+    reader) and ``xarray.open_dataset`` read the result (same encoding conventions as before: ``_encode``)."""
+    import os
 
     coord_names = [k for k, c in ds.coords.items() if not (c.dims == (k,))]
-    with netcdf_file(str(file), "w", version=2) as nc:
-        def dim(name, size):
-            if name not in nc.dimensions:
-                nc.createDimension(name, int(size))
+    dims, variables = {}, []  # name -> size; (name, dims, array, attrs)
 
-        def put(name, v, is_data_var):
-            arr, extra, attrs = _encode(name, np.asarray(v.values))
-            dims = tuple(v.dims) + extra
-            for d, n in zip(dims, arr.shape):
-                dim(d, n)
-            var = nc.createVariable(name, "c" if arr.dtype.kind == "S" else arr.dtype, dims)
-            if arr.ndim:
-                var[...] = arr
-            else:
-                var.assignValue(arr)
-            for k, a in dict(v.attrs or {}, **attrs).items():
-                if isinstance(a, (str, bytes, int, float, np.integer, np.floating)):
-                    setattr(var, k, a)
-            if is_data_var:
-                mine = [c for c in coord_names if set(ds.coords[c].dims) <= set(v.dims)]
-                if mine:
-                    var.coordinates = " ".join(mine)
+    def put(name, v, is_data_var):
+        arr, extra, attrs = _encode(name, np.asarray(v.values))
+        vdims = tuple(v.dims) + extra
+        for d, n in zip(vdims, arr.shape):
+            if dims.setdefault(d, int(n)) != int(n):
+                raise ValueError(f"{name}: dimension {d} has {n} entries here and {dims[d]} elsewhere")
+        attrs = dict({k: a for k, a in dict(v.attrs or {}).items() if not k.startswith("__")}, **attrs)
+        if is_data_var:
+            mine = [c for c in coord_names if set(ds.coords[c].dims) <= set(v.dims)]
+            if mine:
+                attrs["coordinates"] = " ".join(mine)
+        variables.append((name, vdims, arr, attrs))
 
-        for k, v in ds.data_vars.items():
-            put(k, v, True)
-        for k, c in ds.coords.items():
-            put(k, c, False)
-        if coord_names:
-            nc.coordinates = " ".join(coord_names)
-        for k, a in ds.attrs.items():
-            if isinstance(a, (str, bytes, int, float, np.integer, np.floating)):
-                setattr(nc, k, a)
-            elif isinstance(a, (list, tuple)) and all(isinstance(x, str) for x in a):
-                setattr(nc, k, " ".join(a))
+    for k, v in ds.data_vars.items():
+        put(k, v, True)
+    for k, c in ds.coords.items():
+        put(k, c, False)
+    gattrs = {}
+    if coord_names:
+        gattrs["coordinates"] = " ".join(coord_names)
+    for k, a in ds.attrs.items():
+        if isinstance(a, (str, bytes, int, float, np.integer, np.floating)):
+            gattrs[k] = a
+        elif isinstance(a, (list, tuple)) and all(isinstance(x, str) for x in a):
+            gattrs[k] = " ".join(a)
+    dim_ids = {d: i for i, d in enumerate(dims)}
+
+    def header(begins):
+        out = [b"CDF\x02", _struct.pack(">i", 0)]
+        if dims:
+            out.append(_struct.pack(">ii", 0x0A, len(dims)))
+            out += [_nc_name(d) + _struct.pack(">i", n) for d, n in dims.items()]
+        else:
+            out.append(_struct.pack(">ii", 0, 0))
+        out.append(_nc_attrs(gattrs))
+        if variables:
+            out.append(_struct.pack(">ii", 0x0B, len(variables)))
+            for (name, vdims, arr, attrs), begin in zip(variables, begins):
+                kind = "S1" if arr.dtype.kind == "S" else f"{arr.dtype.kind}{arr.dtype.itemsize}"
+                vsize = arr.nbytes + (-arr.nbytes % 4)
+                out.append(_nc_name(name) + _struct.pack(">i", len(vdims)) + b"".join(_struct.pack(">i", dim_ids[d]) for d in vdims)
+                           + _nc_attrs(attrs) + _struct.pack(">iIq", _NC_TYPE[kind], min(vsize, 0xFFFFFFFF), begin))
+        else:
+            out.append(_struct.pack(">ii", 0, 0))
+        return b"".join(out)
+
+    head_len = len(header([0] * len(variables)))
+    begins, pos = [], head_len
+    for _, _, arr, _ in variables:
+        begins.append(pos)
+        pos += arr.nbytes + (-arr.nbytes % 4)
+    head = header(begins)
+    assert len(head) == head_len
+    fd = os.open(str(file), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        os.ftruncate(fd, pos)  # (the padding behind every variable reads as zeros)
+        os.pwrite(fd, head, 0)
+        runs, keep = [], []
+        for (_, _, arr, _), begin in zip(variables, begins):
+            if arr.nbytes == 0:
+                continue
+            if arr.dtype.itemsize > 1 and arr.dtype.byteorder != ">" and not (arr.dtype.byteorder == "=" and _sys.byteorder == "big"):
+                arr = arr.astype(arr.dtype.newbyteorder(">"))  # (not a sink's block: swapped here)
+            arr = np.ascontiguousarray(arr)
+            keep.append(arr)
+            flat = arr.reshape(-1).view(np.uint8)
+            for lo in range(0, flat.size, _PIECE):
+                runs.append((begin + lo, flat[lo: lo + _PIECE]))
+        _write_runs(fd, runs, threads)
+    finally:
+        os.close(fd)
+
+
+_PIECE = 8 << 20
+
+
+def _write_runs(fd, runs, threads=None):
+    """(file offset, uint8 array) pieces -> the file: by the library's writer threads when it is there, else one by one."""
+    import os
+
+    if not runs:
+        return
+    try:
+        from . import _native
+
+        lib = _native.lib()
+    except Exception:  # noqa: BLE001  (mg.save on a machine without the built library: plain positional writes)
+        lib = None
+    if lib is None or len(runs) == 1:
+        for off, piece in runs:
+            view, done = memoryview(piece), 0
+            while done < len(view):
+                done += os.pwrite(fd, view[done:], off + done)
+        return
+    import ctypes
+
+    n = len(runs)
+    fds = np.full(n, fd, dtype=np.int32)
+    offs = np.fromiter((r[0] for r in runs), dtype=np.int64, count=n)
+    lens = np.fromiter((r[1].size for r in runs), dtype=np.int64, count=n)
+    srcs = np.fromiter((r[1].ctypes.data for r in runs), dtype=np.uint64, count=n)
+    failed = (ctypes.c_int64 * 2)(-1, 0)
+    if threads is None:
+        threads = max(1, min(8, (os.cpu_count() or 1) // 2))
+    rc = lib.mg_host_write_runs(fds.ctypes.data, offs.ctypes.data, lens.ctypes.data, srcs.ctypes.data, n, int(threads),
+                                ctypes.addressof(failed))
+    if rc == -3:
+        raise OSError(int(failed[1]), f"{os.strerror(int(failed[1])) if failed[1] else 'short write'} (NetCDF payload, run {int(failed[0])})")
+    if rc != 0:
+        raise RuntimeError(f"mg_host_write_runs failed ({rc})")
 
 
 def load(file):

@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import queue
 import threading
+import time
 
 import numpy as np
 import torch
@@ -58,7 +59,9 @@ class _Sink:
     """``depth``: how many chunks may be on their way (copy in flight / being written) before ``__call__`` waits for
     the writer -- the GPU feed never waits for a file while the writer keeps up."""
 
-    copy_out = False  # True: the assays outlive the staging blocks (HostSink keeps them): copied out of them
+    copy_out = False    # True: the assays outlive the staging blocks (HostSink keeps them): copied out of them
+    big_endian = False  # True: multi-byte values are byte-swapped ON THE DEVICE before they travel (SaveSink: NetCDF-3 is
+                        # big-endian -- the writer then puts the staging block's bytes into the file as they lie)
 
     def __init__(self, want_roi=True, want_masks=True, depth=3):
         self.want_roi, self.want_masks = want_roi, want_masks
@@ -68,6 +71,9 @@ class _Sink:
         self._jobs = queue.Queue()
         self._writer = None
         self._error = None
+        # where the writer thread's time went (seconds): waiting for the device-to-host copy, building the assays'
+        # Datasets, `take` (HostSink: storing, SaveSink: mg.save); and how long __call__ waited for a free slot
+        self.stats = {"chunks": 0, "copy_wait_s": 0.0, "build_s": 0.0, "take_s": 0.0, "slot_wait_s": 0.0, "bytes": 0}
 
     # -- called by process_stream ---------------------------------------------------------------------------------
     def __call__(self, out):
@@ -76,7 +82,9 @@ class _Sink:
         self._raise_writer_error()
         dev_keys = [k for k in ("sums", "counts") + (("roi",) if self.want_roi else ()) + (("fg", "bg") if self.want_masks else ())
                     if out.get(k) is not None]
+        t0 = time.perf_counter()
         self._slots.acquire()
+        self.stats["slot_wait_s"] += time.perf_counter() - t0
         if self._writer is None:
             self._writer = threading.Thread(target=self._write_loop, daemon=True)
             self._writer.start()
@@ -85,23 +93,27 @@ class _Sink:
             self._side = torch.cuda.Stream()
         ready = torch.cuda.Event()
         ready.record(main)
-        host, blocks = {}, []
+        host, blocks, swapped = {}, [], set()
         self._side.wait_event(ready)
         with torch.cuda.stream(self._side):
             for k in dev_keys:
                 src = out[k]
                 if src.numel():
-                    block = self._staging.take(src.numel() * src.element_size())
+                    size = src.element_size()
+                    block = self._staging.take(src.numel() * size)
                     blocks.append(block)
-                    dst = block[: src.numel() * src.element_size()].view(src.dtype).view(src.shape)
-                    dst.copy_(src, non_blocking=True)
+                    dst = block[: src.numel() * size].view(src.dtype).view(src.shape)
                     src.record_stream(self._side)
+                    if self.big_endian and size > 1:  # (one gather kernel on the side stream, beside the next chunk's work)
+                        src = src.contiguous().view(torch.uint8).view(-1, size).flip(1).view(src.dtype).view(src.shape)
+                        swapped.add(k)
+                    dst.copy_(src, non_blocking=True)
                 else:
                     dst = torch.empty(src.shape, dtype=src.dtype)
                 host[k] = dst
             done = torch.cuda.Event()
             done.record(self._side)
-        meta = {"beads": [np.asarray(b) for b in out["beads"]], "offsets": np.asarray(out["offsets"]),
+        meta = {"beads": [np.asarray(b) for b in out["beads"]], "offsets": np.asarray(out["offsets"]), "swapped": swapped,
                 "first": int(out.get("first_timepoint", 0)), "time": out.get("time"), "channel": out.get("channel")}
         self._jobs.put((done, host, meta, blocks))
         return done  # process_stream makes the chunk after next wait for it (that one reuses these device buffers)
@@ -137,13 +149,27 @@ class _Sink:
 
     # -- per assay ---------------------------------------------------------------------------------------------------
     def _finish(self, done, host, meta):
+        t0 = time.perf_counter()
         done.synchronize()
+        t1 = time.perf_counter()
         arrays = {k: (np.array(v.numpy()) if self.copy_out else v.numpy()) for k, v in host.items()}
+        for k in meta["swapped"]:  # the block's bytes are big-endian: say so in the dtype (the values read correctly)
+            arrays[k] = arrays[k].view(arrays[k].dtype.newbyteorder(">"))
         off = meta["offsets"]
+        st = self.stats
+        st["chunks"] += 1
+        st["copy_wait_s"] += t1 - t0
+        st["bytes"] += sum(v.nbytes for v in arrays.values())
+        st["build_s"] += time.perf_counter() - t1
         for a, beads in enumerate(meta["beads"]):
             lo, hi = int(off[a]), int(off[a + 1])
-            self.take(meta["first"] + a, self.assay_dataset(beads, {k: v[lo:hi] for k, v in arrays.items()},
-                                                            None if meta["time"] is None else meta["time"][a], meta["channel"]))
+            t2 = time.perf_counter()
+            ds = self.assay_dataset(beads, {k: v[lo:hi] for k, v in arrays.items()},
+                                    None if meta["time"] is None else meta["time"][a], meta["channel"])
+            t3 = time.perf_counter()
+            self.take(meta["first"] + a, ds)
+            st["build_s"] += t3 - t2
+            st["take_s"] += time.perf_counter() - t3
 
     @staticmethod
     def assay_dataset(beads, arrays, time_label=None, channels=None):
@@ -194,6 +220,8 @@ class HostSink(_Sink):
 
 class SaveSink(_Sink):
     """Every assay written with ``mg.save`` to ``pattern.format(index=...)`` as soon as it is on the host."""
+
+    big_endian = True
 
     def __init__(self, pattern, want_roi=True, want_masks=True, shard_bytes=None, depth=3):
         super().__init__(want_roi, want_masks, depth)

@@ -288,6 +288,13 @@ def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False,
 
     producer = threading.Thread(target=produce, daemon=True)
     producer.start()
+    # Three Python threads (reader, this one, the sink's writer) share the interpreter lock; with the default switch
+    # interval of 5 ms a thread that comes back from a native call can wait that long for a thread busy in bytecode --
+    # longer than a whole timepoint takes on the GPU.  A short interval for the duration of the stream.
+    import sys
+
+    old_interval = sys.getswitchinterval()
+    sys.setswitchinterval(min(old_interval, 2e-4))
     procs, done, n_chunk, copied = {}, int(first_timepoint), 0, [None, None]
     try:
         while True:
@@ -328,6 +335,7 @@ def process_stream(chunks, flatfield=1.0, darkfield=0.0, seed=0, want_roi=False,
             yield out
     finally:
         cancelled.set()
+        sys.setswitchinterval(old_interval)
         if sink is not None:
             sink.close()
 

@@ -408,8 +408,10 @@ static inline uint64_t mix64(uint64_t z) {
 }
 /* k-th (0,1,2) 32-bit uniform of iteration it: oracle/ref_numeric.py draw_uniform32 */
 uint32_t ref_draw_uniform32(uint64_t seed, uint64_t it, int k) {
-  const uint64_t ctr = it * 3ull + (uint64_t)(k + 1);
-  return (uint32_t)(mix64(seed + ctr * 0x9E3779B97F4A7C15ull) >> 32);
+  /* k = 0: top half at counter 3 it + 1; k = 1, 2: top / bottom half at counter 3 it + 2 */
+  const uint64_t ctr = it * 3ull + (k == 0 ? 1ull : 2ull);
+  const uint64_t z = mix64(seed + ctr * 0x9E3779B97F4A7C15ull);
+  return k == 2 ? (uint32_t)z : (uint32_t)(z >> 32);
 }
 
 /* Circle through p0, p1, p2 in the reference's arithmetic (utils.py:319-342); out = row, col, r. */

@@ -330,12 +330,13 @@ def _mix64(z: np.ndarray) -> np.ndarray:
 
 
 def draw_uniform32(seed: int, it: np.ndarray, k: int) -> np.ndarray:
-    """k-th (k = 0, 1, 2) 32-bit uniform of iteration ``it`` for plane seed ``seed``:
-    top half of splitmix64's finaliser applied to seed + (3*it + k + 1) * golden."""
+    """k-th (k = 0, 1, 2) 32-bit uniform of iteration ``it`` for plane seed ``seed``: splitmix64's finaliser applied
+    to seed + (3*it + c) * golden -- k = 0: the top half at counter c = 1; k = 1 and k = 2: the top and the bottom half
+    at counter c = 2 (one finaliser for the two picks inside p0's cell; counter c = 3 is not used)."""
     with np.errstate(over="ignore"):
-        ctr = np.asarray(it, dtype=np.uint64) * np.uint64(3) + np.uint64(k + 1)
-        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + ctr * _GOLDEN
-        return _mix64(z) >> np.uint64(32)
+        ctr = np.asarray(it, dtype=np.uint64) * np.uint64(3) + np.uint64(1 if k == 0 else 2)
+        z = _mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + ctr * _GOLDEN)
+        return (z & np.uint64(0xFFFFFFFF)) if k == 2 else (z >> np.uint64(32))
 
 
 def stratum(it: np.ndarray, n_edges: int, num_iter: int):

@@ -125,8 +125,18 @@ def main():
             return mg.SaveSink(os.path.join(save_dir, "t{index:05d}.nc"), want_roi=args.want_roi, want_masks=args.want_roi)
         return None
 
+    sink_stats = {}
+
     def run():
         sink = make_sink()
+        try:
+            return stream(sink)
+        finally:
+            if sink is not None:
+                sink_stats.clear()
+                sink_stats.update({k: round(v, 4) if isinstance(v, float) else v for k, v in sink.stats.items()})
+
+    def stream(sink):
         if pattern:
             table, _ = mgd.stream_series(pattern, args.chunk, flat, 100.0, seed=7, sink=sink, rank=rank, world=world,
                                          workers=workers, overlap=ov, want_roi=args.want_roi, **kw)
@@ -179,6 +189,7 @@ def main():
                       "shared_gpu": os.environ.get("MG_SHARE_GPU") == "1", "timepoints_per_rank": hi - lo},
             "seconds": dt, "ms_per_timepoint": 1e3 * dt / T, "stitched_MPs": T * C * h * w / dt / 1e6,
             "host_to_device_GBs": tile_bytes / dt / 1e9, "markers": markers, "markers_per_s": markers / dt,
+            "sink_writer": sink_stats or None,
             "reader_alone": None if reader_s is None else {"seconds": reader_s, "ms_per_timepoint": 1e3 * reader_s / T,
                                                            "GBs": tile_bytes / reader_s / 1e9, "workers_per_rank": workers}}))
     if world > 1:
