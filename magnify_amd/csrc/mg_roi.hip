@@ -5,6 +5,8 @@
 // bytes (u16); the reductions ride along in registers (wavefront shuffles), 0 extra bytes.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "mg_common.h"
 
 namespace {
@@ -488,6 +490,286 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
   }
 }
 
+// ---- image-centric ROI pass (round 4): every image line is fetched once ----------------------------------------
+// The window-centric kernel above reads 200-byte window rows at arbitrary alignment: a row touches 2.56 lines of 128 B
+// (measured 15.7 GB fetched for 9.7 GB of window pixels at C4), and pixels shared by overlapping windows are fetched
+// again by each of them -- an L2 of 4 MB per XCD does not keep a line for the ~20 us until a neighbouring window of
+// another workgroup comes by.  Here a workgroup owns a TILE of RT_H x RT_W pixels of one assay: it loads the tile's
+// (channel, time) planes -- RT_CT at a time -- into LDS with full, aligned lines, finds the windows that reach into the
+// tile (a scan of the assay's bead table) and serves every one of them its FRAGMENT from LDS: roi pixels and mask
+// bytes to their places in the marker's outputs, masked sums and counts by atomic adds (integer sums below 2^53 are
+// exact in float64 whatever the order).  Masks as in the window kernel: fg = own disk and no other disk, bg = no disk
+// (utils.py:380-395 / find.py:571-586), from tile-wide any / multi bit maps.
+constexpr int RT_H = 16, RT_W = 384, RT_WPR = RT_W / 32;  // tile rows / pixels / words per bit row
+constexpr int RT_CT = 4;                                  // planes in LDS at a time (RT_CT * RT_H * RT_W * 2 B = 48 KB)
+constexpr int RT_F = 16;                                  // fragments per round (their mask rows are held in LDS)
+constexpr int RT_IDS = 2048;                              // windows reaching into one tile, at most (launcher: <= beads per assay)
+// (LDS per workgroup: 48 + 1.5 + 8 + 4 KB and ~2.5 KB of descriptors: two workgroups per CU -- one loads while the
+// other serves)
+constexpr int RT_DISKS = 128;                             // disks reaching into one tile that are drawn row-parallel
+
+struct RtFrag {
+  int g;             // marker (row of the outputs)
+  int top, left;     // window origin in the image
+  int yj, xj, rj;    // its own disk
+  int r0, r1;        // tile rows [r0, r1) the window covers
+};
+
+__global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict__ d_image, int64_t assay_stride, int n_c,
+                                                      int n_t, int h, int w, const int32_t* __restrict__ d_beads,
+                                                      int64_t bead_stride, const int32_t* __restrict__ d_assay_offsets,
+                                                      int time_major, int len, const int32_t* __restrict__ d_halfwidths,
+                                                      int max_r, uint16_t* __restrict__ d_roi, uint8_t* __restrict__ d_fg,
+                                                      uint8_t* __restrict__ d_bg, double* __restrict__ d_sums,
+                                                      int32_t* __restrict__ d_counts) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t rt_smem[];
+  uint32_t* s_tile = reinterpret_cast<uint32_t*>(rt_smem);                       // [RT_CT][RT_H][RT_W / 2] pixel pairs
+  uint32_t* s_any = s_tile + RT_CT * RT_H * (RT_W / 2);                          // [RT_H][RT_WPR]
+  uint32_t* s_multi = s_any + RT_H * RT_WPR;                                     // [RT_H][RT_WPR]
+  uint32_t* s_fg = s_multi + RT_H * RT_WPR;                                      // [RT_F][RT_H][4]
+  uint32_t* s_bg = s_fg + RT_F * RT_H * 4;                                       // [RT_F][RT_H][4]
+  uint16_t* s_ids = reinterpret_cast<uint16_t*>(s_bg + RT_F * RT_H * 4);         // [RT_IDS]
+  __shared__ int s_nfrag, s_ndisk;
+  __shared__ int s_disk[RT_DISKS][3];
+  __shared__ RtFrag s_frag[RT_F];
+  __shared__ int s_cnt[RT_F][2];
+  const int assay = blockIdx.z, tx0 = blockIdx.x * RT_W, ty0 = blockIdx.y * RT_H;
+  const int tw = min(RT_W, w - tx0), th = min(RT_H, h - ty0);
+  const int first = d_assay_offsets[assay], nb = d_assay_offsets[assay + 1] - first;
+  if (nb <= 0) return;
+  const int32_t* beads = d_beads + 3 * (bead_stride ? (int64_t)assay * bead_stride : (int64_t)first);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int WV = NT / 64;
+  for (int i = threadIdx.x; i < 2 * RT_H * RT_WPR; i += NT) s_any[i] = 0u;  // (any and multi are adjacent)
+  if (threadIdx.x == 0) s_nfrag = 0, s_ndisk = 0;
+  __syncthreads();
+  // ---- 1. the assay's beads: whose window reaches into the tile, whose disk does ----
+  const int side = 2 * max_r + 1;
+  auto draw_row = [&](int r, int yj, int xj, int rj) {  // row r of the tile under the disk
+    const int dy = ty0 + r - yj;
+    if (dy < -rj || dy > rj) return;
+    const int hwid = d_halfwidths[(int64_t)rj * side + dy + rj];
+    if (hwid < 0) return;
+    const int xa = max(xj - hwid, tx0) - tx0, xb = min(xj + hwid, tx0 + tw - 1) - tx0;
+    for (int wd = xa >> 5; xa <= xb && wd <= (xb >> 5); ++wd) {
+      const int lo = max(xa, 32 * wd) - 32 * wd, hi = min(xb, 32 * wd + 31) - 32 * wd;
+      const uint32_t bits = (hi - lo == 31) ? 0xFFFFFFFFu : (((1u << (hi - lo + 1)) - 1u) << lo);
+      const uint32_t old = atomicOr(&s_any[r * RT_WPR + wd], bits);
+      if (old & bits) atomicOr(&s_multi[r * RT_WPR + wd], old & bits);
+    }
+  };
+  constexpr int UB = 4;
+  for (int b0 = 0; b0 < nb; b0 += NT * UB) {
+    int yy[UB], xx[UB], rr[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int j = b0 + u * NT + (int)threadIdx.x;
+      yy[u] = xx[u] = 0;
+      rr[u] = -1;
+      if (j < nb) yy[u] = beads[3 * j], xx[u] = beads[3 * j + 1], rr[u] = beads[3 * j + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int j = b0 + u * NT + (int)threadIdx.x;
+      if (j >= nb) continue;
+      const int yj = yy[u], xj = xx[u], rj = rr[u];
+      int top, left;
+      window(yj, len, h, top);
+      window(xj, len, w, left);
+      if (top < ty0 + th && top + len > ty0 && left < tx0 + tw && left + len > tx0) {
+        const int k = atomicAdd(&s_nfrag, 1);
+        if (k < RT_IDS) s_ids[k] = (uint16_t)j;
+      }
+      if (rj < 2 || rj > max_r) continue;  // undefined in the reference, no coverage (as k_circle_labels)
+      if (yj + rj < ty0 || yj - rj >= ty0 + th || xj + rj < tx0 || xj - rj >= tx0 + tw) continue;
+      const int k = atomicAdd(&s_ndisk, 1);
+      if (k < RT_DISKS) {
+        s_disk[k][0] = yj, s_disk[k][1] = xj, s_disk[k][2] = rj;
+      } else {  // an extremely crowded tile: this thread draws the whole disk itself
+        for (int r = max(yj - rj, ty0) - ty0; r <= min(yj + rj, ty0 + th - 1) - ty0; ++r) draw_row(r, yj, xj, rj);
+      }
+    }
+  }
+  __syncthreads();
+  const int nfrag = min(s_nfrag, RT_IDS);
+  if (nfrag == 0) return;  // nobody wants this tile: it is not read at all
+  {
+    const int nd = min(s_ndisk, RT_DISKS);
+    for (int p = threadIdx.x; p < nd * RT_H; p += NT) {
+      const int k = p / RT_H, r = p - k * RT_H;
+      if (r < th) draw_row(r, s_disk[k][0], s_disk[k][1], s_disk[k][2]);
+    }
+  }
+  __syncthreads();
+  // ---- 2. rounds of RT_F windows ----
+  const uint16_t* img = d_image + (int64_t)assay * assay_stride;
+  const int nct = n_c * n_t, half = len >> 1, n = len * len;
+  const int64_t plane_elems = (int64_t)h * w;
+  // this thread's 16-byte pieces of a tile plane: piece q = threadIdx.x + NT * i, row q / (RT_W / 8), 8 pixels from column 8 (q % (RT_W / 8))
+  constexpr int PIECES = RT_H * (RT_W / 8) / NT;
+  static_assert(PIECES * NT == RT_H * (RT_W / 8), "tile pieces must divide evenly over the threads");
+  auto load_planes = [&](int ct0) {
+#pragma unroll
+    for (int c = 0; c < RT_CT; ++c) {
+      const int ct = min(ct0 + c, nct - 1);
+      const uint16_t* plane = img + (int64_t)(time_major ? (ct % n_t) * n_c + ct / n_t : ct) * plane_elems;
+      uint4 v[PIECES];
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) {
+        const int q = threadIdx.x + NT * i, r = q / (RT_W / 8), c8 = q - r * (RT_W / 8);
+        v[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (r < th && 8 * c8 < tw) v[i] = *reinterpret_cast<const uint4*>(plane + (int64_t)(ty0 + r) * w + tx0 + 8 * c8);
+      }
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) {
+        const int q = threadIdx.x + NT * i;
+        reinterpret_cast<uint4*>(s_tile + c * RT_H * (RT_W / 2))[q] = v[i];
+      }
+    }
+  };
+  for (int f0 = 0; f0 < nfrag; f0 += RT_F) {
+    const int nf = min(RT_F, nfrag - f0);
+    __syncthreads();  // the previous round's descriptors, masks and tile planes are no longer read
+    if ((int)threadIdx.x < nf) {
+      const int j = s_ids[f0 + threadIdx.x];
+      RtFrag fr;
+      fr.g = first + j;
+      fr.yj = beads[3 * j], fr.xj = beads[3 * j + 1], fr.rj = beads[3 * j + 2];
+      window(fr.yj, len, h, fr.top);
+      window(fr.xj, len, w, fr.left);
+      fr.r0 = max(fr.top - ty0, 0);
+      fr.r1 = min(fr.top + len - ty0, th);
+      s_frag[threadIdx.x] = fr;
+      s_cnt[threadIdx.x][0] = s_cnt[threadIdx.x][1] = 0;
+    }
+    __syncthreads();
+    // mask rows: (fragment, tile row, 32-column word of the window) -> fg / bg bits of the pixels that lie in this tile
+    for (int it = threadIdx.x; it < nf * RT_H * 4; it += NT) {
+      const int f = it / (RT_H * 4), r = (it >> 2) & (RT_H - 1), wd = it & 3;
+      const RtFrag fr = s_frag[f];
+      uint32_t fgb = 0u, bgb = 0u;
+      if (r >= fr.r0 && r < fr.r1 && 32 * wd < len) {
+        const int c0 = fr.left - tx0 + 32 * wd;  // tile column of the word's bit 0 (may be negative / beyond the tile)
+        // columns of the word that are window columns (< len) AND lie in the tile
+        const int lo = max(0, -c0), hi = min(min(32, len - 32 * wd), tw - c0);  // bits [lo, hi)
+        if (lo < hi) {
+          const uint32_t in = (hi - lo == 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << lo);
+          // any / multi bits of tile columns c0 .. c0 + 31
+          const int wi = c0 >> 5, sh = c0 & 31;  // (arithmetic shift: floor)
+          auto word_at = [&](const uint32_t* row, int k) { return (k >= 0 && k < RT_WPR) ? row[k] : 0u; };
+          const uint32_t* ar = s_any + r * RT_WPR;
+          const uint32_t* mr = s_multi + r * RT_WPR;
+          const uint64_t a2 = ((uint64_t)word_at(ar, wi + 1) << 32) | word_at(ar, wi);
+          const uint64_t m2 = ((uint64_t)word_at(mr, wi + 1) << 32) | word_at(mr, wi);
+          const uint32_t anyb = (uint32_t)(a2 >> sh), multib = (uint32_t)(m2 >> sh);
+          // the window's own disk in this row
+          uint32_t own = 0u;
+          const int dy = ty0 + r - fr.yj;
+          if (fr.rj >= 2 && fr.rj <= max_r && dy >= -fr.rj && dy <= fr.rj) {
+            const int hwid = d_halfwidths[(int64_t)fr.rj * side + dy + fr.rj];
+            if (hwid >= 0) {
+              const int xa = max(fr.xj - hwid - fr.left - 32 * wd, 0), xb = min(fr.xj + hwid - fr.left - 32 * wd, 31);
+              if (xa <= xb) own = (xb - xa == 31) ? 0xFFFFFFFFu : (((1u << (xb - xa + 1)) - 1u) << xa);
+            }
+          }
+          fgb = own & ~multib & in;
+          bgb = ~anyb & in;
+        }
+      }
+      s_fg[(f * RT_H + r) * 4 + wd] = fgb;
+      s_bg[(f * RT_H + r) * 4 + wd] = bgb;
+      if (fgb) atomicAdd(&s_cnt[f][0], __popc(fgb));
+      if (bgb) atomicAdd(&s_cnt[f][1], __popc(bgb));
+    }
+    load_planes(0);  // (the first planes' loads are in flight while the masks settle)
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * nf && d_counts) {
+      const int f = threadIdx.x >> 1, k = threadIdx.x & 1;
+      if (s_cnt[f][k]) atomicAdd(&d_counts[2 * (int64_t)s_frag[f].g + k], s_cnt[f][k]);
+    }
+    // per fragment (a wave each): lane l serves window columns 2 l, 2 l + 1
+    const int x = 2 * lane;
+    const bool act = lane < half;
+    const int mword = x >> 5, msh = x & 31;
+    // mask bytes of the fragment's pixels
+    if (d_fg || d_bg) {
+      for (int f = wave; f < nf; f += WV) {
+        const RtFrag fr = s_frag[f];
+        const int tc = fr.left - tx0 + x;  // tile column of the lane's first pixel
+        const bool in0 = act && tc >= 0 && tc < tw, in1 = act && tc + 1 >= 0 && tc + 1 < tw;
+        for (int r = fr.r0; r < fr.r1; ++r) {
+          const uint32_t fb = (s_fg[(f * RT_H + r) * 4 + mword] >> msh) & 3u, bb = (s_bg[(f * RT_H + r) * 4 + mword] >> msh) & 3u;
+          const int64_t o = (int64_t)fr.g * n + (ty0 + r - fr.top) * len + x;
+          if (in0 && in1) {
+            if (d_fg) *reinterpret_cast<uint16_t*>(&d_fg[o]) = (uint16_t)((fb & 1u) | ((fb & 2u) << 7));
+            if (d_bg) *reinterpret_cast<uint16_t*>(&d_bg[o]) = (uint16_t)((bb & 1u) | ((bb & 2u) << 7));
+          } else if (in0) {
+            if (d_fg) d_fg[o] = (uint8_t)(fb & 1u);
+            if (d_bg) d_bg[o] = (uint8_t)(bb & 1u);
+          } else if (in1) {
+            if (d_fg) d_fg[o + 1] = (uint8_t)(fb >> 1);
+            if (d_bg) d_bg[o + 1] = (uint8_t)(bb >> 1);
+          }
+        }
+      }
+    }
+    for (int ct0 = 0; ct0 < nct; ct0 += RT_CT) {
+      if (ct0) {
+        __syncthreads();  // the planes before are served
+        load_planes(ct0);
+        __syncthreads();
+      }
+      for (int f = wave; f < nf; f += WV) {
+        const RtFrag fr = s_frag[f];
+        const int odd = fr.left & 1;  // (tx0 is even: the parity of the window's first column inside the tile)
+        const uint32_t shift = odd ? 16u : 0u;
+        const int e2 = (fr.left - odd - tx0) >> 1;  // dword of the lane-0 pair's first source pixel (may be negative)
+        const int di = min(max(e2 + min(lane, half - 1 + odd), 0), RT_W / 2 - 1);
+        const int tc = fr.left - tx0 + x;
+        const bool in0 = act && tc >= 0 && tc < tw, in1 = act && tc + 1 >= 0 && tc + 1 < tw;
+        uint32_t sf[RT_CT], sb[RT_CT];
+#pragma unroll
+        for (int c = 0; c < RT_CT; ++c) sf[c] = 0u, sb[c] = 0u;
+#pragma unroll 2
+        for (int r = fr.r0; r < fr.r1; ++r) {
+          const uint32_t mf = roi_pair((s_fg[(f * RT_H + r) * 4 + mword] >> msh) & 3u);
+          const uint32_t mb = roi_pair((s_bg[(f * RT_H + r) * 4 + mword] >> msh) & 3u);
+          const int64_t oi = (int64_t)(ty0 + r - fr.top) * half + lane;  // dword of the window
+#pragma unroll
+          for (int c = 0; c < RT_CT; ++c) {
+            if (ct0 + c >= nct) break;  // uniform
+            const uint32_t d = s_tile[(c * RT_H + r) * (RT_W / 2) + di];
+            const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x130, 0xF, 0xF, false);  // lane + 1
+            const uint32_t v = __builtin_amdgcn_alignbit(nx, d, shift);
+            if (d_roi) {
+              uint32_t* out = reinterpret_cast<uint32_t*>(d_roi + ((int64_t)fr.g * nct + ct0 + c) * n);
+              if (in0 && in1) out[oi] = v;
+              else if (in0) reinterpret_cast<uint16_t*>(out)[2 * oi] = (uint16_t)v;
+              else if (in1) reinterpret_cast<uint16_t*>(out)[2 * oi + 1] = (uint16_t)(v >> 16);
+            }
+            sf[c] = roi_dot2(v, mf, sf[c]);  // (pixels outside the tile carry mask 0)
+            sb[c] = roi_dot2(v, mb, sb[c]);
+          }
+        }
+        if (d_sums) {
+#pragma unroll
+          for (int c = 0; c < RT_CT; ++c) {
+            if (ct0 + c >= nct) break;
+            const uint32_t a = (uint32_t)mg_wave_scan_incl_i32((int)sf[c]), b = (uint32_t)mg_wave_scan_incl_i32((int)sb[c]);
+            if (lane == 63) {
+              double* o = d_sums + ((int64_t)fr.g * nct + ct0 + c) * 2;
+              if (a) atomicAdd(o, (double)a);
+              if (b) atomicAdd(o + 1, (double)b);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+constexpr size_t RT_LDS = (size_t)RT_CT * RT_H * RT_W * 2 + 2 * RT_H * RT_WPR * 4 + 2 * RT_F * RT_H * 4 * 4 + RT_IDS * 2;
+
 // ---- masked median: byte-wise radix select in LDS -------------------------------------------------
 // Keys are the order-preserving unsigned images of the values: an unsigned integer is its own key, an IEEE float has
 // its sign bit flipped (positive) or all bits inverted (negative).  A NaN pixel counts as masked out (nanmedian).
@@ -642,6 +924,30 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
   if (m == 0) return MG_OK;
   hipStream_t s = mg_stream(stream);
   const dim3 grid(m);
+  // image-centric pass (round 4): masks from the bead tables of whole assays, uint16, 16-byte aligned rows;
+  // MG_ROI_WINDOWS=1 keeps the window-centric kernel (the tests compare the two)
+  static const bool windows_only = getenv("MG_ROI_WINDOWS") != nullptr;
+  if (!windows_only && dtype == MG_U16 && d_halfwidths && d_assay_offsets && !d_labels && (roi_len & 1) == 0 && roi_len <= 126 &&
+      (w & 7) == 0 && (assay_stride & 7) == 0 && (int64_t)h * w < (1LL << 31) && n_assays > 0 && n_assays <= 65535 &&
+      (bead_stride ? bead_stride : (int64_t)m) <= RT_IDS && max_r >= 2 &&
+      (reinterpret_cast<uintptr_t>(d_image) & 15) == 0 && (!d_roi || (reinterpret_cast<uintptr_t>(d_roi) & 3) == 0) &&
+      (!d_fg || (reinterpret_cast<uintptr_t>(d_fg) & 1) == 0) && (!d_bg || (reinterpret_cast<uintptr_t>(d_bg) & 1) == 0)) {
+    const int nct = n_c * n_t;
+    if (d_sums && mg_zero_async(d_sums, (size_t)m * nct * 2 * sizeof(double), s) != hipSuccess) return MG_ELAUNCH;
+    if (d_counts && mg_zero_async(d_counts, (size_t)m * 2 * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_roi_tiles_u16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)RT_LDS) != hipSuccess)
+        return MG_ELAUNCH;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_roi_tiles_u16, dim3((w + RT_W - 1) / RT_W, (h + RT_H - 1) / RT_H, n_assays), dim3(NT), RT_LDS, s,
+                       (const uint16_t*)d_image, assay_stride, n_c, n_t, h, w, d_beads, bead_stride, d_assay_offsets,
+                       time_major, roi_len, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg, d_sums, d_counts);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+  }
   if (dtype == MG_U16 && (roi_len & 1) == 0 && roi_len <= 126 && (w & 1) == 0 && (assay_stride & 1) == 0 &&
       (int64_t)h * w < (1LL << 31) &&
       (reinterpret_cast<uintptr_t>(d_image) & 3) == 0 && (!d_roi || (reinterpret_cast<uintptr_t>(d_roi) & 3) == 0) &&

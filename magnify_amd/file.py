@@ -108,17 +108,18 @@ def _take_block(ds: Dataset, dim, lo, hi, first):
     return out
 
 
-def save(file, xp, shard_bytes=None):
+def save(file, xp, shard_bytes=None, threads=None):
     """file.py:6-8.  ``shard_bytes``: write parts whose largest variable stays below it (default: parts only when
     a variable exceeds NetCDF-3's 4 GiB, then 2 GiB each).  Everything is written under temporary names first and
     renamed when complete; what an earlier save left under this name (the whole file, or parts -- possibly more of
     them) is removed only AFTER the new data is in place: a crash or a full disk during the write leaves the old
-    data untouched."""
+    data untouched.  ``threads``: writer threads for one file's payload (default: a few; a caller that saves several
+    files side by side passes 1)."""
     ds = xp.unstack() if isinstance(xp, Dataset) else Dataset({xp.name or "data": xp})
     sizes = {k: _nbytes(v) for k, v in list(ds.data_vars.items()) + list(ds.coords.items())}
     biggest = max(sizes.values(), default=0)
     if shard_bytes is None and biggest <= _LIMIT:
-        return _commit(file, [(str(file), ds)])
+        return _commit(file, [(str(file), ds)], threads)
     limit = int(shard_bytes or _SHARD)
     dim = next((d for d in ("mark", "mark_row", "time") if d in ds.sizes and ds.sizes[d] > 1), None)
     if dim is None:
@@ -141,7 +142,7 @@ def save(file, xp, shard_bytes=None):
             part.attrs.update(mg_part=k, mg_parts=len(bounds) - 1, mg_split_dim=dim, mg_split_lo=lo)
             yield f"{file}.part{k:03d}", part
 
-    _commit(file, parts())
+    _commit(file, parts(), threads)
 
 
 def _stale(file):
@@ -151,7 +152,7 @@ def _stale(file):
     return [old for old in [str(file)] + glob.glob(glob.escape(str(file)) + ".part[0-9][0-9][0-9]") if os.path.isfile(old)]
 
 
-def _commit(file, named):
+def _commit(file, named, threads=None):
     """Write every (final name, dataset) of ``named`` under a temporary name (one at a time: a part comes to the host
     when it is written), then rename them all, then remove what an earlier save left that was not replaced."""
     import os
@@ -161,7 +162,7 @@ def _commit(file, named):
     written = []
     try:
         for final, ds in named:
-            _write_nc(final + tag, ds)
+            _write_nc(final + tag, ds, threads)
             written.append(final)
         for final in written:
             os.replace(final + tag, final)

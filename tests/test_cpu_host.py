@@ -1080,11 +1080,11 @@ def test_save_keeps_the_old_data_until_the_new_is_written(tmp_path, monkeypatch)
     new = mg.Dataset({"roi": mg.DataArray(np.arange(64, dtype=np.uint16).reshape(16, 4) + 100, ("mark", "x"))})
     real, n = mgfile._write_nc, [0]
 
-    def failing(path, ds):
+    def failing(path, ds, threads=None):
         n[0] += 1
         if n[0] == 3:
             raise OSError("No space left on device")
-        real(path, ds)
+        real(path, ds, threads)
 
     monkeypatch.setattr(mgfile, "_write_nc", failing)
     with pytest.raises(OSError):

@@ -367,8 +367,8 @@ def test_filters_on_a_chip_searched_at_two_timesteps(mg):
     b = draw_chip((3, 3), 24, offset=(10, 10))  # moved AND grown: other windows, other fg disks at time 1
     a[a > 0] = 3000
     rng = np.random.default_rng(8)
-    data = (np.stack([a, b]).astype(np.int64) + rng.integers(90, 120, size=(2,) + a.shape)).astype(np.uint16)
-    pipe = mg.microfluidic_chip_pipe(shape=(3, 3), num_iter=5000, search_timestep=[0, 1], **KW)
+    data = (np.stack([a, b]).astype(np.int64) + rng.integers(97, 104, size=(2,) + a.shape)).astype(np.uint16)
+    pipe = mg.microfluidic_chip_pipe(shape=(3, 3), num_iter=20000, search_timestep=[0, 1], **KW)
     pipe.remove_pipe("restore_format")
     xp = pipe(chip(mg, data, ("time", "y", "x"), time=[0, 1]))
     assert xp.sizes["mark"] == 9 and xp.sizes["time"] == 2
@@ -405,7 +405,7 @@ def test_filters_on_a_chip_searched_at_two_timesteps(mg):
     assert mg.filter.filter_expression(xp, min_contrast=100).valid.values.all()
     # filter_leaky on the same result with blanks: tagged neighbours of a blank that shows expression go
     pinlist = np.array([["x", "", "x"], ["x", "x", "x"], ["", "x", "x"]])
-    pipe2 = mg.microfluidic_chip_pipe(shape=(3, 3), num_iter=5000, search_timestep=[0, 1], **KW)
+    pipe2 = mg.microfluidic_chip_pipe(shape=(3, 3), num_iter=20000, search_timestep=[0, 1], **KW)
     pipe2.remove_pipe("restore_format")
     xr = pipe2(chip(mg, data, ("time", "y", "x"), time=[0, 1]))
     xr = xr.assign_coords(tag=(("mark",), pinlist.reshape(-1)))
