@@ -503,9 +503,10 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
 constexpr int RT_H = 16, RT_W = 384, RT_WPR = RT_W / 32;  // tile rows / pixels / words per bit row
 constexpr int RT_CT = 4;                                  // planes in LDS at a time (RT_CT * RT_H * RT_W * 2 B = 48 KB)
 constexpr int RT_F = 16;                                  // fragments per round (their mask rows are held in LDS)
-constexpr int RT_IDS = 2048;                              // windows reaching into one tile, at most (launcher: <= beads per assay)
+constexpr int RT_IDS = 2048;                              // beads per block of the window scan (one block unless an assay holds more)
 // (LDS per workgroup: 48 + 1.5 + 8 + 4 KB and ~2.5 KB of descriptors: two workgroups per CU -- one loads while the
 // other serves)
+constexpr int RTN = 512;                                  // threads of a tile workgroup (8 waves; two workgroups per CU)
 constexpr int RT_DISKS = 128;                             // disks reaching into one tile that are drawn row-parallel
 
 struct RtFrag {
@@ -515,7 +516,7 @@ struct RtFrag {
   int r0, r1;        // tile rows [r0, r1) the window covers
 };
 
-__global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict__ d_image, int64_t assay_stride, int n_c,
+__global__ __launch_bounds__(RTN) void k_roi_tiles_u16(const uint16_t* __restrict__ d_image, int64_t assay_stride, int n_c,
                                                       int n_t, int h, int w, const int32_t* __restrict__ d_beads,
                                                       int64_t bead_stride, const int32_t* __restrict__ d_assay_offsets,
                                                       int time_major, int len, const int32_t* __restrict__ d_halfwidths,
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
   uint32_t* s_fg = s_multi + RT_H * RT_WPR;                                      // [RT_F][RT_H][4]
   uint32_t* s_bg = s_fg + RT_F * RT_H * 4;                                       // [RT_F][RT_H][4]
   uint16_t* s_ids = reinterpret_cast<uint16_t*>(s_bg + RT_F * RT_H * 4);         // [RT_IDS]
+  int32_t* s_hw = reinterpret_cast<int32_t*>(s_ids + RT_IDS);                    // [(max_r + 1)][2 max_r + 1] half widths
   __shared__ int s_nfrag, s_ndisk;
   __shared__ int s_disk[RT_DISKS][3];
   __shared__ RtFrag s_frag[RT_F];
@@ -539,8 +541,9 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
   if (nb <= 0) return;
   const int32_t* beads = d_beads + 3 * (bead_stride ? (int64_t)assay * bead_stride : (int64_t)first);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int WV = NT / 64;
-  for (int i = threadIdx.x; i < 2 * RT_H * RT_WPR; i += NT) s_any[i] = 0u;  // (any and multi are adjacent)
+  constexpr int WV = RTN / 64;
+  for (int i = threadIdx.x; i < 2 * RT_H * RT_WPR; i += RTN) s_any[i] = 0u;  // (any and multi are adjacent)
+  for (int i = threadIdx.x; i < (max_r + 1) * (2 * max_r + 1); i += RTN) s_hw[i] = d_halfwidths[i];
   if (threadIdx.x == 0) s_nfrag = 0, s_ndisk = 0;
   __syncthreads();
   // ---- 1. the assay's beads: whose window reaches into the tile, whose disk does ----
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
   auto draw_row = [&](int r, int yj, int xj, int rj) {  // row r of the tile under the disk
     const int dy = ty0 + r - yj;
     if (dy < -rj || dy > rj) return;
-    const int hwid = d_halfwidths[(int64_t)rj * side + dy + rj];
+    const int hwid = s_hw[rj * side + dy + rj];
     if (hwid < 0) return;
     const int xa = max(xj - hwid, tx0) - tx0, xb = min(xj + hwid, tx0 + tw - 1) - tx0;
     for (int wd = xa >> 5; xa <= xb && wd <= (xb >> 5); ++wd) {
@@ -559,26 +562,25 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
     }
   };
   constexpr int UB = 4;
-  for (int b0 = 0; b0 < nb; b0 += NT * UB) {
+  for (int b0 = 0; b0 < nb; b0 += RTN * UB) {
     int yy[UB], xx[UB], rr[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      const int j = b0 + u * NT + (int)threadIdx.x;
+      const int j = b0 + u * RTN + (int)threadIdx.x;
       yy[u] = xx[u] = 0;
       rr[u] = -1;
       if (j < nb) yy[u] = beads[3 * j], xx[u] = beads[3 * j + 1], rr[u] = beads[3 * j + 2];
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      const int j = b0 + u * NT + (int)threadIdx.x;
+      const int j = b0 + u * RTN + (int)threadIdx.x;
       if (j >= nb) continue;
       const int yj = yy[u], xj = xx[u], rj = rr[u];
-      int top, left;
-      window(yj, len, h, top);
-      window(xj, len, w, left);
-      if (top < ty0 + th && top + len > ty0 && left < tx0 + tw && left + len > tx0) {
-        const int k = atomicAdd(&s_nfrag, 1);
-        if (k < RT_IDS) s_ids[k] = (uint16_t)j;
+      if (j < RT_IDS) {  // (the windows of the first RT_IDS beads: the block loop below scans the later ones itself)
+        int top, left;
+        window(yj, len, h, top);
+        window(xj, len, w, left);
+        if (top < ty0 + th && top + len > ty0 && left < tx0 + tw && left + len > tx0) s_ids[atomicAdd(&s_nfrag, 1)] = (uint16_t)j;
       }
       if (rj < 2 || rj > max_r) continue;  // undefined in the reference, no coverage (as k_circle_labels)
       if (yj + rj < ty0 || yj - rj >= ty0 + th || xj + rj < tx0 || xj - rj >= tx0 + tw) continue;
@@ -591,11 +593,10 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
     }
   }
   __syncthreads();
-  const int nfrag = min(s_nfrag, RT_IDS);
-  if (nfrag == 0) return;  // nobody wants this tile: it is not read at all
+  if (nb <= RT_IDS && s_nfrag == 0) return;  // nobody wants this tile: it is not read at all
   {
     const int nd = min(s_ndisk, RT_DISKS);
-    for (int p = threadIdx.x; p < nd * RT_H; p += NT) {
+    for (int p = threadIdx.x; p < nd * RT_H; p += RTN) {
       const int k = p / RT_H, r = p - k * RT_H;
       if (r < th) draw_row(r, s_disk[k][0], s_disk[k][1], s_disk[k][2]);
     }
@@ -605,33 +606,50 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
   const uint16_t* img = d_image + (int64_t)assay * assay_stride;
   const int nct = n_c * n_t, half = len >> 1, n = len * len;
   const int64_t plane_elems = (int64_t)h * w;
-  // this thread's 16-byte pieces of a tile plane: piece q = threadIdx.x + NT * i, row q / (RT_W / 8), 8 pixels from column 8 (q % (RT_W / 8))
-  constexpr int PIECES = RT_H * (RT_W / 8) / NT;
-  static_assert(PIECES * NT == RT_H * (RT_W / 8), "tile pieces must divide evenly over the threads");
-  auto load_planes = [&](int ct0) {
+  // this thread's 16-byte pieces of a tile plane: piece q = threadIdx.x + RTN * i, row q / (RT_W / 8), 8 pixels from column 8 (q % (RT_W / 8))
+  constexpr int PIECES = (RT_H * (RT_W / 8) + RTN - 1) / RTN;
+  auto fetch_planes = [&](int ct0, uint4 (&v)[RT_CT][PIECES]) {
 #pragma unroll
     for (int c = 0; c < RT_CT; ++c) {
       const int ct = min(ct0 + c, nct - 1);
       const uint16_t* plane = img + (int64_t)(time_major ? (ct % n_t) * n_c + ct / n_t : ct) * plane_elems;
-      uint4 v[PIECES];
 #pragma unroll
       for (int i = 0; i < PIECES; ++i) {
-        const int q = threadIdx.x + NT * i, r = q / (RT_W / 8), c8 = q - r * (RT_W / 8);
-        v[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (r < th && 8 * c8 < tw) v[i] = *reinterpret_cast<const uint4*>(plane + (int64_t)(ty0 + r) * w + tx0 + 8 * c8);
-      }
-#pragma unroll
-      for (int i = 0; i < PIECES; ++i) {
-        const int q = threadIdx.x + NT * i;
-        reinterpret_cast<uint4*>(s_tile + c * RT_H * (RT_W / 2))[q] = v[i];
+        const int q = threadIdx.x + RTN * i, r = q / (RT_W / 8), c8 = q - r * (RT_W / 8);
+        v[c][i] = make_uint4(0u, 0u, 0u, 0u);
+        if (q < RT_H * (RT_W / 8) && r < th && 8 * c8 < tw) v[c][i] = *reinterpret_cast<const uint4*>(plane + (int64_t)(ty0 + r) * w + tx0 + 8 * c8);
       }
     }
   };
+  auto stash_planes = [&](const uint4 (&v)[RT_CT][PIECES]) {
+#pragma unroll
+    for (int c = 0; c < RT_CT; ++c)
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) {
+        const int q = threadIdx.x + RTN * i;
+        if (q < RT_H * (RT_W / 8)) reinterpret_cast<uint4*>(s_tile + c * RT_H * (RT_W / 2))[q] = v[c][i];
+      }
+  };
+  // blocks of RT_IDS beads (one block unless an assay holds more): the windows of a block that reach into the tile
+  for (int blk = 0; blk < nb; blk += RT_IDS) {
+  if (blk > 0) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_nfrag = 0;
+    __syncthreads();
+    for (int j = blk + threadIdx.x; j < min(blk + RT_IDS, nb); j += RTN) {
+      int top, left;
+      window(beads[3 * j], len, h, top);
+      window(beads[3 * j + 1], len, w, left);
+      if (top < ty0 + th && top + len > ty0 && left < tx0 + tw && left + len > tx0) s_ids[atomicAdd(&s_nfrag, 1)] = (uint16_t)(j - blk);
+    }
+    __syncthreads();
+  }
+  const int nfrag = s_nfrag;
   for (int f0 = 0; f0 < nfrag; f0 += RT_F) {
     const int nf = min(RT_F, nfrag - f0);
     __syncthreads();  // the previous round's descriptors, masks and tile planes are no longer read
     if ((int)threadIdx.x < nf) {
-      const int j = s_ids[f0 + threadIdx.x];
+      const int j = blk + s_ids[f0 + threadIdx.x];
       RtFrag fr;
       fr.g = first + j;
       fr.yj = beads[3 * j], fr.xj = beads[3 * j + 1], fr.rj = beads[3 * j + 2];
@@ -644,7 +662,7 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
     }
     __syncthreads();
     // mask rows: (fragment, tile row, 32-column word of the window) -> fg / bg bits of the pixels that lie in this tile
-    for (int it = threadIdx.x; it < nf * RT_H * 4; it += NT) {
+    for (int it = threadIdx.x; it < nf * RT_H * 4; it += RTN) {
       const int f = it / (RT_H * 4), r = (it >> 2) & (RT_H - 1), wd = it & 3;
       const RtFrag fr = s_frag[f];
       uint32_t fgb = 0u, bgb = 0u;
@@ -666,7 +684,7 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
           uint32_t own = 0u;
           const int dy = ty0 + r - fr.yj;
           if (fr.rj >= 2 && fr.rj <= max_r && dy >= -fr.rj && dy <= fr.rj) {
-            const int hwid = d_halfwidths[(int64_t)fr.rj * side + dy + fr.rj];
+            const int hwid = s_hw[fr.rj * side + dy + fr.rj];
             if (hwid >= 0) {
               const int xa = max(fr.xj - hwid - fr.left - 32 * wd, 0), xb = min(fr.xj + hwid - fr.left - 32 * wd, 31);
               if (xa <= xb) own = (xb - xa == 31) ? 0xFFFFFFFFu : (((1u << (xb - xa + 1)) - 1u) << xa);
@@ -681,7 +699,11 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
       if (fgb) atomicAdd(&s_cnt[f][0], __popc(fgb));
       if (bgb) atomicAdd(&s_cnt[f][1], __popc(bgb));
     }
-    load_planes(0);  // (the first planes' loads are in flight while the masks settle)
+    {
+      uint4 v[RT_CT][PIECES];
+      fetch_planes(0, v);  // (the first planes' loads are in flight while the masks settle)
+      stash_planes(v);
+    }
     __syncthreads();
     if ((int)threadIdx.x < 2 * nf && d_counts) {
       const int f = threadIdx.x >> 1, k = threadIdx.x & 1;
@@ -691,32 +713,12 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
     const int x = 2 * lane;
     const bool act = lane < half;
     const int mword = x >> 5, msh = x & 31;
-    // mask bytes of the fragment's pixels
-    if (d_fg || d_bg) {
-      for (int f = wave; f < nf; f += WV) {
-        const RtFrag fr = s_frag[f];
-        const int tc = fr.left - tx0 + x;  // tile column of the lane's first pixel
-        const bool in0 = act && tc >= 0 && tc < tw, in1 = act && tc + 1 >= 0 && tc + 1 < tw;
-        for (int r = fr.r0; r < fr.r1; ++r) {
-          const uint32_t fb = (s_fg[(f * RT_H + r) * 4 + mword] >> msh) & 3u, bb = (s_bg[(f * RT_H + r) * 4 + mword] >> msh) & 3u;
-          const int64_t o = (int64_t)fr.g * n + (ty0 + r - fr.top) * len + x;
-          if (in0 && in1) {
-            if (d_fg) *reinterpret_cast<uint16_t*>(&d_fg[o]) = (uint16_t)((fb & 1u) | ((fb & 2u) << 7));
-            if (d_bg) *reinterpret_cast<uint16_t*>(&d_bg[o]) = (uint16_t)((bb & 1u) | ((bb & 2u) << 7));
-          } else if (in0) {
-            if (d_fg) d_fg[o] = (uint8_t)(fb & 1u);
-            if (d_bg) d_bg[o] = (uint8_t)(bb & 1u);
-          } else if (in1) {
-            if (d_fg) d_fg[o + 1] = (uint8_t)(fb >> 1);
-            if (d_bg) d_bg[o + 1] = (uint8_t)(bb >> 1);
-          }
-        }
-      }
-    }
     for (int ct0 = 0; ct0 < nct; ct0 += RT_CT) {
       if (ct0) {
+        uint4 v[RT_CT][PIECES];
+        fetch_planes(ct0, v);
         __syncthreads();  // the planes before are served
-        load_planes(ct0);
+        stash_planes(v);
         __syncthreads();
       }
       for (int f = wave; f < nf; f += WV) {
@@ -730,15 +732,29 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
         uint32_t sf[RT_CT], sb[RT_CT];
 #pragma unroll
         for (int c = 0; c < RT_CT; ++c) sf[c] = 0u, sb[c] = 0u;
-#pragma unroll 2
-        for (int r = fr.r0; r < fr.r1; ++r) {
-          const uint32_t mf = roi_pair((s_fg[(f * RT_H + r) * 4 + mword] >> msh) & 3u);
-          const uint32_t mb = roi_pair((s_bg[(f * RT_H + r) * 4 + mword] >> msh) & 3u);
-          const int64_t oi = (int64_t)(ty0 + r - fr.top) * half + lane;  // dword of the window
+        const bool masks_out = ct0 == 0 && (d_fg || d_bg);
+        auto serve_row = [&](int r, const uint32_t (&dd)[RT_CT]) {
+          const uint32_t fb = (s_fg[(f * RT_H + r) * 4 + mword] >> msh) & 3u, bb = (s_bg[(f * RT_H + r) * 4 + mword] >> msh) & 3u;
+          const uint32_t mf = roi_pair(fb), mb = roi_pair(bb);
+          const int ry = ty0 + r - fr.top;
+          const int64_t oi = (int64_t)ry * half + lane;  // dword of the window
+          if (masks_out) {  // the mask bytes of the fragment's pixels, once
+            const int64_t o = (int64_t)fr.g * n + ry * len + x;
+            if (in0 && in1) {
+              if (d_fg) *reinterpret_cast<uint16_t*>(&d_fg[o]) = (uint16_t)((fb & 1u) | ((fb & 2u) << 7));
+              if (d_bg) *reinterpret_cast<uint16_t*>(&d_bg[o]) = (uint16_t)((bb & 1u) | ((bb & 2u) << 7));
+            } else if (in0) {
+              if (d_fg) d_fg[o] = (uint8_t)(fb & 1u);
+              if (d_bg) d_bg[o] = (uint8_t)(bb & 1u);
+            } else if (in1) {
+              if (d_fg) d_fg[o + 1] = (uint8_t)(fb >> 1);
+              if (d_bg) d_bg[o + 1] = (uint8_t)(bb >> 1);
+            }
+          }
 #pragma unroll
           for (int c = 0; c < RT_CT; ++c) {
             if (ct0 + c >= nct) break;  // uniform
-            const uint32_t d = s_tile[(c * RT_H + r) * (RT_W / 2) + di];
+            const uint32_t d = dd[c];
             const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x130, 0xF, 0xF, false);  // lane + 1
             const uint32_t v = __builtin_amdgcn_alignbit(nx, d, shift);
             if (d_roi) {
@@ -750,6 +766,17 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
             sf[c] = roi_dot2(v, mf, sf[c]);  // (pixels outside the tile carry mask 0)
             sb[c] = roi_dot2(v, mb, sb[c]);
           }
+        };
+        for (int r = fr.r0; r < fr.r1; r += 2) {  // two rows per trip: their LDS reads are in flight together
+          const int rb = min(r + 1, fr.r1 - 1);
+          uint32_t da[RT_CT], db[RT_CT];
+#pragma unroll
+          for (int c = 0; c < RT_CT; ++c) {
+            da[c] = s_tile[(c * RT_H + r) * (RT_W / 2) + di];
+            db[c] = s_tile[(c * RT_H + rb) * (RT_W / 2) + di];
+          }
+          serve_row(r, da);
+          if (r + 1 < fr.r1) serve_row(r + 1, db);  // wave-uniform
         }
         if (d_sums) {
 #pragma unroll
@@ -766,9 +793,10 @@ __global__ __launch_bounds__(NT) void k_roi_tiles_u16(const uint16_t* __restrict
       }
     }
   }
+  }
 }
 
-constexpr size_t RT_LDS = (size_t)RT_CT * RT_H * RT_W * 2 + 2 * RT_H * RT_WPR * 4 + 2 * RT_F * RT_H * 4 * 4 + RT_IDS * 2;
+constexpr size_t RT_LDS = (size_t)RT_CT * RT_H * RT_W * 2 + 2 * RT_H * RT_WPR * 4 + 2 * RT_F * RT_H * 4 * 4 + RT_IDS * 2;  // + the half-width table
 
 // ---- masked median: byte-wise radix select in LDS -------------------------------------------------
 // Keys are the order-preserving unsigned images of the values: an unsigned integer is its own key, an IEEE float has
@@ -924,12 +952,15 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
   if (m == 0) return MG_OK;
   hipStream_t s = mg_stream(stream);
   const dim3 grid(m);
-  // image-centric pass (round 4): masks from the bead tables of whole assays, uint16, 16-byte aligned rows;
-  // MG_ROI_WINDOWS=1 keeps the window-centric kernel (the tests compare the two)
-  static const bool windows_only = getenv("MG_ROI_WINDOWS") != nullptr;
-  if (!windows_only && dtype == MG_U16 && d_halfwidths && d_assay_offsets && !d_labels && (roi_len & 1) == 0 && roi_len <= 126 &&
+  // MG_ROI_TILES=1 (looked at on every call: the tests switch it): the image-centric pass of round 4 -- masks from the
+  // bead tables of whole assays, uint16, 16-byte aligned rows.  Measured at C4 (profiles/r4_roi_tiles.txt): 21.9 GB of
+  // HBM traffic instead of 28.2 (fetches 15.7 -> 8.5 GB: every line once), but 7.05 ms against 4.37 -- 16 waves per CU
+  // behind 68 KB of LDS and ten barriers per tile leave its latencies in the open.  Not the default.
+  const char* tiles_env = getenv("MG_ROI_TILES");
+  const bool tiles = tiles_env && tiles_env[0] == '1';
+  if (tiles && dtype == MG_U16 && d_halfwidths && d_assay_offsets && !d_labels && (roi_len & 1) == 0 && roi_len <= 126 &&
       (w & 7) == 0 && (assay_stride & 7) == 0 && (int64_t)h * w < (1LL << 31) && n_assays > 0 && n_assays <= 65535 &&
-      (bead_stride ? bead_stride : (int64_t)m) <= RT_IDS && max_r >= 2 &&
+      (bead_stride ? bead_stride : (int64_t)m) <= 65535 && max_r >= 2 && (max_r + 1) * (2 * max_r + 1) * 4 <= 27 * 53 * 4 + 8192 &&
       (reinterpret_cast<uintptr_t>(d_image) & 15) == 0 && (!d_roi || (reinterpret_cast<uintptr_t>(d_roi) & 3) == 0) &&
       (!d_fg || (reinterpret_cast<uintptr_t>(d_fg) & 1) == 0) && (!d_bg || (reinterpret_cast<uintptr_t>(d_bg) & 1) == 0)) {
     const int nct = n_c * n_t;
@@ -938,11 +969,11 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
     static bool attr_set = false;
     if (!attr_set) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_roi_tiles_u16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)RT_LDS) != hipSuccess)
+                              (int)RT_LDS + 27 * 53 * 4 + 8192) != hipSuccess)
         return MG_ELAUNCH;
       attr_set = true;
     }
-    hipLaunchKernelGGL(k_roi_tiles_u16, dim3((w + RT_W - 1) / RT_W, (h + RT_H - 1) / RT_H, n_assays), dim3(NT), RT_LDS, s,
+    hipLaunchKernelGGL(k_roi_tiles_u16, dim3((w + RT_W - 1) / RT_W, (h + RT_H - 1) / RT_H, n_assays), dim3(RTN), RT_LDS + (size_t)(max_r + 1) * (2 * max_r + 1) * 4, s,
                        (const uint16_t*)d_image, assay_stride, n_c, n_t, h, w, d_beads, bead_stride, d_assay_offsets,
                        time_major, roi_len, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg, d_sums, d_counts);
     MG_CHECK_LAUNCH();

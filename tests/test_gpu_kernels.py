@@ -1057,3 +1057,48 @@ def test_candidates_degenerate_triplets(hp, num_iter):
         if k == 2:
             assert ok.sum() > num_iter // 50  # the circles are found
     assert {"zero radius", "huge"} <= kinds and ("nan" in kinds or "inf" in kinds), kinds
+
+
+@pytest.mark.parametrize("L,time_major", [(100, False), (40, False), (64, True)])
+def test_roi_image_centric_pass_equals_window_pass(hp, monkeypatch, L, time_major):
+    """The image-centric ROI pass of round 4 (MG_ROI_TILES=1: a workgroup owns a 16 x 384 tile, loads its planes into
+    LDS once and serves every window's fragment -- roi pixels, mask bytes, sums and counts by atomic adds) against the
+    window-centric pass and against the masks of the oracle's circle_labels map: windows cut by tile borders in both
+    directions, shifted into the image at its edges, overlapping and contested disks, a crowded assay (hundreds of
+    windows per tile: several rounds), an empty one, 5 planes per assay (the second pass over the planes is partial)."""
+    rng = np.random.default_rng(44)
+    c, t, h, w = (5, 1, 150, 800) if not time_major else (2, 3, 150, 800)
+    A = 3
+    images = rng.integers(0, 65536, size=(A, t, c, h, w) if time_major else (A, c, t, h, w)).astype(np.uint16)
+    crowded = np.column_stack([rng.integers(0, h, 300), rng.integers(300, 500, 300), rng.integers(2, 14, 300)])
+    assays = [np.array([[20, 20, 8], [5, 790, 6], [149, 400, 10], [80, 380, 9], [84, 392, 9], [16, 384, 5], [15, 383, 12],
+                        [31, 767, 7], [-3, 100, 6], [90, 805, 7], [80, 84, 25], [75, 300, 1]]), crowded, np.empty((0, 3), dtype=np.int64)]
+    tab = np.zeros((A, 320, 3), dtype=np.int32)
+    for a, beads in enumerate(assays):
+        tab[a, : len(beads)] = beads
+    counts = [len(b) for b in assays]
+    kw = dict(disks=True, device_tables=(dev(tab), counts, 25), time_major=time_major)
+    monkeypatch.delenv("MG_ROI_TILES", raising=False)
+    want = hp.roi_gather_reduce(dev(images), None, L, None, **kw)
+    monkeypatch.setenv("MG_ROI_TILES", "1")
+    got = hp.roi_gather_reduce(dev(images), None, L, None, **kw)
+    monkeypatch.delenv("MG_ROI_TILES")
+    for key in ("roi", "fg", "bg", "sums", "counts"):
+        np.testing.assert_array_equal(got[key].cpu().numpy(), want[key].cpu().numpy(), err_msg=key)
+    off = got["offsets"]
+    lab = rn.circle_labels(assays[0][assays[0][:, 2] >= 2], h, w)  # (a radius below 2 covers nothing: undefined in the reference)
+    for i, (row, col, r) in enumerate(assays[0]):
+        top, bottom, left, right = rn.bounding_box(int(col), int(row), L, w, h)
+        sub = lab[top:bottom, left:right]
+        if r >= 2:
+            np.testing.assert_array_equal(got["fg"][off[0] + i].cpu().numpy().astype(bool), sub == i)
+        np.testing.assert_array_equal(got["bg"][off[0] + i].cpu().numpy().astype(bool), sub == -1)
+        win = images[0][..., top:bottom, left:right]
+        win = win.transpose(1, 0, 2, 3) if time_major else win
+        np.testing.assert_array_equal(got["roi"][off[0] + i].cpu().numpy(), win)
+    # only the reductions (no pixel stack, no mask bytes)
+    monkeypatch.setenv("MG_ROI_TILES", "1")
+    light = hp.roi_gather_reduce(dev(images), None, L, None, want_roi=False, want_masks=False, **kw)
+    monkeypatch.delenv("MG_ROI_TILES")
+    np.testing.assert_array_equal(light["sums"].cpu().numpy(), want["sums"].cpu().numpy())
+    np.testing.assert_array_equal(light["counts"].cpu().numpy(), want["counts"].cpu().numpy())
