@@ -78,7 +78,8 @@ def spawn_ranks(argv, n: int, share_gpu: bool | None = None, timeout: float | No
 
     def relay(p, dst):
         for line in p.stdout:
-            dst.write(line)
+            # (gloo announces its connections on stdout: not part of rank 0's report)
+            (sys.stderr if line.startswith("[Gloo]") else dst).write(line)
             dst.flush()
 
     threads = [threading.Thread(target=relay, args=(p, out if r == 0 else sys.stderr), daemon=True)

@@ -55,6 +55,15 @@ class _Staging:
             self._free.extend(blocks)
 
 
+_STAGING = _Staging()  # kept by the module, like the reader's blocks: a second stream (or sink) pins nothing new
+
+
+def release_staging():
+    """Give the sinks' page-locked staging blocks back."""
+    global _STAGING
+    _STAGING = _Staging()
+
+
 class _Sink:
     """``depth``: how many chunks may be on their way (copy in flight / being written) before ``__call__`` waits for
     the writer -- the GPU feed never waits for a file while the writer keeps up."""
@@ -68,7 +77,7 @@ class _Sink:
     def __init__(self, want_roi=True, want_masks=True, depth=3):
         self.want_roi, self.want_masks = want_roi, want_masks
         self._side = None
-        self._staging = _Staging()
+        self._staging = _STAGING
         self._slots = threading.Semaphore(max(1, int(depth)))
         self._jobs = queue.Queue()
         self._writer = None

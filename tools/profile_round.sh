@@ -6,7 +6,7 @@
 # trace domains); the chain is launched eagerly (MG_NO_GRAPH=1) so that every kernel is a dispatch of its own.  Only the
 # summaries stay under gpurun_out/ (the raw traces are hundreds of megabytes).
 set -e
-TAG=${1:-r3}
+TAG=${1:-r4}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 RAW=/tmp/mg_prof_$TAG
