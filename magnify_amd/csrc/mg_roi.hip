@@ -7,8 +7,6 @@
 
 #include <stdlib.h>
 
-#include <algorithm>
-
 #include "mg_common.h"
 
 namespace {
@@ -518,13 +516,14 @@ struct RtFrag {
   int r0, r1;        // tile rows [r0, r1) the window covers
 };
 
-template <int NTH>
-__device__ void rt_tile_body(uint8_t* rt_smem, const uint16_t* __restrict__ d_image, int64_t assay_stride, int n_c, int n_t,
-                             int h, int w, const int32_t* __restrict__ d_beads, int64_t bead_stride,
-                             const int32_t* __restrict__ d_assay_offsets, int time_major, int len,
-                             const int32_t* __restrict__ d_halfwidths, int max_r, uint16_t* __restrict__ d_roi,
-                             uint8_t* __restrict__ d_fg, uint8_t* __restrict__ d_bg, double* __restrict__ d_sums,
-                             int32_t* __restrict__ d_counts, int assay, int tx0, int ty0) {
+__global__ __launch_bounds__(RTN) void k_roi_tiles_u16(const uint16_t* __restrict__ d_image, int64_t assay_stride, int n_c,
+                                                      int n_t, int h, int w, const int32_t* __restrict__ d_beads,
+                                                      int64_t bead_stride, const int32_t* __restrict__ d_assay_offsets,
+                                                      int time_major, int len, const int32_t* __restrict__ d_halfwidths,
+                                                      int max_r, uint16_t* __restrict__ d_roi, uint8_t* __restrict__ d_fg,
+                                                      uint8_t* __restrict__ d_bg, double* __restrict__ d_sums,
+                                                      int32_t* __restrict__ d_counts) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t rt_smem[];
   uint32_t* s_tile = reinterpret_cast<uint32_t*>(rt_smem);                       // [RT_CT][RT_H][RT_W / 2] pixel pairs
   uint32_t* s_any = s_tile + RT_CT * RT_H * (RT_W / 2);                          // [RT_H][RT_WPR]
   uint32_t* s_multi = s_any + RT_H * RT_WPR;                                     // [RT_H][RT_WPR]
@@ -536,14 +535,15 @@ __device__ void rt_tile_body(uint8_t* rt_smem, const uint16_t* __restrict__ d_im
   __shared__ int s_disk[RT_DISKS][3];
   __shared__ RtFrag s_frag[RT_F];
   __shared__ int s_cnt[RT_F][2];
+  const int assay = blockIdx.z, tx0 = blockIdx.x * RT_W, ty0 = blockIdx.y * RT_H;
   const int tw = min(RT_W, w - tx0), th = min(RT_H, h - ty0);
   const int first = d_assay_offsets[assay], nb = d_assay_offsets[assay + 1] - first;
   if (nb <= 0) return;
   const int32_t* beads = d_beads + 3 * (bead_stride ? (int64_t)assay * bead_stride : (int64_t)first);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int WV = NTH / 64;
-  for (int i = threadIdx.x; i < 2 * RT_H * RT_WPR; i += NTH) s_any[i] = 0u;  // (any and multi are adjacent)
-  for (int i = threadIdx.x; i < (max_r + 1) * (2 * max_r + 1); i += NTH) s_hw[i] = d_halfwidths[i];
+  constexpr int WV = RTN / 64;
+  for (int i = threadIdx.x; i < 2 * RT_H * RT_WPR; i += RTN) s_any[i] = 0u;  // (any and multi are adjacent)
+  for (int i = threadIdx.x; i < (max_r + 1) * (2 * max_r + 1); i += RTN) s_hw[i] = d_halfwidths[i];
   if (threadIdx.x == 0) s_nfrag = 0, s_ndisk = 0;
   __syncthreads();
   // ---- 1. the assay's beads: whose window reaches into the tile, whose disk does ----
@@ -562,18 +562,18 @@ __device__ void rt_tile_body(uint8_t* rt_smem, const uint16_t* __restrict__ d_im
     }
   };
   constexpr int UB = 4;
-  for (int b0 = 0; b0 < nb; b0 += NTH * UB) {
+  for (int b0 = 0; b0 < nb; b0 += RTN * UB) {
     int yy[UB], xx[UB], rr[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      const int j = b0 + u * NTH + (int)threadIdx.x;
+      const int j = b0 + u * RTN + (int)threadIdx.x;
       yy[u] = xx[u] = 0;
       rr[u] = -1;
       if (j < nb) yy[u] = beads[3 * j], xx[u] = beads[3 * j + 1], rr[u] = beads[3 * j + 2];
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      const int j = b0 + u * NTH + (int)threadIdx.x;
+      const int j = b0 + u * RTN + (int)threadIdx.x;
       if (j >= nb) continue;
       const int yj = yy[u], xj = xx[u], rj = rr[u];
       if (j < RT_IDS) {  // (the windows of the first RT_IDS beads: the block loop below scans the later ones itself)
@@ -596,7 +596,7 @@ __device__ void rt_tile_body(uint8_t* rt_smem, const uint16_t* __restrict__ d_im
   if (nb <= RT_IDS && s_nfrag == 0) return;  // nobody wants this tile: it is not read at all
   {
     const int nd = min(s_ndisk, RT_DISKS);
-    for (int p = threadIdx.x; p < nd * RT_H; p += NTH) {
+    for (int p = threadIdx.x; p < nd * RT_H; p += RTN) {
       const int k = p / RT_H, r = p - k * RT_H;
       if (r < th) draw_row(r, s_disk[k][0], s_disk[k][1], s_disk[k][2]);
     }
@@ -606,8 +606,8 @@ __device__ void rt_tile_body(uint8_t* rt_smem, const uint16_t* __restrict__ d_im
   const uint16_t* img = d_image + (int64_t)assay * assay_stride;
   const int nct = n_c * n_t, half = len >> 1, n = len * len;
   const int64_t plane_elems = (int64_t)h * w;
-  // this thread's 16-byte pieces of a tile plane: piece q = threadIdx.x + NTH * i, row q / (RT_W / 8), 8 pixels from column 8 (q % (RT_W / 8))
-  constexpr int PIECES = (RT_H * (RT_W / 8) + NTH - 1) / NTH;
+  // this thread's 16-byte pieces of a tile plane: piece q = threadIdx.x + RTN * i, row q / (RT_W / 8), 8 pixels from column 8 (q % (RT_W / 8))
+  constexpr int PIECES = (RT_H * (RT_W / 8) + RTN - 1) / RTN;
   auto fetch_planes = [&](int ct0, uint4 (&v)[RT_CT][PIECES]) {
 #pragma unroll
     for (int c = 0; c < RT_CT; ++c) {
@@ -615,7 +615,7 @@ __device__ void rt_tile_body(uint8_t* rt_smem, const uint16_t* __restrict__ d_im
       const uint16_t* plane = img + (int64_t)(time_major ? (ct % n_t) * n_c + ct / n_t : ct) * plane_elems;
 #pragma unroll
       for (int i = 0; i < PIECES; ++i) {
-        const int q = threadIdx.x + NTH * i, r = q / (RT_W / 8), c8 = q - r * (RT_W / 8);
+        const int q = threadIdx.x + RTN * i, r = q / (RT_W / 8), c8 = q - r * (RT_W / 8);
         v[c][i] = make_uint4(0u, 0u, 0u, 0u);
         if (q < RT_H * (RT_W / 8) && r < th && 8 * c8 < tw) v[c][i] = *reinterpret_cast<const uint4*>(plane + (int64_t)(ty0 + r) * w + tx0 + 8 * c8);
       }
@@ -626,7 +626,7 @@ __device__ void rt_tile_body(uint8_t* rt_smem, const uint16_t* __restrict__ d_im
     for (int c = 0; c < RT_CT; ++c)
 #pragma unroll
       for (int i = 0; i < PIECES; ++i) {
-        const int q = threadIdx.x + NTH * i;
+        const int q = threadIdx.x + RTN * i;
         if (q < RT_H * (RT_W / 8)) reinterpret_cast<uint4*>(s_tile + c * RT_H * (RT_W / 2))[q] = v[c][i];
       }
   };
@@ -636,7 +636,7 @@ __device__ void rt_tile_body(uint8_t* rt_smem, const uint16_t* __restrict__ d_im
     __syncthreads();
     if (threadIdx.x == 0) s_nfrag = 0;
     __syncthreads();
-    for (int j = blk + threadIdx.x; j < min(blk + RT_IDS, nb); j += NTH) {
+    for (int j = blk + threadIdx.x; j < min(blk + RT_IDS, nb); j += RTN) {
       int top, left;
       window(beads[3 * j], len, h, top);
       window(beads[3 * j + 1], len, w, left);
@@ -662,7 +662,7 @@ __device__ void rt_tile_body(uint8_t* rt_smem, const uint16_t* __restrict__ d_im
     }
     __syncthreads();
     // mask rows: (fragment, tile row, 32-column word of the window) -> fg / bg bits of the pixels that lie in this tile
-    for (int it = threadIdx.x; it < nf * RT_H * 4; it += NTH) {
+    for (int it = threadIdx.x; it < nf * RT_H * 4; it += RTN) {
       const int f = it / (RT_H * 4), r = (it >> 2) & (RT_H - 1), wd = it & 3;
       const RtFrag fr = s_frag[f];
       uint32_t fgb = 0u, bgb = 0u;
@@ -793,348 +793,6 @@ __device__ void rt_tile_body(uint8_t* rt_smem, const uint16_t* __restrict__ d_im
       }
     }
   }
-  }
-}
-
-__global__ __launch_bounds__(RTN) void k_roi_tiles_u16(const uint16_t* __restrict__ d_image, int64_t assay_stride, int n_c,
-                                                      int n_t, int h, int w, const int32_t* __restrict__ d_beads,
-                                                      int64_t bead_stride, const int32_t* __restrict__ d_assay_offsets,
-                                                      int time_major, int len, const int32_t* __restrict__ d_halfwidths,
-                                                      int max_r, uint16_t* __restrict__ d_roi, uint8_t* __restrict__ d_fg,
-                                                      uint8_t* __restrict__ d_bg, double* __restrict__ d_sums,
-                                                      int32_t* __restrict__ d_counts) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t rt_smem[];
-  rt_tile_body<RTN>(rt_smem, d_image, assay_stride, n_c, n_t, h, w, d_beads, bead_stride, d_assay_offsets, time_major, len,
-                    d_halfwidths, max_r, d_roi, d_fg, d_bg, d_sums, d_counts, blockIdx.z, blockIdx.x * RT_W, blockIdx.y * RT_H);
-}
-
-// ---- the same pass as a software pipeline over tiles (round 4) ------------------------------------------------
-// k_roi_tiles_u16 spends ~20 us per tile in ten phases that wait for each other (bead scan, disk maps, descriptors, mask
-// rows, plane loads, serving), two workgroups per CU.  Here ONE persistent workgroup of 1024 per CU walks its tiles and
-// every trip of its loop works on FOUR tiles at once, one phase each -- the loads of a phase are issued first, the
-// phase that only needs LDS (serving tile j - 3) runs while they fly:
-//     A(j): the assay's beads -> windows and disks that reach into tile j          (set j % 5)
-//     B(j - 1): disk rows -> any / multi maps; fragment descriptors                (set (j - 1) % 5)
-//     C(j - 2): planes of the tile -> LDS buffer (j - 2) % 2; mask rows; counts    (masks (j - 2) % 2)
-//     D(j - 3): every fragment's pixels, mask bytes and sums                       (planes / masks (j - 3) % 2)
-// One barrier per trip.  Tiles the pipeline has no room for (more than RT_F windows, RT_PDISKS disks, RT_PIDS window
-// ids or 2048 beads in the assay) are noted and worked on afterwards by the unpipelined body.
-constexpr int RTP = 1024;      // threads
-constexpr int RT_PIDS = 512;   // windows reaching into a tile (pipeline)
-constexpr int RT_PDISKS = 64;  // disks reaching into a tile (pipeline)
-constexpr int RT_SETS = 5;
-constexpr int RT_TODO = 512;   // tiles left for the unpipelined body, per workgroup
-
-struct RtSet {
-  uint32_t any[RT_H * RT_WPR], multi[RT_H * RT_WPR];
-  uint16_t ids[RT_PIDS];
-  int disk[RT_PDISKS][3];
-  RtFrag frag[RT_F];
-  int nfrag, ndisk, slow, assay;
-};
-constexpr size_t RT_PLANE_BYTES = (size_t)RT_CT * RT_H * RT_W * 2;
-constexpr size_t RT_MASK_BYTES = (size_t)RT_F * RT_H * 4 * 4;
-constexpr size_t RT_PIPE_LDS = 2 * RT_PLANE_BYTES + 4 * RT_MASK_BYTES + RT_SETS * sizeof(RtSet) + RT_TODO * 4;  // + the half-width table
-
-
-__global__ __launch_bounds__(RTP) void k_roi_tiles_pipe_u16(const uint16_t* __restrict__ d_image, int64_t assay_stride, int n_c,
-                                                           int n_t, int h, int w, const int32_t* __restrict__ d_beads,
-                                                           int64_t bead_stride, const int32_t* __restrict__ d_assay_offsets,
-                                                           int time_major, int len, const int32_t* __restrict__ d_halfwidths,
-                                                           int max_r, uint16_t* __restrict__ d_roi, uint8_t* __restrict__ d_fg,
-                                                           uint8_t* __restrict__ d_bg, double* __restrict__ d_sums,
-                                                           int32_t* __restrict__ d_counts, int ntx, int nty, int n_assays) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t rt_smem[];
-  uint32_t* s_planes = reinterpret_cast<uint32_t*>(rt_smem);                                   // [2][RT_CT][RT_H][RT_W / 2]
-  uint32_t* s_masks = reinterpret_cast<uint32_t*>(rt_smem + 2 * RT_PLANE_BYTES);               // [2][fg | bg][RT_F][RT_H][4]
-  RtSet* s_sets = reinterpret_cast<RtSet*>(rt_smem + 2 * RT_PLANE_BYTES + 4 * RT_MASK_BYTES);  // [RT_SETS]
-  uint32_t* s_todo = reinterpret_cast<uint32_t*>(s_sets + RT_SETS);                            // [RT_TODO]
-  int32_t* s_hw = reinterpret_cast<int32_t*>(s_todo + RT_TODO);                                // [(max_r + 1)][2 max_r + 1]
-  __shared__ int s_ntodo;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int side = 2 * max_r + 1, nct = n_c * n_t, half = len >> 1, n = len * len;
-  const int64_t plane_elems = (int64_t)h * w;
-  const int tiles_per_assay = ntx * nty;
-  const int64_t total = (int64_t)tiles_per_assay * n_assays;
-  const int64_t first_tile = blockIdx.x, stride_tiles = gridDim.x;
-  const int n_my = first_tile < total ? (int)((total - first_tile + stride_tiles - 1) / stride_tiles) : 0;
-  for (int i = threadIdx.x; i < (max_r + 1) * side; i += RTP) s_hw[i] = d_halfwidths[i];
-  for (int i = threadIdx.x; i < 2 * RT_H * RT_WPR; i += RTP) s_sets[0].any[i] = 0u;  // (any and multi are adjacent)
-  if (threadIdx.x == 0) s_ntodo = 0, s_sets[0].nfrag = 0, s_sets[0].ndisk = 0, s_sets[0].slow = 0;
-  __syncthreads();
-  auto tile_of = [&](int j, int& assay, int& tx0, int& ty0) {
-    const int64_t t = first_tile + (int64_t)j * stride_tiles;
-    assay = (int)(t / tiles_per_assay);
-    const int rest = (int)(t - (int64_t)assay * tiles_per_assay);
-    ty0 = (rest / ntx) * RT_H;
-    tx0 = (rest - (rest / ntx) * ntx) * RT_W;
-  };
-  constexpr int PIECES = (RT_H * (RT_W / 8) + RTP - 1) / RTP;  // 16-byte pieces of a tile plane per thread
-  const int x = 2 * lane;
-  const bool act = lane < half;
-  const int mword = x >> 5, msh = x & 31;
-  for (int it = 0; it < n_my + 3; ++it) {
-    const int jA = it, jB = it - 1, jC = it - 2, jD = it - 3;
-    // ---- loads first: A's beads, C's planes ----
-    int a_assay = 0, a_tx0 = 0, a_ty0 = 0, a_nb = 0, a_first = 0;
-    int by[2] = {0, 0}, bx[2] = {0, 0}, br[2] = {-1, -1};
-    const int32_t* a_beads = d_beads;
-    if (jA < n_my) {
-      tile_of(jA, a_assay, a_tx0, a_ty0);
-      a_first = d_assay_offsets[a_assay];
-      a_nb = d_assay_offsets[a_assay + 1] - a_first;
-      a_beads = d_beads + 3 * (bead_stride ? (int64_t)a_assay * bead_stride : (int64_t)a_first);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int j = threadIdx.x + u * RTP;
-        if (j < a_nb) by[u] = a_beads[3 * j], bx[u] = a_beads[3 * j + 1], br[u] = a_beads[3 * j + 2];
-      }
-    }
-    uint4 pv[RT_CT][PIECES];
-    bool c_live = false;
-    int c_assay = 0, c_tx0 = 0, c_ty0 = 0;
-    if (jC >= 0 && jC < n_my) {
-      const RtSet& sc = s_sets[jC % RT_SETS];
-      c_live = !sc.slow && sc.nfrag > 0;
-      if (c_live) {
-        tile_of(jC, c_assay, c_tx0, c_ty0);
-        const int tw = min(RT_W, w - c_tx0), th = min(RT_H, h - c_ty0);
-        const uint16_t* img = d_image + (int64_t)c_assay * assay_stride;
-#pragma unroll
-        for (int c = 0; c < RT_CT; ++c) {
-          const int ct = min(c, nct - 1);
-          const uint16_t* plane = img + (int64_t)(time_major ? (ct % n_t) * n_c + ct / n_t : ct) * plane_elems;
-#pragma unroll
-          for (int i = 0; i < PIECES; ++i) {
-            const int q = threadIdx.x + RTP * i, r = q / (RT_W / 8), c8 = q - r * (RT_W / 8);
-            pv[c][i] = make_uint4(0u, 0u, 0u, 0u);
-            if (q < RT_H * (RT_W / 8) && r < th && 8 * c8 < tw)
-              pv[c][i] = *reinterpret_cast<const uint4*>(plane + (int64_t)(c_ty0 + r) * w + c_tx0 + 8 * c8);
-          }
-        }
-      }
-    }
-    // ---- D(jD): serve ----
-    if (jD >= 0 && jD < n_my) {
-      const RtSet& sd = s_sets[jD % RT_SETS];
-      if (!sd.slow && wave < sd.nfrag) {
-        int assay, tx0, ty0;
-        tile_of(jD, assay, tx0, ty0);
-        const int tw = min(RT_W, w - tx0);
-        const uint32_t* tile = s_planes + (jD & 1) * (RT_PLANE_BYTES / 4);
-        const uint32_t* fgm = s_masks + (jD & 1) * (2 * RT_MASK_BYTES / 4) + wave * RT_H * 4;
-        const uint32_t* bgm = fgm + RT_MASK_BYTES / 4;
-        const RtFrag fr = sd.frag[wave];
-        const int odd = fr.left & 1;
-        const uint32_t shift = odd ? 16u : 0u;
-        const int e2 = (fr.left - odd - tx0) >> 1;
-        const int di = min(max(e2 + min(lane, half - 1 + odd), 0), RT_W / 2 - 1);
-        const int tc = fr.left - tx0 + x;
-        const bool in0 = act && tc >= 0 && tc < tw, in1 = act && tc + 1 >= 0 && tc + 1 < tw;
-        uint32_t sf[RT_CT], sb[RT_CT];
-#pragma unroll
-        for (int c = 0; c < RT_CT; ++c) sf[c] = 0u, sb[c] = 0u;
-        auto serve_row = [&](int r, const uint32_t (&dd)[RT_CT]) {
-          const uint32_t fb = (fgm[r * 4 + mword] >> msh) & 3u, bb = (bgm[r * 4 + mword] >> msh) & 3u;
-          const uint32_t mf = roi_pair(fb), mb = roi_pair(bb);
-          const int ry = ty0 + r - fr.top;
-          const int64_t oi = (int64_t)ry * half + lane;
-          if (d_fg || d_bg) {
-            const int64_t o = (int64_t)fr.g * n + ry * len + x;
-            if (in0 && in1) {
-              if (d_fg) *reinterpret_cast<uint16_t*>(&d_fg[o]) = (uint16_t)((fb & 1u) | ((fb & 2u) << 7));
-              if (d_bg) *reinterpret_cast<uint16_t*>(&d_bg[o]) = (uint16_t)((bb & 1u) | ((bb & 2u) << 7));
-            } else if (in0) {
-              if (d_fg) d_fg[o] = (uint8_t)(fb & 1u);
-              if (d_bg) d_bg[o] = (uint8_t)(bb & 1u);
-            } else if (in1) {
-              if (d_fg) d_fg[o + 1] = (uint8_t)(fb >> 1);
-              if (d_bg) d_bg[o + 1] = (uint8_t)(bb >> 1);
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < RT_CT; ++c) {
-            if (c >= nct) break;  // uniform
-            const uint32_t d = dd[c];
-            const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x130, 0xF, 0xF, false);  // lane + 1
-            const uint32_t v = __builtin_amdgcn_alignbit(nx, d, shift);
-            if (d_roi) {
-              uint32_t* out = reinterpret_cast<uint32_t*>(d_roi + ((int64_t)fr.g * nct + c) * n);
-              if (in0 && in1) out[oi] = v;
-              else if (in0) reinterpret_cast<uint16_t*>(out)[2 * oi] = (uint16_t)v;
-              else if (in1) reinterpret_cast<uint16_t*>(out)[2 * oi + 1] = (uint16_t)(v >> 16);
-            }
-            sf[c] = roi_dot2(v, mf, sf[c]);
-            sb[c] = roi_dot2(v, mb, sb[c]);
-          }
-        };
-        for (int r = fr.r0; r < fr.r1; r += 2) {
-          const int rb = min(r + 1, fr.r1 - 1);
-          uint32_t da[RT_CT], db[RT_CT];
-#pragma unroll
-          for (int c = 0; c < RT_CT; ++c) {
-            da[c] = tile[(c * RT_H + r) * (RT_W / 2) + di];
-            db[c] = tile[(c * RT_H + rb) * (RT_W / 2) + di];
-          }
-          serve_row(r, da);
-          if (r + 1 < fr.r1) serve_row(r + 1, db);
-        }
-        if (d_sums) {
-#pragma unroll
-          for (int c = 0; c < RT_CT; ++c) {
-            if (c >= nct) break;
-            const uint32_t a = (uint32_t)mg_wave_scan_incl_i32((int)sf[c]), b = (uint32_t)mg_wave_scan_incl_i32((int)sb[c]);
-            if (lane == 63) {
-              double* o = d_sums + ((int64_t)fr.g * nct + c) * 2;
-              if (a) atomicAdd(o, (double)a);
-              if (b) atomicAdd(o + 1, (double)b);
-            }
-          }
-        }
-      }
-    }
-    // ---- C(jC): planes into LDS, mask rows, counts ----
-    if (c_live) {
-      const RtSet& sc = s_sets[jC % RT_SETS];
-      uint32_t* tile = s_planes + (jC & 1) * (RT_PLANE_BYTES / 4);
-#pragma unroll
-      for (int c = 0; c < RT_CT; ++c)
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-          const int q = threadIdx.x + RTP * i;
-          if (q < RT_H * (RT_W / 8)) reinterpret_cast<uint4*>(tile + c * RT_H * (RT_W / 2))[q] = pv[c][i];
-        }
-      // thread = (fragment, tile row, 32-column word): a wave per fragment
-      const int f = wave, r = (lane >> 2), wd = lane & 3;
-      uint32_t fgb = 0u, bgb = 0u;
-      const int tw = min(RT_W, w - c_tx0), th = min(RT_H, h - c_ty0);
-      if (f < sc.nfrag) {
-        const RtFrag fr = sc.frag[f];
-        if (r >= fr.r0 && r < fr.r1 && r < th && 32 * wd < len) {
-          const int c0 = fr.left - c_tx0 + 32 * wd;
-          const int lo = max(0, -c0), hi = min(min(32, len - 32 * wd), tw - c0);
-          if (lo < hi) {
-            const uint32_t in = (hi - lo == 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << lo);
-            const int wi = c0 >> 5, sh = c0 & 31;
-            auto word_at = [&](const uint32_t* row, int k) { return (k >= 0 && k < RT_WPR) ? row[k] : 0u; };
-            const uint32_t* ar = sc.any + r * RT_WPR;
-            const uint32_t* mr = sc.multi + r * RT_WPR;
-            const uint64_t a2 = ((uint64_t)word_at(ar, wi + 1) << 32) | word_at(ar, wi);
-            const uint64_t m2 = ((uint64_t)word_at(mr, wi + 1) << 32) | word_at(mr, wi);
-            const uint32_t anyb = (uint32_t)(a2 >> sh), multib = (uint32_t)(m2 >> sh);
-            uint32_t own = 0u;
-            const int dy = c_ty0 + r - fr.yj;
-            if (fr.rj >= 2 && fr.rj <= max_r && dy >= -fr.rj && dy <= fr.rj) {
-              const int hwid = s_hw[fr.rj * side + dy + fr.rj];
-              if (hwid >= 0) {
-                const int xa = max(fr.xj - hwid - fr.left - 32 * wd, 0), xb = min(fr.xj + hwid - fr.left - 32 * wd, 31);
-                if (xa <= xb) own = (xb - xa == 31) ? 0xFFFFFFFFu : (((1u << (xb - xa + 1)) - 1u) << xa);
-              }
-            }
-            fgb = own & ~multib & in;
-            bgb = ~anyb & in;
-          }
-        }
-      }
-      uint32_t* fgm = s_masks + (jC & 1) * (2 * RT_MASK_BYTES / 4);
-      fgm[(f * RT_H + r) * 4 + wd] = fgb;
-      fgm[RT_MASK_BYTES / 4 + (f * RT_H + r) * 4 + wd] = bgb;
-      if (d_counts && f < sc.nfrag) {  // (wave-uniform)
-        const int cf = mg_wave_sum_i32(__popc(fgb)), cb = mg_wave_sum_i32(__popc(bgb));
-        if (lane == 0) {
-          if (cf) atomicAdd(&d_counts[2 * (int64_t)sc.frag[f].g], cf);
-          if (cb) atomicAdd(&d_counts[2 * (int64_t)sc.frag[f].g + 1], cb);
-        }
-      }
-    }
-    // ---- B(jB): disk rows into the maps, fragment descriptors ----
-    if (jB >= 0 && jB < n_my) {
-      RtSet& sb_ = s_sets[jB % RT_SETS];
-      int assay, tx0, ty0;
-      tile_of(jB, assay, tx0, ty0);
-      const int tw = min(RT_W, w - tx0), th = min(RT_H, h - ty0);
-      const int nd = sb_.ndisk, nf = sb_.nfrag;
-      const bool slow = sb_.slow || nf > RT_F || nd > RT_PDISKS;
-      if (!slow) {
-        for (int p = threadIdx.x; p < nd * RT_H; p += RTP) {
-          const int k = p / RT_H, r = p - k * RT_H;
-          const int yj = sb_.disk[k][0], xj = sb_.disk[k][1], rj = sb_.disk[k][2];
-          const int dy = ty0 + r - yj;
-          if (r >= th || dy < -rj || dy > rj) continue;
-          const int hwid = s_hw[rj * side + dy + rj];
-          if (hwid < 0) continue;
-          const int xa = max(xj - hwid, tx0) - tx0, xb = min(xj + hwid, tx0 + tw - 1) - tx0;
-          for (int wd = xa >> 5; xa <= xb && wd <= (xb >> 5); ++wd) {
-            const int lo = max(xa, 32 * wd) - 32 * wd, hi = min(xb, 32 * wd + 31) - 32 * wd;
-            const uint32_t bits = (hi - lo == 31) ? 0xFFFFFFFFu : (((1u << (hi - lo + 1)) - 1u) << lo);
-            const uint32_t old = atomicOr(&sb_.any[r * RT_WPR + wd], bits);
-            if (old & bits) atomicOr(&sb_.multi[r * RT_WPR + wd], old & bits);
-          }
-        }
-        if ((int)threadIdx.x < nf) {
-          const int first = d_assay_offsets[assay];
-          const int32_t* beads = d_beads + 3 * (bead_stride ? (int64_t)assay * bead_stride : (int64_t)first);
-          const int j = sb_.ids[threadIdx.x];
-          RtFrag fr;
-          fr.g = first + j;
-          fr.yj = beads[3 * j], fr.xj = beads[3 * j + 1], fr.rj = beads[3 * j + 2];
-          window(fr.yj, len, h, fr.top);
-          window(fr.xj, len, w, fr.left);
-          fr.r0 = max(fr.top - ty0, 0);
-          fr.r1 = min(fr.top + len - ty0, th);
-          sb_.frag[threadIdx.x] = fr;
-        }
-      } else if (threadIdx.x == 0) {
-        sb_.slow = 1;
-        const int k = s_ntodo++;
-        if (k < RT_TODO) s_todo[k] = (uint32_t)jB;
-      }
-    }
-    // ---- A(jA): this thread's beads; the next trip's set is cleared ----
-    if (jA < n_my) {
-      RtSet& sa = s_sets[jA % RT_SETS];
-      const int tw = min(RT_W, w - a_tx0), th = min(RT_H, h - a_ty0);
-      if (a_nb > 2 * RTP) {
-        if (threadIdx.x == 0) sa.slow = 1;  // (B notes it for the unpipelined body)
-      } else {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int j = threadIdx.x + u * RTP;
-          if (j >= a_nb) continue;
-          const int yj = by[u], xj = bx[u], rj = br[u];
-          int top, left;
-          window(yj, len, h, top);
-          window(xj, len, w, left);
-          if (top < a_ty0 + th && top + len > a_ty0 && left < a_tx0 + tw && left + len > a_tx0) {
-            const int k = atomicAdd(&sa.nfrag, 1);
-            if (k < RT_PIDS) sa.ids[k] = (uint16_t)j;
-            else sa.slow = 1;
-          }
-          if (rj < 2 || rj > max_r) continue;
-          if (yj + rj < a_ty0 || yj - rj >= a_ty0 + th || xj + rj < a_tx0 || xj - rj >= a_tx0 + tw) continue;
-          const int k = atomicAdd(&sa.ndisk, 1);
-          if (k < RT_PDISKS) sa.disk[k][0] = yj, sa.disk[k][1] = xj, sa.disk[k][2] = rj;
-        }
-      }
-    }
-    {
-      RtSet& sn = s_sets[(jA + 1) % RT_SETS];  // (the set of tile jA - 4: done with)
-      for (int i = threadIdx.x; i < 2 * RT_H * RT_WPR; i += RTP) sn.any[i] = 0u;
-      if (threadIdx.x == 0) sn.nfrag = 0, sn.ndisk = 0, sn.slow = 0;
-    }
-    __syncthreads();
-  }
-  // ---- the tiles the pipeline left out ----
-  const int ntodo = min(s_ntodo, RT_TODO);
-  __syncthreads();
-  for (int k = 0; k < ntodo; ++k) {
-    const int j = (int)s_todo[k];  // (read before the body reuses the LDS: s_todo lies behind its footprint)
-    int assay, tx0, ty0;
-    tile_of(j, assay, tx0, ty0);
-    __syncthreads();
-    rt_tile_body<RTP>(rt_smem, d_image, assay_stride, n_c, n_t, h, w, d_beads, bead_stride, d_assay_offsets, time_major, len,
-                      d_halfwidths, max_r, d_roi, d_fg, d_bg, d_sums, d_counts, assay, tx0, ty0);
-    __syncthreads();
   }
 }
 
@@ -1299,8 +957,7 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
   // HBM traffic instead of 28.2 (fetches 15.7 -> 8.5 GB: every line once), but 7.05 ms against 4.37 -- 16 waves per CU
   // behind 68 KB of LDS and ten barriers per tile leave its latencies in the open.  Not the default.
   const char* tiles_env = getenv("MG_ROI_TILES");
-  const bool pipelined = tiles_env && tiles_env[0] == '2';  // "2": the pipelined form (one persistent workgroup per CU)
-  const bool tiles = tiles_env && (tiles_env[0] == '1' || pipelined);
+  const bool tiles = tiles_env && tiles_env[0] == '1';
   if (tiles && dtype == MG_U16 && d_halfwidths && d_assay_offsets && !d_labels && (roi_len & 1) == 0 && roi_len <= 126 &&
       (w & 7) == 0 && (assay_stride & 7) == 0 && (int64_t)h * w < (1LL << 31) && n_assays > 0 && n_assays <= 65535 &&
       (bead_stride ? bead_stride : (int64_t)m) <= 65535 && max_r >= 2 && (max_r + 1) * (2 * max_r + 1) * 4 <= 27 * 53 * 4 + 8192 &&
@@ -1309,27 +966,6 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
     const int nct = n_c * n_t;
     if (d_sums && mg_zero_async(d_sums, (size_t)m * nct * 2 * sizeof(double), s) != hipSuccess) return MG_ELAUNCH;
     if (d_counts && mg_zero_async(d_counts, (size_t)m * 2 * sizeof(int32_t), s) != hipSuccess) return MG_ELAUNCH;
-    const size_t hw_bytes = (size_t)(max_r + 1) * (2 * max_r + 1) * 4;
-    const int ntx = (w + RT_W - 1) / RT_W, nty = (h + RT_H - 1) / RT_H;
-    if (pipelined && nct <= RT_CT && hw_bytes <= 27 * 53 * 4) {
-      static int n_cu = 0;
-      if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-          n_cu = 256;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_roi_tiles_pipe_u16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(RT_PIPE_LDS + 27 * 53 * 4)) != hipSuccess) {  // (static + dynamic must stay within 160 KB)
-          n_cu = 0;
-          return MG_ELAUNCH;
-        }
-      }
-      const int64_t total = (int64_t)ntx * nty * n_assays;
-      hipLaunchKernelGGL(k_roi_tiles_pipe_u16, dim3((unsigned)std::min<int64_t>(total, n_cu)), dim3(RTP), RT_PIPE_LDS + hw_bytes, s,
-                         (const uint16_t*)d_image, assay_stride, n_c, n_t, h, w, d_beads, bead_stride, d_assay_offsets, time_major,
-                         roi_len, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg, d_sums, d_counts, ntx, nty, n_assays);
-      MG_CHECK_LAUNCH();
-      return MG_OK;
-    }
     static bool attr_set = false;
     if (!attr_set) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_roi_tiles_u16), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1337,7 +973,7 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
         return MG_ELAUNCH;
       attr_set = true;
     }
-    hipLaunchKernelGGL(k_roi_tiles_u16, dim3(ntx, nty, n_assays), dim3(RTN), RT_LDS + hw_bytes, s,
+    hipLaunchKernelGGL(k_roi_tiles_u16, dim3((w + RT_W - 1) / RT_W, (h + RT_H - 1) / RT_H, n_assays), dim3(RTN), RT_LDS + (size_t)(max_r + 1) * (2 * max_r + 1) * 4, s,
                        (const uint16_t*)d_image, assay_stride, n_c, n_t, h, w, d_beads, bead_stride, d_assay_offsets,
                        time_major, roi_len, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg, d_sums, d_counts);
     MG_CHECK_LAUNCH();

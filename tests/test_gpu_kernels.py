@@ -1059,19 +1059,15 @@ def test_candidates_degenerate_triplets(hp, num_iter):
     assert {"zero radius", "huge"} <= kinds and ("nan" in kinds or "inf" in kinds), kinds
 
 
-@pytest.mark.parametrize("tiles", ["1", "2"])  # a workgroup per tile / the pipelined form (a persistent workgroup per CU)
-@pytest.mark.parametrize("L,time_major", [(100, False), (40, False), (64, True), (100, None)])
-def test_roi_image_centric_pass_equals_window_pass(hp, monkeypatch, L, time_major, tiles):
+@pytest.mark.parametrize("L,time_major", [(100, False), (40, False), (64, True)])
+def test_roi_image_centric_pass_equals_window_pass(hp, monkeypatch, L, time_major):
     """The image-centric ROI pass of round 4 (MG_ROI_TILES=1: a workgroup owns a 16 x 384 tile, loads its planes into
     LDS once and serves every window's fragment -- roi pixels, mask bytes, sums and counts by atomic adds) against the
     window-centric pass and against the masks of the oracle's circle_labels map: windows cut by tile borders in both
     directions, shifted into the image at its edges, overlapping and contested disks, a crowded assay (hundreds of
     windows per tile: several rounds), an empty one, 5 planes per assay (the second pass over the planes is partial)."""
     rng = np.random.default_rng(44)
-    # (5 or 6 planes per assay: two passes over the planes, which the pipelined form leaves to its unpipelined body;
-    #  time_major None: 4 planes -- the shape the pipeline itself serves)
-    c, t, h, w = (5, 1, 150, 800) if time_major is False else ((2, 3, 150, 800) if time_major else (4, 1, 150, 800))
-    time_major = bool(time_major)
+    c, t, h, w = (5, 1, 150, 800) if not time_major else (2, 3, 150, 800)
     A = 3
     images = rng.integers(0, 65536, size=(A, t, c, h, w) if time_major else (A, c, t, h, w)).astype(np.uint16)
     crowded = np.column_stack([rng.integers(0, h, 300), rng.integers(300, 500, 300), rng.integers(2, 14, 300)])
@@ -1084,7 +1080,7 @@ def test_roi_image_centric_pass_equals_window_pass(hp, monkeypatch, L, time_majo
     kw = dict(disks=True, device_tables=(dev(tab), counts, 25), time_major=time_major)
     monkeypatch.delenv("MG_ROI_TILES", raising=False)
     want = hp.roi_gather_reduce(dev(images), None, L, None, **kw)
-    monkeypatch.setenv("MG_ROI_TILES", tiles)
+    monkeypatch.setenv("MG_ROI_TILES", "1")
     got = hp.roi_gather_reduce(dev(images), None, L, None, **kw)
     monkeypatch.delenv("MG_ROI_TILES")
     for key in ("roi", "fg", "bg", "sums", "counts"):
@@ -1101,7 +1097,7 @@ def test_roi_image_centric_pass_equals_window_pass(hp, monkeypatch, L, time_majo
         win = win.transpose(1, 0, 2, 3) if time_major else win
         np.testing.assert_array_equal(got["roi"][off[0] + i].cpu().numpy(), win)
     # only the reductions (no pixel stack, no mask bytes)
-    monkeypatch.setenv("MG_ROI_TILES", tiles)
+    monkeypatch.setenv("MG_ROI_TILES", "1")
     light = hp.roi_gather_reduce(dev(images), None, L, None, want_roi=False, want_masks=False, **kw)
     monkeypatch.delenv("MG_ROI_TILES")
     np.testing.assert_array_equal(light["sums"].cpu().numpy(), want["sums"].cpu().numpy())
