@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1, help="ranks the time axis is split over")
     ap.add_argument("--reader-only", action="store_true", help="also time the reader alone (no GPU work): where a file-bound run loses its time")
     ap.add_argument("--save-dir", default=None, help="where --sink save writes (default: a temporary directory)")
+    ap.add_argument("--writers", type=int, default=8, help="files a SaveSink writes side by side")
     return ap.parse_args()
 
 
@@ -122,7 +123,8 @@ def main():
         if args.sink == "host":
             return mg.HostSink(want_roi=args.want_roi, want_masks=args.want_roi)
         if args.sink == "save":
-            return mg.SaveSink(os.path.join(save_dir, "t{index:05d}.nc"), want_roi=args.want_roi, want_masks=args.want_roi)
+            return mg.SaveSink(os.path.join(save_dir, "t{index:05d}.nc"), want_roi=args.want_roi, want_masks=args.want_roi,
+                               writers=args.writers)
         return None
 
     sink_stats = {}
