@@ -1,44 +1,44 @@
-"""Does the 256 MB Infinity Cache keep one assay (4 x 32 MB + the 64 MB flat image) between the maxima pass and the
-correction pass?  Times the correction of an assay right after its own maxima pass (warm) and after another assay's (cold)."""
-import os, sys
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", ".")); sys.path.insert(0, "tests")
-import numpy as np, torch
-from magnify_amd import hotpath as hp
-from magnify_amd.stack import synthetic_stack
-from synth import vignette
+"""Infinity Cache reuse between two streaming passes over one 134 MB block (mg_stream_probe, one 16-byte access per
+lane): a read pass over block i directly followed by a copy pass reading block i (reuse) -- or block i + 8 (none).
+Run under rocprofv3 --kernel-trace; the copy kernels' durations tell.  python tools/mall_probe2.py [--mb 128]"""
+import argparse
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from magnify_amd import _native as nat, hotpath as hp
 
-S, C, A = 4096, 4, 8
-stack, _ = synthetic_stack(A, C, S, S, seed=4000)
-flat = torch.from_numpy(vignette((S, S))).cuda()
-out = torch.empty_like(stack)
-mm = torch.empty((A * C, 2), dtype=torch.float64, device="cuda")
-tiles = stack.view(A * C, 1, 1, 1, S, S)
-def fmax(a):
-    return hp.flatfield_max(tiles[a * C:(a + 1) * C], flat, 100.0, 1)
-def fapply(a, m2):
-    hp.flatfield_stitch(tiles[a * C:(a + 1) * C], 0, flat, 100.0, max2=m2, out=out[a], minmax_out=mm[a * C:(a + 1) * C], n_groups=1)
-m2s = [fmax(a) for a in range(A)]
-torch.cuda.synchronize()
-for mode, shift in (("warm", 0), ("cold", 4), ("warm", 0), ("cold", 4)):
-    ev = []
-    for it in range(40):
-        a = it % A
-        fmax(a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fapply((a + shift) % A, m2s[(a + shift) % A]); e1.record()
-        ev.append((e0, e1))
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mb", type=int, default=128)
+    args = ap.parse_args()
+    n = args.mb << 20
+    N = 16
+    src = torch.randint(0, 255, (N, n), dtype=torch.uint8, device="cuda")
+    dst = torch.empty((N, n), dtype=torch.uint8, device="cuda")
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+    lib = nat.lib()
+
+    def probe(s, d, mode, nb=n):
+        nat.check(lib.mg_stream_probe(s.data_ptr(), d.data_ptr(), nb, mode, sink.data_ptr(), 0, hp._stream()), "probe")
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    for name, shift in (("reuse", 0), ("none", 8)):
+        for rep in range(3):
+            tot = 0.0
+            for i in range(N):
+                probe(src[(i + shift) % N], dst[0], 1)
+                a, b = ev(), ev()
+                a.record()
+                probe(src[i], dst[i], 0)
+                b.record()
+                b.synchronize()
+                tot += a.elapsed_time(b)
+            print(name, "copy after read: %.1f us per block of %d MiB (events)" % (1e3 * tot / N, args.mb))
+    # half-block granularity: read 2 halves, copy 2 halves
     torch.cuda.synchronize()
-    t = np.array([a.elapsed_time(b) for a, b in ev][8:])
-    print(f"{mode}: correction of one assay (128 MiB in, 128 MiB out, 64 MiB flat) {np.median(t)*1e3:.1f} us median, {t.min()*1e3:.1f} min "
-          f"-> {(256 + 64) * 1.048576 / np.median(t):.0f} GB/s", flush=True)
-# maxima pass alone, warm (same assay again) vs cold
-for mode, shift in (("max warm", 0), ("max cold", 1)):
-    ev = []
-    for it in range(40):
-        a = (it * shift) % A
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fmax(a); e1.record()
-        ev.append((e0, e1))
-    torch.cuda.synchronize()
-    t = np.array([a.elapsed_time(b) for a, b in ev][8:])
-    print(f"{mode}: {np.median(t)*1e3:.1f} us median, {t.min()*1e3:.1f} min -> {(128 + 64) * 1.048576 / np.median(t):.0f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
