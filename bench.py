@@ -35,7 +35,8 @@ def algorithmic_bytes(stage, p):
         "mg_flatfield_max": 2 * c * n * p["n_t"],            # read u16, whole stack
         "mg_flatfield_apply_stitch": 4 * c * n * p["n_t"],   # read u16 + write u16
         "mg_to_uint8_blur": 3 * planes * n,                 # read u16, write blurred u8
-        "mg_scharr_hist": 1 * planes * n * p["hist_passes"],  # read u8
+        "mg_to_uint8_blur_hist": 3 * planes * n,            # the same bytes: the histogram is taken from registers
+        "mg_scharr_hist": 1 * planes * n * (p["hist_passes"] - 1),  # window passes only: read u8
         "mg_canny_nms": (1 + 5 / 8) * planes * n,           # read u8, write weak + strong bitmaps + 3 orientation bit planes
         "mg_canny_hysteresis": (3 / 8) * planes * n * p["sweeps"],  # weak + strong bits in, strong out, per sweep
         "mg_edge_angles": p["edges"] * (8 + 9 + 4),          # coordinate, 3x3 blurred neighbourhood, angle
@@ -96,7 +97,7 @@ STAGE_NOTES = {
 # stages launched outside the finder's chain: timed live in the timed region even when the chain is a graph replay
 LIVE_STAGES = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_roi_segment_reduce", "mg_counts_to_offsets"]
 
-STREAM_STAGES = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_to_uint8_blur", "mg_scharr_hist", "mg_canny_nms",
+STREAM_STAGES = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_to_uint8_blur", "mg_to_uint8_blur_hist", "mg_scharr_hist", "mg_canny_nms",
                  "mg_canny_hysteresis", "mg_edge_grid", "mg_edge_angles", "mg_circle_labels",
                  "mg_roi_gather_reduce_batched", "mg_roi_segment_reduce"]
 

@@ -136,6 +136,16 @@ int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w, int mode, 
  * d_scratch == NULL selects the atomic hand-over. */
 int64_t mg_scharr_hist_scratch_words(int n_planes, int h, int w, int mode);
 
+/* mg_to_uint8_blur and mg_scharr_hist (mode 0) of the same planes as ONE call (utils.py:20-27 and 115-125 follow each
+ * other in find_circles): where the input is an integer type, no un-blurred copy is asked for, w % 4 == 0 and the
+ * rows are aligned, one kernel blurs a strip and histograms its Scharr magnitudes while the blurred rows are still
+ * in registers; otherwise the two passes run one after the other.  Same results either way.  d_hist must be
+ * pre-zeroed; d_scratch: mg_blur_hist_scratch_words words (NULL: the two passes, histogram handed over by atomics). */
+int mg_to_uint8_blur_hist(const void* d_src, int dtype, int n_planes, int64_t plane_stride, int h, int w,
+                          int64_t row_stride, const double* d_minmax, uint8_t* d_blur, uint8_t* d_u8, uint32_t* d_hist,
+                          uint32_t* d_scratch, int64_t scratch_words, void* stream);
+int64_t mg_blur_hist_scratch_words(int n_planes, int h, int w);
+
 /* np.quantile(grad, q) for the two Canny quantiles and cv::Canny's threshold preparation (utils.py:126-134),
  * from the combined histogram of mg_scharr_hist (mode 0), on the device: ranks4 (HOST array) = the prev / next
  * order-statistic indices of numpy's linear interpolation for the low and the high quantile, gamma_* its

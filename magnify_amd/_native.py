@@ -41,6 +41,8 @@ PROTOTYPES = {
     "mg_to_uint8_blur": [_p, _i, _i, _l, _i, _i, _l, _p, _p, _p, _p],
     "mg_scharr_hist": [_p, _i, _i, _i, _i, _p, _p, _p, _l, _p],
     "mg_scharr_hist_scratch_words": [_i, _i, _i, _i],
+    "mg_to_uint8_blur_hist": [_p, _i, _i, _l, _i, _i, _l, _p, _p, _p, _p, _p, _l, _p],
+    "mg_blur_hist_scratch_words": [_i, _i, _i],
     "mg_edge_thresholds": [_p, _i, _p, _f, _f, _p, _p, _p, _p, _p, _p],
     "mg_edge_thresholds_window": [_p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p],
     "mg_canny_nms": [_p, _i, _i, _i, _p, _p, _p, _p, _l, _p],
@@ -80,7 +82,7 @@ PROTOTYPES = {
     "mg_host_write_runs": [_p, _p, _p, _p, _i, _i, _p],
 }
 
-RETURNS_INT64 = {"mg_scharr_hist_scratch_words", "mg_edge_grid_scan_words", "mg_flatfield_max_scratch_floats"}
+RETURNS_INT64 = {"mg_scharr_hist_scratch_words", "mg_blur_hist_scratch_words", "mg_edge_grid_scan_words", "mg_flatfield_max_scratch_floats"}
 
 _lib = None
 

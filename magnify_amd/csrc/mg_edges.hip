@@ -10,6 +10,9 @@
 // loads; every lane owns 4 adjacent pixels (one dword) of 16 rows.  Integer arithmetic throughout:
 // bit-exact against the oracle.  Roofline: HBM.
 #include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
 
 #include "mg_common.h"
 
@@ -286,21 +289,16 @@ constexpr uint32_t MG_HIST_SKIP = 0xFFFFFFFFu;  // mode 1: d_base[plane] of a pl
 // through the LDS-staged path (reflect-101) in a second launch.
 constexpr int HIST_TILES = 3;
 
-__device__ __forceinline__ void hist_add4(const Row12& ra, const Row12& rb, const Row12& rc, int gx, int w, int mode,
-                                          uint32_t base, int n_bins, uint32_t* hist, uint32_t& zeros) {
-  // packed 16-bit arithmetic, two pixels per instruction (columns c0-1 .. c0+4 as three pairs); |gradient|^2 by
-  // one dot2 per pixel (see k_canny_nms)
-  typedef short s2 __attribute__((ext_vector_type(2)));
-  typedef unsigned short u2 __attribute__((ext_vector_type(2)));
-  u2 pa[3], pb2[3], pc[3];
-#define MG_UNPACK3(r, o)                                                                    \
-  o[0] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(r.d1, r.d0, 0x0C040C03u)); /* c0-1, c0 */ \
-  o[1] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(0u, r.d1, 0x0C020C01u));   /* c0+1, c0+2 */ \
-  o[2] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(r.d2, r.d1, 0x0C040C03u)); /* c0+3, c0+4 */
-  MG_UNPACK3(ra, pa)
-  MG_UNPACK3(rb, pb2)
-  MG_UNPACK3(rc, pc)
-#undef MG_UNPACK3
+typedef short hs2 __attribute__((ext_vector_type(2)));
+typedef unsigned short hu2 __attribute__((ext_vector_type(2)));
+
+// The four pixels c0 .. c0+3 of the centre row pb2, from three rows given as pixel PAIRS (c0-1, c0), (c0+1, c0+2),
+// (c0+3, c0+4): packed 16-bit arithmetic, two pixels per instruction; |gradient|^2 by one dot2 per pixel (see
+// k_canny_nms).
+__device__ __forceinline__ void hist_add4_pairs(const hu2 (&pa)[3], const hu2 (&pb2)[3], const hu2 (&pc)[3], int gx, int w,
+                                                int mode, uint32_t base, int n_bins, uint32_t* hist, uint32_t& zeros) {
+  typedef hs2 s2;
+  typedef hu2 u2;
   s2 S[3], D[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -335,6 +333,21 @@ __device__ __forceinline__ void hist_add4(const Row12& ra, const Row12& rb, cons
       }
     }
   }
+}
+
+__device__ __forceinline__ void hist_add4(const Row12& ra, const Row12& rb, const Row12& rc, int gx, int w, int mode,
+                                          uint32_t base, int n_bins, uint32_t* hist, uint32_t& zeros) {
+  typedef hu2 u2;
+  u2 pa[3], pb2[3], pc[3];
+#define MG_UNPACK3(r, o)                                                                    \
+  o[0] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(r.d1, r.d0, 0x0C040C03u)); /* c0-1, c0 */ \
+  o[1] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(0u, r.d1, 0x0C020C01u));   /* c0+1, c0+2 */ \
+  o[2] = __builtin_bit_cast(u2, __builtin_amdgcn_perm(r.d2, r.d1, 0x0C040C03u)); /* c0+3, c0+4 */
+  MG_UNPACK3(ra, pa)
+  MG_UNPACK3(rb, pb2)
+  MG_UNPACK3(rc, pc)
+#undef MG_UNPACK3
+  hist_add4_pairs(pa, pb2, pc, gx, w, mode, base, n_bins, hist, zeros);
 }
 
 __device__ __forceinline__ bool hist_group_interior(const uint8_t* pb, int h, int w, int tx0, int gy) {
@@ -439,6 +452,150 @@ __global__ __launch_bounds__(NT) void k_scharr_hist(const uint8_t* __restrict__ 
     if (v & 0xFFFFu) atomicAdd(&out[2 * i], v & 0xFFFFu);
     if (v >> 16) atomicAdd(&out[2 * i + 1], v >> 16);
   }
+}
+
+// ---- K1 + K2 in one pass (integer inputs, w % 4 == 0): the blurred rows feed the histogram from registers ----
+// Both passes are bound by vector issue, not by their bytes, and the histogram pass read the blurred image back
+// (3.3 GB fetched at 64 planes of 4096^2 for 1.07 GB) only to do arithmetic on it.  Here a wave walks down a strip of
+// FR rows: a lane loads its four pixels of an input row straight into registers, the neighbours' pixels come by
+// whole-wave DPP shifts (no LDS tile, no workgroup barrier in the loop), the 5 x 5 blur runs in packed 16-bit
+// arithmetic (every intermediate fits: 16 x 255 per row pass, 256 x 255 per column pass), the blurred dword is
+// stored, and the Scharr magnitudes of the row before it -- three blurred rows are kept as pixel pairs -- enter the
+// workgroup's histogram in LDS.  Lanes 1 .. 62 own the strip's FW = 248 columns, lanes 0 and 63 recompute the
+// neighbours' nearest columns (a strip needs the blurred columns next to it, which belong to another workgroup);
+// likewise a wave blurs one row above and below its strip.  BORDER_REFLECT_101 of the blurred image equals the blur
+// of the reflected input (the kernel is symmetric), so the halo simply reads reflected input pixels.
+constexpr int FW = 248;           // columns owned by a workgroup
+constexpr int FR = 64;            // rows per wave
+constexpr int FH = (NT / 64) * FR;
+constexpr int FB = 5;             // rows per batch of loads; two batches per trip (the 5-row ring returns to its place)
+static_assert((FR + 6) % (2 * FB) == 0, "row loop");
+
+template <typename T>
+struct alignas(4 * sizeof(T)) Raw4 {
+  T v[4];
+};
+
+// One wave's strip.  VEC: every lane's four columns lie inside the image row (one aligned load per lane and row);
+// else (the first / last strips of a row of strips) every lane reads its four reflected columns one by one.  The
+// choice is the workgroup's, not the lane's: a branch around a load inside the loop would end every load with a wait.
+template <typename T, bool VEC>
+__device__ __forceinline__ void blur_hist_strip(const T* __restrict__ pin, int64_t row_stride, int h, int w, int y0, int cx,
+                                                bool owner, const U8Scale& sc, uint8_t* __restrict__ pout, uint32_t* hist,
+                                                uint32_t& zeros) {
+  typedef hu2 u2;
+  constexpr int n_bins = FINE + COARSE;
+  const int y_end = min(y0 + FR, h);
+  uint32_t col[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) col[q] = VEC ? (uint32_t)(cx + q) : (uint32_t)mg_reflect101(cx + q, w);
+  auto load = [&](int j) {  // input row y0 - 3 + j
+    int ry = y0 - 3 + j;
+    if (ry < 0) ry = -ry;
+    if (ry >= h) ry = mg_reflect101(ry, h);
+    const T* rowp = pin + (int64_t)ry * row_stride;
+    Raw4<T> r;
+    if (VEC) {
+      r = *reinterpret_cast<const Raw4<T>*>(rowp + col[0]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r.v[q] = rowp[col[q]];
+    }
+    return r;
+  };
+  u2 H[5][2];   // row-pass sums of the five newest input rows, pixels (0, 1) and (2, 3)
+  u2 P[3][3];   // the three newest blurred rows as pairs (c-1, c), (c+1, c+2), (c+3, c+4)
+#pragma unroll
+  for (int k = 0; k < 5; ++k) H[k][0] = H[k][1] = (u2)(0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) P[k][0] = P[k][1] = P[k][2] = (u2)(0);
+  Raw4<T> cur[FB], nxt[FB];
+#pragma unroll
+  for (int b = 0; b < FB; ++b) cur[b] = load(b);
+#pragma unroll 1
+  for (int j0 = 0; j0 < FR + 6; j0 += 2 * FB) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int jb = j0 + half * FB;
+      // the rows of the next batch: in flight while this one is worked on (past the strip: the last row again)
+#pragma unroll
+      for (int b = 0; b < FB; ++b) nxt[b] = load(min(jb + FB + b, FR + 5));
+#pragma unroll
+      for (int b = 0; b < FB; ++b) {
+        const int j = jb + b;
+        // (to_u8's float64 multiply-add is not what this loop waits for: an exact float32 quotient with one integer
+        // correction, seven single-rate instructions per pixel, ran 2 % slower)
+        const uint32_t d1 = (uint32_t)to_u8<T>(cur[b].v[0], sc) | ((uint32_t)to_u8<T>(cur[b].v[1], sc) << 8) |
+                            ((uint32_t)to_u8<T>(cur[b].v[2], sc) << 16) | ((uint32_t)to_u8<T>(cur[b].v[3], sc) << 24);
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d1, 0x138, 0xF, 0xF, false);  // lane - 1
+        const uint32_t d2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d1, 0x130, 0xF, 0xF, false);  // lane + 1
+        // pixel pairs at even and odd offsets: (-2, -1) (0, 1) (2, 3) (4, 5) and (-1, 0) (1, 2) (3, 4)
+        const u2 em = __builtin_bit_cast(u2, __builtin_amdgcn_perm(0u, d0, 0x0C030C02u));
+        const u2 e0 = __builtin_bit_cast(u2, __builtin_amdgcn_perm(0u, d1, 0x0C010C00u));
+        const u2 e2 = __builtin_bit_cast(u2, __builtin_amdgcn_perm(0u, d1, 0x0C030C02u));
+        const u2 e4 = __builtin_bit_cast(u2, __builtin_amdgcn_perm(0u, d2, 0x0C010C00u));
+        const u2 om = __builtin_bit_cast(u2, __builtin_amdgcn_perm(d1, d0, 0x0C040C03u));
+        const u2 o1 = __builtin_bit_cast(u2, __builtin_amdgcn_perm(0u, d1, 0x0C020C01u));
+        const u2 o3 = __builtin_bit_cast(u2, __builtin_amdgcn_perm(d2, d1, 0x0C040C03u));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) H[k][0] = H[k + 1][0], H[k][1] = H[k + 1][1];
+        H[4][0] = (em + e2) + (om + o1) * (unsigned short)4 + e0 * (unsigned short)6;
+        H[4][1] = (e0 + e4) + (o1 + o3) * (unsigned short)4 + e2 * (unsigned short)6;
+        // blurred row br (centre of the five newest input rows); meaningful from j = 4 on
+        const int br = y0 - 1 + (j - 4);
+        u2 B[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          B[k] = ((H[0][k] + H[4][k]) + (H[1][k] + H[3][k]) * (unsigned short)4 + H[2][k] * (unsigned short)6 +
+                  (unsigned short)128) >> (unsigned short)8;
+        const uint32_t b01 = __builtin_bit_cast(uint32_t, B[0]), b23 = __builtin_bit_cast(uint32_t, B[1]);
+        if (br >= y0 && br < y_end && owner)
+          *reinterpret_cast<uint32_t*>(pout + (int64_t)br * w + cx) = __builtin_amdgcn_perm(b23, b01, 0x06040200u);
+        // pairs at odd offsets of the blurred row: (-1, 0) with the left lane's (2, 3), (3, 4) with the right lane's (0, 1)
+        const uint32_t l23 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b23, 0x138, 0xF, 0xF, false);
+        const uint32_t r01 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b01, 0x130, 0xF, 0xF, false);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) P[0][k] = P[1][k], P[1][k] = P[2][k];
+        P[2][0] = __builtin_bit_cast(u2, __builtin_amdgcn_alignbit(b01, l23, 16));
+        P[2][1] = __builtin_bit_cast(u2, __builtin_amdgcn_alignbit(b23, b01, 16));
+        P[2][2] = __builtin_bit_cast(u2, __builtin_amdgcn_alignbit(r01, b23, 16));
+        const int sr = br - 1;  // the Scharr row: centre of the three newest blurred rows
+        if (sr >= y0 && sr < y_end && owner) hist_add4_pairs(P[0], P[1], P[2], cx, w, 0, 0u, n_bins, hist, zeros);
+      }
+#pragma unroll
+      for (int b = 0; b < FB; ++b) cur[b] = nxt[b];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void k_blur_hist(const T* __restrict__ src, int64_t plane_stride, int h, int w,
+                                                  int64_t row_stride, const double* __restrict__ d_minmax,
+                                                  uint8_t* __restrict__ d_blur, uint32_t* __restrict__ d_partial) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);  // FINE + COARSE 16-bit counters (<= FW * FH = 63 488 pixels)
+  constexpr int n_bins = FINE + COARSE;
+  const int plane = blockIdx.z;
+  const int tx0 = blockIdx.x * FW;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (rows: scalar arithmetic)
+  const int y0 = blockIdx.y * FH + wave * FR;
+  const int cx = tx0 - 4 + 4 * lane;  // the lane's first column
+  const bool owner = lane >= 1 && lane <= 62 && cx < w;
+  const U8Scale sc = make_scale(d_minmax, plane);
+  const T* pin = src + (int64_t)plane * plane_stride;
+  uint8_t* pout = d_blur + (int64_t)plane * h * w;
+  for (int i = threadIdx.x; i < n_bins / 2; i += NT) hist[i] = 0;
+  __syncthreads();
+  uint32_t zeros = 0;
+  if (y0 < h) {  // (a strip below the image: nothing to do but the hand-over)
+    if (tx0 >= 4 && tx0 + FW + 4 <= w) blur_hist_strip<T, true>(pin, row_stride, h, w, y0, cx, owner, sc, pout, hist, zeros);
+    else blur_hist_strip<T, false>(pin, row_stride, h, w, y0, cx, owner, sc, pout, hist, zeros);
+  }
+  zeros = (uint32_t)mg_wave_sum_i32((int)zeros);
+  if (lane == 0 && zeros) atomicAdd(&hist[0], zeros);  // (bin 0 shares the packed counters: <= 63 488 in all)
+  __syncthreads();
+  uint32_t* slot = d_partial + ((int64_t)plane * gridDim.y * gridDim.x + (int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (n_bins / 2);
+  for (int i = threadIdx.x; i < n_bins / 2; i += NT) slot[i] = hist[i];
 }
 
 // d_hist[plane][bin] += sum over the plane's workgroup slots (packed 16-bit pairs).  The slots are split over
@@ -1274,6 +1431,53 @@ extern "C" int mg_scharr_hist(const uint8_t* d_blur, int n_planes, int h, int w,
                        dim3(NT), 0, mg_stream(stream), d_scratch, slots, n_bins, d_hist, mode == 1 ? d_base : nullptr);
     MG_CHECK_LAUNCH();
   }
+  return MG_OK;
+}
+
+// to_uint8 + blur + combined histogram: one pass where the fused kernel applies (integer input, no un-blurred
+// copy wanted, w % 4 == 0, aligned rows), else the two passes above.
+static bool blur_hist_fused(const void* d_src, int dtype, int64_t plane_stride, int h, int w, int64_t row_stride,
+                            const uint8_t* d_blur, const uint8_t* d_u8) {
+  if (d_u8 || (dtype != MG_U8 && dtype != MG_U16) || h < 2 || w < 8 || (w & 3)) return false;
+  const int64_t esz = dtype == MG_U8 ? 1 : 2;
+  return (reinterpret_cast<uintptr_t>(d_src) % (4 * esz)) == 0 && plane_stride % 4 == 0 && row_stride % 4 == 0 &&
+         (reinterpret_cast<uintptr_t>(d_blur) & 3) == 0;
+}
+
+extern "C" int64_t mg_blur_hist_scratch_words(int n_planes, int h, int w) {
+  if (n_planes < 0 || h < 0 || w < 0) return -1;
+  const int64_t fused = (int64_t)n_planes * ((w + FW - 1) / FW) * ((h + FH - 1) / FH) * ((FINE + COARSE) / 2);
+  return std::max(fused, mg_scharr_hist_scratch_words(n_planes, h, w, 0));
+}
+
+extern "C" int mg_to_uint8_blur_hist(const void* d_src, int dtype, int n_planes, int64_t plane_stride, int h, int w,
+                                     int64_t row_stride, const double* d_minmax, uint8_t* d_blur, uint8_t* d_u8,
+                                     uint32_t* d_hist, uint32_t* d_scratch, int64_t scratch_words, void* stream) {
+  if (!d_src || !d_blur || !d_hist || n_planes < 0 || h < 0 || w < 0) return MG_EINVAL;
+  if (!d_minmax && dtype != MG_U8) return MG_EINVAL;
+  if (n_planes == 0 || h == 0 || w == 0) return MG_OK;
+  if (d_scratch && scratch_words < mg_blur_hist_scratch_words(n_planes, h, w)) return MG_EINVAL;
+  static const bool off = getenv("MG_NO_BLUR_HIST") != nullptr;
+  if (off || !d_scratch || !blur_hist_fused(d_src, dtype, plane_stride, h, w, row_stride, d_blur, d_u8)) {
+    const int rc = mg_to_uint8_blur(d_src, dtype, n_planes, plane_stride, h, w, row_stride, d_minmax, d_blur, d_u8, stream);
+    if (rc != MG_OK) return rc;
+    return mg_scharr_hist(d_blur, n_planes, h, w, 0, nullptr, d_hist, d_scratch, scratch_words, stream);
+  }
+  const dim3 g((w + FW - 1) / FW, (h + FH - 1) / FH, n_planes);
+  if (g.y > 65535 || g.z > 65535) return MG_EINVAL;
+  hipStream_t s = mg_stream(stream);
+  constexpr int n_bins = FINE + COARSE;
+  if (dtype == MG_U8)
+    hipLaunchKernelGGL((k_blur_hist<uint8_t>), g, dim3(NT), (size_t)n_bins * 2, s, (const uint8_t*)d_src, plane_stride, h, w,
+                       row_stride, d_minmax, d_blur, d_scratch);
+  else
+    hipLaunchKernelGGL((k_blur_hist<uint16_t>), g, dim3(NT), (size_t)n_bins * 2, s, (const uint16_t*)d_src, plane_stride, h,
+                       w, row_stride, d_minmax, d_blur, d_scratch);
+  MG_CHECK_LAUNCH();
+  const int slots = (int)(g.x * g.y);
+  hipLaunchKernelGGL(k_hist_reduce, dim3((n_bins / 2 + NT - 1) / NT, n_planes, (slots + HIST_SLOTS_PER_BLOCK - 1) / HIST_SLOTS_PER_BLOCK),
+                     dim3(NT), 0, s, d_scratch, slots, n_bins, d_hist, (const uint32_t*)nullptr);
+  MG_CHECK_LAUNCH();
   return MG_OK;
 }
 

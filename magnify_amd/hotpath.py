@@ -344,7 +344,7 @@ class CircleFinder:
         self.hist = torch.zeros((P, COMBINED_BINS), dtype=i32, device=dev)
         self.hist_base = torch.zeros((P,), dtype=i32, device=dev)
         # per-workgroup histogram slots: plain stores + a reduce kernel instead of global atomics
-        self.hist_scratch = torch.empty((int(nat.lib().mg_scharr_hist_scratch_words(P, h, w, 0)),), dtype=i32, device=dev)
+        self.hist_scratch = torch.empty((int(nat.lib().mg_blur_hist_scratch_words(P, h, w)),), dtype=i32, device=dev)
         self.thresh = torch.zeros((P, 2), dtype=i32, device=dev)
         self.quant_d = torch.zeros((P, 2), dtype=torch.float32, device=dev)  # np.quantile's two values per plane
         # Every per-plane counter the host ever looks at lives in ONE block: one fill clears it, one copy fetches it
@@ -473,11 +473,11 @@ class CircleFinder:
         elif minmax is None:
             minmax = plane_minmax(planes)
         self.u8 = torch.empty((P, h, w), dtype=torch.uint8, device=self.dev) if keep_u8 else None
-        _call("mg_to_uint8_blur", planes.data_ptr(), code, P, planes.stride(0), h, w, planes.stride(1),
-                                     _ptr(minmax), self.blur.data_ptr(), _ptr(self.u8), s)
-        # one-pass combined histogram of m = dx^2 + dy^2: exact below 8192, coarse (m >> 13) above
+        # to_uint8 + blur and the one-pass combined histogram of m = dx^2 + dy^2 (exact below 8192, coarse (m >> 13)
+        # above) of the blurred planes: one kernel for integer inputs, else two passes behind the same entry point
         self.hist.zero_()
-        _call("mg_scharr_hist", self.blur.data_ptr(), P, h, w, 0, 0, self.hist.data_ptr(), self.hist_scratch.data_ptr(),
+        _call("mg_to_uint8_blur_hist", planes.data_ptr(), code, P, planes.stride(0), h, w, planes.stride(1), _ptr(minmax),
+              self.blur.data_ptr(), _ptr(self.u8), self.hist.data_ptr(), self.hist_scratch.data_ptr(),
               self.hist_scratch.numel(), s)
         n = h * w
         idx = [quantile_indexes(n, q) for q in (low_q, high_q)]  # (prev, next, gamma) per quantile

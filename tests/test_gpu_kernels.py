@@ -162,6 +162,49 @@ def test_to_uint8_blur(hp, dtype, shape):
         np.testing.assert_array_equal(blur[k], rcv.gaussian_blur5(want))
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint8])
+@pytest.mark.parametrize("shape", [(2, 300, 512), (1, 257, 248), (3, 70, 252), (1, 2, 8), (1, 700, 1000), (2, 64, 260), (1, 5, 12)])
+def test_blur_and_histogram_in_one_pass(hp, dtype, shape):
+    """mg_to_uint8_blur_hist (one kernel: strips of 248 columns x 64 rows per wave, neighbours by wave shifts) against the
+    oracle's blur and against the two-pass histogram (mg_scharr_hist mode 0) of the same planes."""
+    from magnify_amd import _native as nat
+
+    rng = np.random.default_rng(shape[1] * 7 + shape[2])
+    p, h, w = shape
+    planes = rng.integers(0, np.iinfo(dtype).max // 3, size=shape).astype(dtype)
+    planes[0, :, : w // 2] //= 16  # a flat-ish half: many zero magnitudes
+    d = dev(planes)
+    mm = hp.plane_minmax(d)
+    lib, s = nat.lib(), torch.cuda.current_stream().cuda_stream
+    words = int(lib.mg_blur_hist_scratch_words(p, h, w))
+    assert words >= int(lib.mg_scharr_hist_scratch_words(p, h, w, 0))
+    scratch = torch.empty((words,), dtype=torch.int32, device="cuda")
+    blur = torch.zeros((p, h, w), dtype=torch.uint8, device="cuda")
+    hist = torch.zeros((p, 12288), dtype=torch.int32, device="cuda")
+    nat.check(lib.mg_to_uint8_blur_hist(d.data_ptr(), nat.dtype_code(d.dtype), p, d.stride(0), h, w, d.stride(1), mm.data_ptr(),
+                                        blur.data_ptr(), 0, hist.data_ptr(), scratch.data_ptr(), words, s), "blur_hist")
+    for k in range(p):
+        np.testing.assert_array_equal(blur[k].cpu().numpy(), rcv.gaussian_blur5(rn.to_uint8(planes[k])))
+    hist2 = torch.zeros_like(hist)
+    nat.check(lib.mg_scharr_hist(blur.data_ptr(), p, h, w, 0, 0, hist2.data_ptr(), scratch.data_ptr(), words, s), "hist")
+    assert torch.equal(hist, hist2)
+    assert hist.sum(dim=1).tolist() == [h * w] * p
+    # a view with padded rows and planes (strides that keep the 4-element alignment), and the un-blurred copy asked for
+    # (the two-pass route behind the same entry point)
+    wide = torch.zeros((p, h + 3, w + 8), dtype=d.dtype, device="cuda")
+    wide[:, :h, :w] = d
+    view = wide[:, :h, :w]
+    blur3, hist3, u8 = torch.zeros_like(blur), torch.zeros_like(hist), torch.zeros_like(blur)
+    nat.check(lib.mg_to_uint8_blur_hist(view.data_ptr(), nat.dtype_code(d.dtype), p, view.stride(0), h, w, view.stride(1),
+                                        mm.data_ptr(), blur3.data_ptr(), 0, hist3.data_ptr(), scratch.data_ptr(), words, s), "blur_hist")
+    assert torch.equal(blur3, blur) and torch.equal(hist3, hist)
+    blur3.zero_(), hist3.zero_()
+    nat.check(lib.mg_to_uint8_blur_hist(d.data_ptr(), nat.dtype_code(d.dtype), p, d.stride(0), h, w, d.stride(1), mm.data_ptr(),
+                                        blur3.data_ptr(), u8.data_ptr(), hist3.data_ptr(), scratch.data_ptr(), words, s), "blur_hist")
+    assert torch.equal(blur3, blur) and torch.equal(hist3, hist)
+    np.testing.assert_array_equal(u8[0].cpu().numpy(), rn.to_uint8(planes[0]))
+
+
 def test_to_uint8_golden_and_constant(hp, golden):
     g = golden("to_uint8")
     for key in ("a16", "a16n", "af32", "af64", "const"):

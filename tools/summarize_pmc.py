@@ -14,7 +14,7 @@ import bench  # noqa: E402
 
 tag, fetch_dir, write_dir, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 STAGE_OF = {"k_flatfield_max": "mg_flatfield_max", "k_flat_rcmax": "mg_flatfield_max", "k_apply_stitch": "mg_flatfield_apply_stitch",
-            "k_u8_blur": "mg_to_uint8_blur", "k_scharr_hist": "mg_scharr_hist", "k_hist_reduce": "mg_scharr_hist",
+            "k_u8_blur": "mg_to_uint8_blur", "k_blur_hist": "mg_to_uint8_blur_hist", "k_scharr_hist": "mg_scharr_hist", "k_hist_reduce": "mg_to_uint8_blur_hist",
             "k_edge_thresholds": "mg_edge_thresholds", "k_window_resolve": "mg_edge_thresholds", "k_canny_nms": "mg_canny_nms",
             "k_hysteresis": "mg_canny_hysteresis", "k_cell_": "mg_edge_grid", "k_edge_angles": "mg_edge_angles",
             "k_candidates": "mg_candidate_circles", "k_layer_": "mg_bitmap_to_circles", "k_tile_": "mg_bitmap_to_circles",

@@ -10,7 +10,7 @@ import sys
 tag, stats_dir, fetch_dir, write_dir, steps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
 shutil.copy(glob.glob(f"{stats_dir}/**/*kernel_stats.csv", recursive=True)[0], f"profiles/{tag}_kernel_stats.csv")
 
-STAGE_OF = {"k_flatfield_max": "mg_flatfield_max", "k_apply_stitch": "mg_flatfield_apply_stitch", "k_u8_blur": "mg_to_uint8_blur",
+STAGE_OF = {"k_flatfield_max": "mg_flatfield_max", "k_apply_stitch": "mg_flatfield_apply_stitch", "k_u8_blur": "mg_to_uint8_blur", "k_blur_hist": "mg_to_uint8_blur_hist",
             "k_scharr_hist": "mg_scharr_hist", "k_canny_nms": "mg_canny_nms", "k_hysteresis": "mg_canny_hysteresis",
             "k_cell_": "mg_edge_grid", "k_edge_angles": "mg_edge_angles", "k_candidates": "mg_candidate_circles",
             "k_layer_": "mg_bitmap_to_circles", "k_tile_": "mg_bitmap_to_circles", "k_score_tiles": "mg_score_circles",
