@@ -53,6 +53,7 @@ def algorithmic_bytes(stage, p):
         "mg_circle_labels": p["markers"] * p["mean_disk"] * 8,
         "mg_roi_gather_reduce_batched": p["markers"] * p["L"] ** 2 * (4 * c + 6),
         "mg_roi_segment_reduce": p["markers"] * p["L"] ** 2 * (4 * c + 2),  # no label map: pixels in/out + masks out
+        "mg_roi_window_order": p["markers"] * (12 + 4),       # bead triples in, order out
         "mg_plane_minmax": 2 * planes * n,
     }
     return table.get(stage)
@@ -95,11 +96,12 @@ STAGE_NOTES = {
 }
 
 # stages launched outside the finder's chain: timed live in the timed region even when the chain is a graph replay
-LIVE_STAGES = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_roi_segment_reduce", "mg_counts_to_offsets"]
+LIVE_STAGES = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_roi_segment_reduce", "mg_counts_to_offsets",
+               "mg_roi_window_order"]
 
 STREAM_STAGES = ["mg_flatfield_max", "mg_flatfield_apply_stitch", "mg_to_uint8_blur", "mg_to_uint8_blur_hist", "mg_scharr_hist", "mg_canny_nms",
                  "mg_canny_hysteresis", "mg_edge_grid", "mg_edge_angles", "mg_circle_labels",
-                 "mg_roi_gather_reduce_batched", "mg_roi_segment_reduce"]
+                 "mg_roi_gather_reduce_batched", "mg_roi_window_order", "mg_roi_segment_reduce"]
 
 
 def source_hash():

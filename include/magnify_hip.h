@@ -452,8 +452,15 @@ int mg_marker_table(const int32_t* d_beads, int64_t bead_stride, const int32_t* 
  * Outputs as mg_roi_gather_reduce. */
 int mg_roi_segment_reduce(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h, int w,
                           int time_major, const int32_t* d_beads, int64_t bead_stride, const int32_t* d_assay_offsets,
-                          int n_assays, int m, int roi_len, const int32_t* d_halfwidths, int max_r, void* d_roi,
-                          uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream);
+                          int n_assays, int m, const int32_t* d_order, int roi_len, const int32_t* d_halfwidths, int max_r,
+                          void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream);
+
+/* d_order[0 .. m) for mg_roi_segment_reduce (NULL there: markers are visited as listed): the markers of every assay
+ * band by band (64 rows) and left to right inside a band, so that windows which share image lines are gathered at
+ * about the same time and meet in the L2s (the reference walks its beads in score order, find.py:571-602; the order
+ * of the work is free, every marker's outputs stay at the marker's index).  Tables as for mg_roi_segment_reduce. */
+int mg_roi_window_order(const int32_t* d_beads, int64_t bead_stride, const int32_t* d_assay_offsets, int n_assays, int m,
+                        int32_t* d_order, void* stream);
 
 /* Masked median of an already gathered roi (m, C, T, L, L) of element type `dtype` (MG_U8 / U16 / F32 / F64):
  * roi.where(mask).median(dim=[roi_x, roi_y]) of identify.py:76-80 and filter.py:20-22, 74, 82 with numpy's nanmedian

@@ -71,7 +71,8 @@ PROTOTYPES = {
     "mg_roi_gather_reduce": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mg_roi_gather_reduce_batched": [_p, _i, _l, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mg_counts_to_offsets": [_p, _i, _i, _p, _p],
-    "mg_roi_segment_reduce": [_p, _i, _l, _i, _i, _i, _i, _i, _p, _l, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p],
+    "mg_roi_segment_reduce": [_p, _i, _l, _i, _i, _i, _i, _i, _p, _l, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p],
+    "mg_roi_window_order": [_p, _l, _p, _i, _i, _p, _p],
     "mg_roi_masked_median": [_p, _i, _p, _l, _l, _i, _i, _i, _i, _p, _p],
     "mg_roi_masked_median_u16": [_p, _p, _i, _i, _i, _i, _p, _p],
     "mg_cluster1d_costs": [_p, _i, _i, _i, _d, _p, _d, _p, _p],

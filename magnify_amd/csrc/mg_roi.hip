@@ -170,6 +170,7 @@ __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64
                                             const int32_t* __restrict__ d_marker_local, int len,
                                             const int32_t* __restrict__ d_labels,
                                             const int32_t* __restrict__ d_assay_offsets, int n_assays, int64_t bead_stride, int time_major,
+                                            const int32_t* __restrict__ d_order,
                                             const int32_t* __restrict__ d_halfwidths, int max_r, T* __restrict__ d_roi,
                                             uint8_t* __restrict__ d_fg, uint8_t* __restrict__ d_bg,
                                             double* __restrict__ d_sums, int32_t* __restrict__ d_counts) {
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(NT) void k_roi(const T* __restrict__ d_image, int64
     // flat grid over the markers of all assays (the launch may be sized by an upper bound: the rest leaves at once);
     // the marker's assay = the last one that starts at or before it
     if (g >= d_assay_offsets[n_assays]) return;
+    if (d_order) g = d_order[g];  // the order the windows are visited in (mg_roi_window_order); outputs stay in place
     int lo = 0, hi = n_assays;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
@@ -303,6 +305,7 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
                                                      const int32_t* __restrict__ d_marker_local, int len,
                                                      const int32_t* __restrict__ d_labels,
                                                      const int32_t* __restrict__ d_assay_offsets, int n_assays, int64_t bead_stride, int time_major,
+                                                     const int32_t* __restrict__ d_order,
                                                      const int32_t* __restrict__ d_halfwidths, int max_r,
                                                      uint16_t* __restrict__ d_roi, uint8_t* __restrict__ d_fg,
                                                      uint8_t* __restrict__ d_bg, double* __restrict__ d_sums,
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(NT) void k_roi_u16_even(const uint16_t* __restrict_
     // flat grid over the markers of all assays (the launch may be sized by an upper bound: the rest leaves at once);
     // the marker's assay = the last one that starts at or before it
     if (g >= d_assay_offsets[n_assays]) return;
+    if (d_order) g = d_order[g];  // the order the windows are visited in (mg_roi_window_order); outputs stay in place
     int lo = 0, hi = n_assays;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
@@ -917,11 +921,11 @@ template <typename T, typename ACC>
 int launch_roi(const void* d_image, int64_t assay_stride, int n_c, int n_t, int h, int w, const int32_t* d_beads,
                const int32_t* d_marker_assay, const int32_t* d_marker_local, dim3 grid, int len,
                const int32_t* d_labels, const int32_t* d_assay_offsets, int n_assays, int64_t bead_stride, int time_major,
-               const int32_t* d_halfwidths,
+               const int32_t* d_order, const int32_t* d_halfwidths,
                int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg, double* d_sums, int32_t* d_counts, hipStream_t s) {
   hipLaunchKernelGGL((k_roi<T, ACC>), grid, dim3(NT), roi_lds_bytes(len, d_halfwidths != nullptr), s,
                      (const T*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, len,
-                     d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_halfwidths, max_r, (T*)d_roi, d_fg, d_bg, d_sums, d_counts);
+                     d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_order, d_halfwidths, max_r, (T*)d_roi, d_fg, d_bg, d_sums, d_counts);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -945,7 +949,7 @@ namespace {
 int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h, int w,
                  const int32_t* d_beads, const int32_t* d_marker_assay, const int32_t* d_marker_local, int m, int roi_len,
                  const int32_t* d_labels, const int32_t* d_assay_offsets, int64_t bead_stride, int time_major, int n_assays,
-                 const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
+                 const int32_t* d_order, const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
                  double* d_sums, int32_t* d_counts, void* stream) {
   if (!d_image || !d_beads || m < 0 || roi_len <= 0 || n_c <= 0 || n_t <= 0) return MG_EINVAL;
   if (roi_len > h || roi_len > w || roi_lds_bytes(roi_len, d_halfwidths != nullptr) > 60000) return MG_EINVAL;
@@ -987,7 +991,7 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
     // 1.14 ms; without the pipelining 1.22, one row per trip 1.22, 4 rows x 2 planes 1.20, 4 x 4 unpipelined 1.24)
     hipLaunchKernelGGL((k_roi_u16_even<2, 4, true>), grid, dim3(NT), (size_t)mask_words(roi_len) * 4, s,
                        (const uint16_t*)d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                       roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg,
+                       roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_order, d_halfwidths, max_r, (uint16_t*)d_roi, d_fg, d_bg,
                        d_sums, d_counts);
     MG_CHECK_LAUNCH();
     return MG_OK;
@@ -995,19 +999,19 @@ int roi_dispatch(const void* d_image, int dtype, int64_t assay_stride, int n_c, 
   switch (dtype) {
     case MG_U8:
       return launch_roi<uint8_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
-                                            d_marker_local, grid, roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_halfwidths, max_r,
+                                            d_marker_local, grid, roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_order, d_halfwidths, max_r,
                                             d_roi, d_fg, d_bg, d_sums, d_counts, s);
     case MG_U16:
       return launch_roi<uint16_t, long long>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay,
-                                             d_marker_local, grid, roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_halfwidths, max_r,
+                                             d_marker_local, grid, roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_order, d_halfwidths, max_r,
                                              d_roi, d_fg, d_bg, d_sums, d_counts, s);
     case MG_F32:
       return launch_roi<float, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                                       grid, roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                                       grid, roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_order, d_halfwidths, max_r, d_roi, d_fg, d_bg,
                                        d_sums, d_counts, s);
     case MG_F64:
       return launch_roi<double, double>(d_image, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local,
-                                        grid, roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                                        grid, roi_len, d_labels, d_assay_offsets, n_assays, bead_stride, time_major, d_order, d_halfwidths, max_r, d_roi, d_fg, d_bg,
                                         d_sums, d_counts, s);
   }
   return MG_EINVAL;
@@ -1093,18 +1097,94 @@ extern "C" int mg_roi_gather_reduce_batched(const void* d_image, int dtype, int6
                                             const int32_t* d_labels, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
                                             double* d_sums, int32_t* d_counts, void* stream) {
   return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, d_marker_assay, d_marker_local, m, roi_len,
-                      d_labels, nullptr, 0, 0, 0, nullptr, 0, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
+                      d_labels, nullptr, 0, 0, 0, nullptr, nullptr, 0, d_roi, d_fg, d_bg, d_sums, d_counts, stream);
+}
+
+namespace {
+// ---- the order the windows of an assay are visited in ---------------------------------------------------------
+// The beads of an assay arrive in suppression (score) order, spatially random: two windows that share image lines
+// (200-byte rows at arbitrary alignment touch 2.56 lines of 128 B; neighbouring windows overlap) are then worked on
+// long after each other and every one fetches its lines from HBM again.  Visited band by band (64 rows) and left to
+// right inside a band, neighbours are in flight together and meet in the L2s: 4.73 instead of 5.17 ms at C4 in
+// tools/roi_order_probe.py.  d_order[g] = the marker the g-th workgroup takes; only the ORDER of the work changes,
+// every marker's outputs stay where they were.  ORDER_PARTS workgroups per assay hold the assay's keys in LDS and rank
+// slices of 256 markers each: rank = keys before the marker that are <= its key + keys after it that are < (equal
+// keys keep their table order) -- two instructions per key except in the few chunks around the wave's own markers.
+// (One workgroup of 1024 per assay took 180 us at C4: 2 000^2 compares on one CU.)  An assay with more beads than
+// ORDER_CAP keeps its order.
+constexpr int ORDER_CAP = 8192;
+constexpr int ORDER_BAND = 6;  // log2 of the band height
+constexpr int ORDER_PARTS = 8;
+
+__global__ __launch_bounds__(NT) void k_window_order(const int32_t* __restrict__ d_beads, int64_t bead_stride,
+                                                     const int32_t* __restrict__ d_assay_offsets, int m,
+                                                     int32_t* __restrict__ d_order) {
+  __shared__ __attribute__((aligned(16))) uint32_t keys[ORDER_CAP];
+  const int assay = blockIdx.x;
+  const int first = d_assay_offsets[assay];
+  const int n = min(d_assay_offsets[assay + 1], m) - first;  // (markers beyond the launch's bound m are not worked on)
+  if (n <= 0) return;
+  if (n > ORDER_CAP) {
+    for (int i = blockIdx.y * NT + threadIdx.x; i < n; i += ORDER_PARTS * NT) d_order[first + i] = first + i;
+    return;
+  }
+  const int32_t* b = d_beads + 3 * (bead_stride ? (int64_t)assay * bead_stride : (int64_t)first);
+  const int n4 = (n + 3) & ~3, nq = n4 >> 2;
+  for (int i = threadIdx.x; i < n4; i += NT) {
+    uint32_t k = 0xFFFFFFFFu;  // (padding: after every marker, above every key)
+    if (i < n) {
+      const int row = min(max(b[3 * i], 0), (1 << 20) - 1), col = min(max(b[3 * i + 1], 0), (1 << 17) - 1);
+      k = ((uint32_t)(row >> ORDER_BAND) << 17) | (uint32_t)col;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  const uint4* k4 = reinterpret_cast<const uint4*>(keys);
+  for (int i0 = blockIdx.y * NT; i0 < n; i0 += ORDER_PARTS * NT) {
+    const int i = i0 + threadIdx.x;
+    const int w0 = __builtin_amdgcn_readfirstlane(i0 + (int)(threadIdx.x & ~63u));  // the wave's first marker
+    const int q_lo = min(w0 >> 2, nq), q_hi = min((w0 + 63) >> 2, nq - 1);
+    const uint32_t ki = keys[min(i, n - 1)];
+    int rank = 0;
+    for (int q = 0; q < q_lo; ++q) {  // before every marker of the wave
+      const uint4 v = k4[q];
+      rank += (v.x <= ki) + (v.y <= ki) + (v.z <= ki) + (v.w <= ki);
+    }
+    for (int q = q_lo; q <= q_hi; ++q) {  // around them
+      const uint4 v = k4[q];
+      const int j = 4 * q;
+      rank += (v.x < ki || (v.x == ki && j < i)) + (v.y < ki || (v.y == ki && j + 1 < i)) +
+              (v.z < ki || (v.z == ki && j + 2 < i)) + (v.w < ki || (v.w == ki && j + 3 < i));
+    }
+    for (int q = q_hi + 1; q < nq; ++q) {  // after
+      const uint4 v = k4[q];
+      rank += (v.x < ki) + (v.y < ki) + (v.z < ki) + (v.w < ki);
+    }
+    if (i < n) d_order[first + rank] = first + i;
+  }
+}
+}  // namespace
+
+extern "C" int mg_roi_window_order(const int32_t* d_beads, int64_t bead_stride, const int32_t* d_assay_offsets,
+                                   int n_assays, int m, int32_t* d_order, void* stream) {
+  if (!d_beads || !d_assay_offsets || !d_order || n_assays <= 0 || n_assays > 65535 || m < 0 || bead_stride < 0)
+    return MG_EINVAL;
+  if (m == 0) return MG_OK;
+  hipLaunchKernelGGL(k_window_order, dim3(n_assays, ORDER_PARTS), dim3(NT), 0, mg_stream(stream), d_beads, bead_stride,
+                     d_assay_offsets, m, d_order);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
 }
 
 extern "C" int mg_roi_segment_reduce(const void* d_image, int dtype, int64_t assay_stride, int n_c, int n_t, int h,
                                      int w, int time_major, const int32_t* d_beads, int64_t bead_stride,
-                                     const int32_t* d_assay_offsets, int n_assays, int m, int roi_len,
-                                     const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg, uint8_t* d_bg,
-                                     double* d_sums, int32_t* d_counts, void* stream) {
+                                     const int32_t* d_assay_offsets, int n_assays, int m, const int32_t* d_order,
+                                     int roi_len, const int32_t* d_halfwidths, int max_r, void* d_roi, uint8_t* d_fg,
+                                     uint8_t* d_bg, double* d_sums, int32_t* d_counts, void* stream) {
   if (!d_assay_offsets || !d_halfwidths || n_assays <= 0 || n_assays > 65535 || max_r < 0 || bead_stride < 0)
     return MG_EINVAL;
   return roi_dispatch(d_image, dtype, assay_stride, n_c, n_t, h, w, d_beads, nullptr, nullptr, m, roi_len, nullptr,
-                      d_assay_offsets, bead_stride, time_major, n_assays, d_halfwidths, max_r, d_roi, d_fg, d_bg,
+                      d_assay_offsets, bead_stride, time_major, n_assays, d_order, d_halfwidths, max_r, d_roi, d_fg, d_bg,
                       d_sums, d_counts, stream);
 }
 

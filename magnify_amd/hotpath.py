@@ -1123,6 +1123,21 @@ def _upload_i32(values, device):
     return host.to(device, non_blocking=True)
 
 
+_ROI_ORDER = os.environ.get("MG_ROI_ORDER", "1") != "0"
+
+
+def _window_order(d_beads, bead_stride, d_off, n_assays, m, pool_tag):
+    """The order mg_roi_segment_reduce visits the markers in (mg_roi_window_order: band by band, left to right), or
+    None (MG_ROI_ORDER=0: as listed)."""
+    if not _ROI_ORDER or m <= 0:
+        return None
+    dev = d_beads.device
+    d_order = (pooled("roi_order" + pool_tag, m, (), torch.int32, dev) if pool_tag is not None
+               else torch.empty((m,), dtype=torch.int32, device=dev))
+    _call("mg_roi_window_order", d_beads.data_ptr(), int(bead_stride), d_off.data_ptr(), n_assays, m, d_order.data_ptr(), _stream())
+    return d_order
+
+
 def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, labels: torch.Tensor | None,
                       want_roi=True, want_masks=True, want_sums=True, reuse_buffers=False, disks=False,
                       device_tables=None, time_major=False, device_counts=None, pool_tag=""):
@@ -1186,8 +1201,9 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
             d_off = _upload_i32(offsets, dev)
         # where the markers' rows and offsets are on the device (marker_table reads them there)
         res["device_tables"] = (d_tab, int(d_tab.shape[1]), d_off)
+        d_order = _window_order(d_tab, d_tab.shape[1], d_off, a, m, pool_tag if reuse_buffers else None)
         _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
-              int(time_major), d_tab.data_ptr(), d_tab.shape[1], d_off.data_ptr(), a, m, L, tab.data_ptr(), max_r,
+              int(time_major), d_tab.data_ptr(), d_tab.shape[1], d_off.data_ptr(), a, m, _ptr(d_order), L, tab.data_ptr(), max_r,
               _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
         return res
     beads = np.zeros((m, 3), dtype=np.int32)
@@ -1205,8 +1221,9 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         max_r = max(int(beads[:, 2].max()), 2)
         tab = _halfwidth_table(max_r, dev)
         d_off = torch.from_numpy(offsets.astype(np.int32)).to(dev)
+        d_order = _window_order(d_beads, 0, d_off, a, m, pool_tag if reuse_buffers else None)
         _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
-              int(time_major), d_beads.data_ptr(), 0, d_off.data_ptr(), a, m, L, tab.data_ptr(), max_r,
+              int(time_major), d_beads.data_ptr(), 0, d_off.data_ptr(), a, m, _ptr(d_order), L, tab.data_ptr(), max_r,
               _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
         return res
     d_assay = torch.from_numpy(assay).to(dev)

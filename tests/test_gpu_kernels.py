@@ -1145,3 +1145,52 @@ def test_roi_image_centric_pass_equals_window_pass(hp, monkeypatch, L, time_majo
     monkeypatch.delenv("MG_ROI_TILES")
     np.testing.assert_array_equal(light["sums"].cpu().numpy(), want["sums"].cpu().numpy())
     np.testing.assert_array_equal(light["counts"].cpu().numpy(), want["counts"].cpu().numpy())
+
+
+@pytest.mark.parametrize("device_counts", [False, True])
+def test_roi_windows_visited_band_by_band(hp, monkeypatch, device_counts):
+    """mg_roi_window_order: every assay's markers band by band (64 rows) and left to right, equal keys in table order, the
+    markers beyond the launch's bound left out; and the ROI pass that visits its windows in that order writes what the
+    pass in table order writes (compact and padded bead tables, an empty assay, offsets made on the device)."""
+    from magnify_amd import _native as nat
+
+    rng = np.random.default_rng(45)
+    c, t, h, w, L, A = 3, 2, 400, 640, 50, 4
+    images = rng.integers(0, 65536, size=(A, c, t, h, w)).astype(np.uint16)
+    assays = [np.column_stack([rng.integers(-5, h + 5, n), rng.integers(-5, w + 5, n), rng.integers(2, 12, n)]) for n in (700, 0, 33, 1)]
+    assays[0][100:140] = assays[0][100]  # equal keys
+    cap = 720
+    tab = np.zeros((A, cap, 3), dtype=np.int32)
+    for a, beads in enumerate(assays):
+        tab[a, : len(beads)] = beads
+    counts = [len(b) for b in assays]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    m = int(off[-1])
+    lib, s = nat.lib(), torch.cuda.current_stream().cuda_stream
+    for bound in (m, m - 10, m + 50):
+        order = torch.full((bound,), -1, dtype=torch.int32, device="cuda")
+        nat.check(lib.mg_roi_window_order(dev(tab).data_ptr(), cap, dev(off).data_ptr(), A, bound, order.data_ptr(), s), "order")
+        got = order.cpu().numpy()
+        for a, beads in enumerate(assays):
+            lo, hi = int(off[a]), min(int(off[a + 1]), bound)
+            if hi <= lo:
+                continue
+            b = beads[: hi - lo]
+            key = (np.clip(b[:, 0], 0, None) >> 6) * (1 << 17) + np.clip(b[:, 1], 0, None)
+            np.testing.assert_array_equal(got[lo:hi], lo + np.argsort(key, kind="stable"))
+        assert (got[m:] == -1).all()
+    kw = dict(disks=True, device_tables=(dev(tab), counts if not device_counts else None, 11))
+    if device_counts:
+        kw["device_counts"] = (dev(np.asarray(counts, dtype=np.int32)), cap, None)
+    monkeypatch.setattr(hp, "_ROI_ORDER", False)
+    want = hp.roi_gather_reduce(dev(images), None, L, None, **kw)
+    monkeypatch.setattr(hp, "_ROI_ORDER", True)
+    got = hp.roi_gather_reduce(dev(images), None, L, None, **kw)
+    for key in ("roi", "fg", "bg", "sums", "counts"):
+        np.testing.assert_array_equal(got[key].cpu().numpy()[:m], want[key].cpu().numpy()[:m], err_msg=key)
+    # the compact table of the host-side route
+    want = hp.roi_gather_reduce(dev(images), assays, L, None, disks=True)
+    monkeypatch.setattr(hp, "_ROI_ORDER", False)
+    plain = hp.roi_gather_reduce(dev(images), assays, L, None, disks=True)
+    for key in ("roi", "fg", "bg", "sums", "counts"):
+        np.testing.assert_array_equal(plain[key].cpu().numpy(), want[key].cpu().numpy(), err_msg=key)

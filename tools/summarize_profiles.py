@@ -16,7 +16,7 @@ STAGE_OF = {"k_flatfield_max": "mg_flatfield_max", "k_apply_stitch": "mg_flatfie
             "k_layer_": "mg_bitmap_to_circles", "k_tile_": "mg_bitmap_to_circles", "k_score_tiles": "mg_score_circles",
             "k_prefilter": "mg_score_circles", "k_exact": "mg_score_circles", "k_nms<": "mg_nms_rounds",
             "k_collect": "mg_collect_circles", "k_clamp": "mg_collect_circles", "k_circle_labels": "mg_circle_labels",
-            "k_roi": "mg_roi_segment_reduce"}
+            "k_window_order": "mg_roi_window_order", "k_roi": "mg_roi_segment_reduce"}
 
 
 def agg(d, name):
