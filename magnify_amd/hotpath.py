@@ -1124,12 +1124,13 @@ def _upload_i32(values, device):
 
 
 _ROI_ORDER = os.environ.get("MG_ROI_ORDER", "1") != "0"
+_ROI_ORDER_MIN = 16  # assays: below, the pass is bound by latencies, not by its lines (8 timepoints: -0.02 ms for 0.025)
 
 
 def _window_order(d_beads, bead_stride, d_off, n_assays, m, pool_tag):
     """The order mg_roi_segment_reduce visits the markers in (mg_roi_window_order: band by band, left to right), or
     None (MG_ROI_ORDER=0: as listed)."""
-    if not _ROI_ORDER or m <= 0:
+    if not _ROI_ORDER or m <= 0 or n_assays < _ROI_ORDER_MIN:
         return None
     dev = d_beads.device
     d_order = (pooled("roi_order" + pool_tag, m, (), torch.int32, dev) if pool_tag is not None

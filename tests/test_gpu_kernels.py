@@ -1182,6 +1182,7 @@ def test_roi_windows_visited_band_by_band(hp, monkeypatch, device_counts):
     kw = dict(disks=True, device_tables=(dev(tab), counts if not device_counts else None, 11))
     if device_counts:
         kw["device_counts"] = (dev(np.asarray(counts, dtype=np.int32)), cap, None)
+    monkeypatch.setattr(hp, "_ROI_ORDER_MIN", 1)
     monkeypatch.setattr(hp, "_ROI_ORDER", False)
     want = hp.roi_gather_reduce(dev(images), None, L, None, **kw)
     monkeypatch.setattr(hp, "_ROI_ORDER", True)
