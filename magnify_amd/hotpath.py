@@ -1124,13 +1124,14 @@ def _upload_i32(values, device):
 
 
 _ROI_ORDER = os.environ.get("MG_ROI_ORDER", "1") != "0"
-_ROI_ORDER_MIN = 16  # assays: below, the pass is bound by latencies, not by its lines (8 timepoints: -0.02 ms for 0.025)
+_ROI_ORDER_MIN = int(os.environ.get("MG_ROI_ORDER_MIN", "200000"))  # windows x planes: below, the pass is bound by latencies,
+# not by its lines (8 timepoints of C4, 61 k: -0.02 ms for a 0.025 ms kernel; mode R, 1 932 markers x 256 planes: -0.45 ms)
 
 
-def _window_order(d_beads, bead_stride, d_off, n_assays, m, pool_tag):
+def _window_order(d_beads, bead_stride, d_off, n_assays, m, pool_tag, planes=1):
     """The order mg_roi_segment_reduce visits the markers in (mg_roi_window_order: band by band, left to right), or
     None (MG_ROI_ORDER=0: as listed)."""
-    if not _ROI_ORDER or m <= 0 or n_assays < _ROI_ORDER_MIN:
+    if not _ROI_ORDER or m <= 0 or m * planes < _ROI_ORDER_MIN:
         return None
     dev = d_beads.device
     d_order = (pooled("roi_order" + pool_tag, m, (), torch.int32, dev) if pool_tag is not None
@@ -1202,7 +1203,7 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
             d_off = _upload_i32(offsets, dev)
         # where the markers' rows and offsets are on the device (marker_table reads them there)
         res["device_tables"] = (d_tab, int(d_tab.shape[1]), d_off)
-        d_order = _window_order(d_tab, d_tab.shape[1], d_off, a, m, pool_tag if reuse_buffers else None)
+        d_order = _window_order(d_tab, d_tab.shape[1], d_off, a, m, pool_tag if reuse_buffers else None, c * t)
         _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
               int(time_major), d_tab.data_ptr(), d_tab.shape[1], d_off.data_ptr(), a, m, _ptr(d_order), L, tab.data_ptr(), max_r,
               _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
@@ -1222,7 +1223,7 @@ def roi_gather_reduce(images: torch.Tensor, centers_per_assay, roi_len: int, lab
         max_r = max(int(beads[:, 2].max()), 2)
         tab = _halfwidth_table(max_r, dev)
         d_off = torch.from_numpy(offsets.astype(np.int32)).to(dev)
-        d_order = _window_order(d_beads, 0, d_off, a, m, pool_tag if reuse_buffers else None)
+        d_order = _window_order(d_beads, 0, d_off, a, m, pool_tag if reuse_buffers else None, c * t)
         _call("mg_roi_segment_reduce", images.data_ptr(), nat.dtype_code(images.dtype), c * t * h * w, c, t, h, w,
               int(time_major), d_beads.data_ptr(), 0, d_off.data_ptr(), a, m, _ptr(d_order), L, tab.data_ptr(), max_r,
               _ptr(res["roi"]), _ptr(res["fg"]), _ptr(res["bg"]), _ptr(res["sums"]), _ptr(res["counts"]), _stream())
