@@ -458,6 +458,9 @@ def main():
                       "find_calls": chain,
                       # optimistic calls whose ~40 launches went out as one hipGraph replay
                       "graph_replays": sum(getattr(x, "graph_replays", 0) for x in finders),
+                      # the processor's first call timed its passes into several image blocks / ROI output sets and
+                      # kept the fastest (stack.StackProcessor placement trial; None: no trial)
+                      "placement": getattr(proc, "placement", None),
                       "stage_timing": "HIP events on the launch stream: live in the timed region for " + ", ".join(LIVE_STAGES)
                                       + "; the stages inside the finder's chain from the same steps re-run eagerly right after it",
                       "kernel_ms_per_step": total_ms / args.steps},

@@ -1048,6 +1048,16 @@ def pooled(name, count, tail, dtype, device):
     return buf[:count]
 
 
+_ROI_POOL_NAMES = ("roi", "fg", "bg", "sums", "counts", "roi_offsets", "roi_order")
+
+
+def drop_pool_tags(tags):
+    """Free the ROI output sets pooled under these tags ("" = the untagged set)."""
+    names = {n + t for n in _ROI_POOL_NAMES for t in tags}
+    for key in [k for k in _POOL if k[0] in names]:
+        del _POOL[key]
+
+
 def release_pool():
     _POOL.clear()
     _BOUND_OF.clear()  # (the bounds lived in pool blocks)

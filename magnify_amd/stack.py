@@ -13,6 +13,7 @@ from __future__ import annotations
 
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -54,6 +55,8 @@ class StackProcessor:
         self.step_stats = []  # per sub-batch (device counters, host counters) of the last call
         self._roi_bound = None  # markers the ROI pass is launched for before the counts are known (None: capacity)
         self.pool_tag = ""      # which set of pooled output buffers the ROI pass writes (process_stream alternates two)
+        self.placement = None   # what the placement trial of the first call measured (None: no trial)
+        self._placed = False
         self.stage = None  # device staging buffer of the host-ingest path
         if self.n_streams > 1:
             # The stack is cut into contiguous sub-batches of assays; HIP stream / host thread k works
@@ -188,13 +191,91 @@ class StackProcessor:
         else:
             if not stack.is_cuda:
                 stack = stack.to(self.dev, non_blocking=True)
-            self.flatfield(stack, flatfield, darkfield)
+            tries = self._placement_tries()
+            if tries:
+                self._trial_image_blocks(stack, flatfield, darkfield, tries[0])
+            else:
+                self.flatfield(stack, flatfield, darkfield)
             if self.mode == "P" and len(self.search_channels) == 1 and self.batch >= self.n_assays:
-                return self._detect_reduce_on_device(seed, want_roi)
+                out = self._detect_reduce_on_device(seed, want_roi)
+                return self._trial_roi_sets(out, want_roi, tries[1]) if tries else out
             beads = self.detect(seed)
         out = self.segment_reduce(beads, want_roi=want_roi)
         out["beads"] = beads
         return out
+
+    # ---- placement trial ------------------------------------------------------------------------------------------
+    # The correction pass and the ROI pass each run at one of two levels for the life of a process (3.30 / 3.47 ms,
+    # 4.2 / 4.6 ms at 64 x 4 x 4096^2), decided by where the image block and the ROI output set landed in physical
+    # memory (not translation, not virtual offsets; between BLOCKS of one process the same two levels
+    # show, tools/placement_probe.py).  A process cannot choose where a block lands -- but it can ask for several and keep
+    # the best: at the FIRST call of a large mode-P processor the flat-field passes are timed into a few image blocks and
+    # the ROI pass into a few output sets; the fastest stay, the rest is freed before the second call.  Transient memory:
+    # tries x the block; time: tries x the pass, once.  MG_PLACEMENT_TRIES="images,sets" (0: off).
+    def _placement_tries(self):
+        if self._placed:
+            return None
+        self._placed = True
+        try:
+            n_img, n_set = (int(v) for v in os.environ.get("MG_PLACEMENT_TRIES", "6,3").split(","))
+        except ValueError:
+            return None
+        block = self.image.numel() * self.image.element_size()
+        if (n_img < 2 and n_set < 2) or self.mode != "P" or self.pool_tag or self.n_streams > 1 or block < (1 << 31):
+            return None  # (small stacks are bound by latencies; the streaming path alternates two sets of its own)
+        free, _ = torch.cuda.mem_get_info(self.dev)
+        roi_set = self.n_assays * 2500 * self.L * self.L * (2 * self.C + 2)  # ~ markers x (pixels + masks)
+        if free < (max(n_img, 1) + 1) * block + (max(n_set, 1) + 1) * roi_set:
+            return None
+        self.placement = {}
+        return max(n_img, 1), max(n_set, 1)
+
+    def _timed(self, fn, reps=2):
+        best = float("inf")
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            b.synchronize()
+            best = min(best, a.elapsed_time(b))
+        return best
+
+    def _trial_image_blocks(self, stack, flatfield, darkfield, tries):
+        """The flat-field passes timed into ``tries`` image blocks; the fastest stays self.image (it holds the
+        corrected stack, as every block tried does)."""
+        best, best_ms, times = None, float("inf"), []
+        for k in range(tries):
+            cand = self.image if k == 0 else torch.empty_like(self.image)
+            self.image = cand
+            ms = self._timed(lambda: self.flatfield(stack, flatfield, darkfield))
+            times.append(round(ms, 3))
+            if ms < best_ms:
+                best, best_ms = cand, ms  # (the block before it, if any, is freed with its last reference)
+            del cand
+        self.image = best
+        self.placement.update(flatfield_ms=times, image_block=int(np.argmin(times)))
+
+    def _trial_roi_sets(self, out, want_roi, tries):
+        """The ROI pass of the call that has just run, repeated into ``tries`` output sets of their own; the fastest
+        is this processor's from now on (``pool_tag``), the others and the untagged set of the call are freed."""
+        tabs = out.get("device_tables")
+        if tabs is None or tries < 2:
+            return out
+        T, C, h, w = self.T, self.C, self.h, self.w
+        counts = [len(b) for b in out["beads"]]
+        tags = ["#place%d" % k for k in range(tries)]
+        run = lambda tag: hp.roi_gather_reduce(self.image.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi,  # noqa: E731
+                                               reuse_buffers=True, disks=True, device_tables=(tabs[0], counts, self.max_r),
+                                               pool_tag=tag)
+        times = [round(self._timed(lambda: run(tag)), 3) for tag in tags]
+        keep = int(np.argmin(times))
+        hp.drop_pool_tags([""] + [t for k, t in enumerate(tags) if k != keep])
+        self.pool_tag = tags[keep]
+        self.placement.update(roi_ms=times, roi_set=keep)
+        res = run(self.pool_tag)  # the call's result, in the set that stays
+        res["beads"] = out["beads"]
+        return res
 
     def _detect_reduce_on_device(self, seed, want_roi):
         """One search channel, the whole stack in one batch: there is no cross-channel de-duplication

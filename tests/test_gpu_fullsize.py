@@ -404,3 +404,41 @@ def test_save_and_spill_a_gpu_resident_result(mg, tmp_path):
     assert isinstance(xp.variables["bg"].raw, np.memmap)  # backed by a file in the process's spill directory
     for k, v in ref.items():
         np.testing.assert_array_equal(np.asarray(xp[k].values), v, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_placement_trial_changes_nothing_but_the_blocks(mg, monkeypatch):
+    """The first call of a large mode-P processor times its passes into several image blocks / ROI output sets and keeps
+    the fastest (StackProcessor._placement_tries): the results of that call and of the next are those of a processor
+    that never tried (MG_PLACEMENT_TRIES=0), and the blocks not kept are gone."""
+    import torch
+
+    from magnify_amd import hotpath as hp
+    from magnify_amd.stack import StackProcessor, synthetic_stack
+
+    T, C, S = 17, 4, 4096  # 2.3 GB of image: above the trial's threshold
+    stack, _ = synthetic_stack(T, C, S, S, seed=77)
+    kw = dict(num_iter=200_000, search_channels=(0,), mode="P")
+
+    def run(tries):
+        monkeypatch.setenv("MG_PLACEMENT_TRIES", tries)
+        hp.release_pool()
+        proc = StackProcessor(T, C, S, S, **kw)
+        outs = []
+        for seed in (3, 4):
+            o = proc(stack, 1.0, 100.0, seed=seed)
+            outs.append({k: (o[k].clone() if torch.is_tensor(o[k]) else o[k]) for k in ("roi", "fg", "bg", "sums", "counts", "beads")})
+        return proc, outs
+
+    plain, want = run("0")
+    assert plain.placement is None
+    del plain
+    tried, got = run("3,3")
+    assert len(tried.placement["flatfield_ms"]) == 3 and len(tried.placement["roi_ms"]) == 3
+    assert tried.pool_tag == "#place%d" % tried.placement["roi_set"]
+    assert not [k for k in hp._POOL if k[0] in ("roi", "roi#place%d" % ((tried.placement["roi_set"] + 1) % 3))]
+    for a, b in zip(want, got):
+        m = sum(len(x) for x in a["beads"])
+        assert m == sum(len(x) for x in b["beads"]) and all(np.array_equal(x, y) for x, y in zip(a["beads"], b["beads"]))
+        for key in ("roi", "fg", "bg", "sums", "counts"):
+            assert torch.equal(a[key][:m], b[key][:m]), key
