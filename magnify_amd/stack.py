@@ -56,6 +56,7 @@ class StackProcessor:
         self._roi_bound = None  # markers the ROI pass is launched for before the counts are known (None: capacity)
         self.pool_tag = ""      # which set of pooled output buffers the ROI pass writes (process_stream alternates two)
         self.placement = None   # what the placement trial of the first call measured (None: no trial)
+        self._trial_blocks = None
         self._placed = False
         self.stage = None  # device staging buffer of the host-ingest path
         if self.n_streams > 1:
@@ -199,6 +200,10 @@ class StackProcessor:
             if self.mode == "P" and len(self.search_channels) == 1 and self.batch >= self.n_assays:
                 out = self._detect_reduce_on_device(seed, want_roi)
                 return self._trial_roi_sets(out, want_roi, tries[1]) if tries else out
+            if tries:  # (no device-side ROI route to try from: the block chosen by its flat-field time stays)
+                self._trial_blocks = None
+                torch.cuda.empty_cache()
+                self.placement.update(image_block=int(np.argmin(self.placement["flatfield_ms"])))
             beads = self.detect(seed)
         out = self.segment_reduce(beads, want_roi=want_roi)
         out["beads"] = beads
@@ -210,14 +215,14 @@ class StackProcessor:
     # memory (not translation, not virtual offsets; between BLOCKS of one process the same two levels
     # show, tools/placement_probe.py).  A process cannot choose where a block lands -- but it can ask for several and keep
     # the best: at the FIRST call of a large mode-P processor the flat-field passes are timed into a few image blocks and
-    # the ROI pass into a few output sets; the fastest stay, the rest is freed before the second call.  Transient memory:
-    # tries x the block; time: tries x the pass, once.  MG_PLACEMENT_TRIES="images,sets" (0: off).
+    # the ROI pass from every one of them into a few output sets; the fastest PAIR stays, the rest is freed before the
+    # second call.  Transient memory: tries x the block; time: images x sets ROI passes, once.  MG_PLACEMENT_TRIES="images,sets" (0: off).
     def _placement_tries(self):
         if self._placed:
             return None
         self._placed = True
         try:
-            n_img, n_set = (int(v) for v in os.environ.get("MG_PLACEMENT_TRIES", "6,3").split(","))
+            n_img, n_set = (int(v) for v in os.environ.get("MG_PLACEMENT_TRIES", "4,3").split(","))
         except ValueError:
             return None
         block = self.image.numel() * self.image.element_size()
@@ -242,38 +247,44 @@ class StackProcessor:
         return best
 
     def _trial_image_blocks(self, stack, flatfield, darkfield, tries):
-        """The flat-field passes timed into ``tries`` image blocks; the fastest stays self.image (it holds the
-        corrected stack, as every block tried does)."""
-        best, best_ms, times = None, float("inf"), []
+        """The flat-field passes timed into ``tries`` image blocks.  All of them are kept until the ROI pass has been
+        tried from them too (_trial_roi_sets; each holds the corrected stack); the fastest is self.image meanwhile."""
+        blocks, times = [], []
         for k in range(tries):
-            cand = self.image if k == 0 else torch.empty_like(self.image)
-            self.image = cand
-            ms = self._timed(lambda: self.flatfield(stack, flatfield, darkfield))
-            times.append(round(ms, 3))
-            if ms < best_ms:
-                best, best_ms = cand, ms  # (the block before it, if any, is freed with its last reference)
-            del cand
-        self.image = best
-        self.placement.update(flatfield_ms=times, image_block=int(np.argmin(times)))
+            self.image = self.image if k == 0 else torch.empty_like(self.image)
+            blocks.append(self.image)
+            times.append(self._timed(lambda: self.flatfield(stack, flatfield, darkfield)))
+        self.image = blocks[int(np.argmin(times))]
+        self._trial_blocks = blocks
+        self.placement.update(flatfield_ms=[round(t, 3) for t in times])
 
     def _trial_roi_sets(self, out, want_roi, tries):
-        """The ROI pass of the call that has just run, repeated into ``tries`` output sets of their own; the fastest
-        is this processor's from now on (``pool_tag``), the others and the untagged set of the call are freed."""
+        """The ROI pass of the call that has just run, repeated from every image block into ``tries`` output sets of
+        their own (the pass reads one and writes the other: its level belongs to the pair); the pair with the smallest
+        flat-field + ROI time is this processor's from now on, everything else is freed."""
+        blocks, self._trial_blocks = self._trial_blocks, None
+        flat_ms = self.placement["flatfield_ms"]
         tabs = out.get("device_tables")
-        if tabs is None or tries < 2:
+        if tabs is None:
+            self.placement.update(image_block=int(np.argmin(flat_ms)))
+            del blocks
+            torch.cuda.empty_cache()
             return out
         T, C, h, w = self.T, self.C, self.h, self.w
         counts = [len(b) for b in out["beads"]]
         tags = ["#place%d" % k for k in range(tries)]
-        run = lambda tag: hp.roi_gather_reduce(self.image.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi,  # noqa: E731
-                                               reuse_buffers=True, disks=True, device_tables=(tabs[0], counts, self.max_r),
-                                               pool_tag=tag)
-        times = [round(self._timed(lambda: run(tag)), 3) for tag in tags]
-        keep = int(np.argmin(times))
-        hp.drop_pool_tags([""] + [t for k, t in enumerate(tags) if k != keep])
-        self.pool_tag = tags[keep]
-        self.placement.update(roi_ms=times, roi_set=keep)
-        res = run(self.pool_tag)  # the call's result, in the set that stays
+        run = lambda img, tag: hp.roi_gather_reduce(img.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi,  # noqa: E731
+                                                    reuse_buffers=True, disks=True, device_tables=(tabs[0], counts, self.max_r),
+                                                    pool_tag=tag)
+        roi_ms = [[self._timed(lambda: run(img, tag)) for tag in tags] for img in blocks]
+        total = np.asarray(roi_ms) + np.asarray(flat_ms)[:, None]
+        bi, bj = (int(v) for v in np.unravel_index(int(np.argmin(total)), total.shape))
+        hp.drop_pool_tags([""] + [t for k, t in enumerate(tags) if k != bj])
+        self.image, self.pool_tag = blocks[bi], tags[bj]
+        del blocks
+        torch.cuda.empty_cache()  # the blocks not kept go back to the driver NOW (~0.4 s for 50 GB), not at the next graph capture
+        self.placement.update(roi_ms=[[round(t, 3) for t in row] for row in roi_ms], image_block=bi, roi_set=bj)
+        res = run(self.image, self.pool_tag)  # the call's result, in the set that stays
         res["beads"] = out["beads"]
         return res
 

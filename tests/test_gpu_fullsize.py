@@ -434,7 +434,8 @@ def test_placement_trial_changes_nothing_but_the_blocks(mg, monkeypatch):
     assert plain.placement is None
     del plain
     tried, got = run("3,3")
-    assert len(tried.placement["flatfield_ms"]) == 3 and len(tried.placement["roi_ms"]) == 3
+    assert len(tried.placement["flatfield_ms"]) == 3 and np.asarray(tried.placement["roi_ms"]).shape == (3, 3)
+    assert tried._trial_blocks is None
     assert tried.pool_tag == "#place%d" % tried.placement["roi_set"]
     assert not [k for k in hp._POOL if k[0] in ("roi", "roi#place%d" % ((tried.placement["roi_set"] + 1) % 3))]
     for a, b in zip(want, got):
