@@ -11,7 +11,9 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 RAW=/tmp/mg_prof_$TAG
 rm -rf $RAW; mkdir -p $RAW $OUT
-export TMPDIR=/tmp MG_NO_GRAPH=1
+# MG_PLACEMENT_TRIES=0: the first call's placement trial launches the flat-field and ROI passes a few times more --
+# the per-step division of the counters below would count them as steps' traffic
+export TMPDIR=/tmp MG_NO_GRAPH=1 MG_PLACEMENT_TRIES=0
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.log
 cp $(find $RAW/stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
