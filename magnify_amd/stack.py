@@ -174,16 +174,18 @@ class StackProcessor:
             raise errors[0]
         return beads
 
-    def segment_reduce(self, beads, want_roi=True):
+    def segment_reduce(self, beads, want_roi=True, image=None, pool_tag=None):
         """fg/bg masks, ROI gather and masked sums for every marker (find.py:561-602)."""
         T, C, h, w = self.T, self.C, self.h, self.w
+        image = self.image if image is None else image
+        tag = self.pool_tag if pool_tag is None else pool_tag
         # masks straight from the bead tables (mg_roi_segment_reduce): no label map is written or read
         if self.mode == "P":
-            return hp.roi_gather_reduce(self.image.view(T, C, 1, h, w), beads, self.L, None, want_roi=want_roi,
-                                        reuse_buffers=True, disks=True, pool_tag=self.pool_tag)
+            return hp.roi_gather_reduce(image.view(T, C, 1, h, w), beads, self.L, None, want_roi=want_roi,
+                                        reuse_buffers=True, disks=True, pool_tag=tag)
         # mode R: one assay whose image block is stored (T, C, h, w); gathered in place (time_major)
-        return hp.roi_gather_reduce(self.image.view(1, T, C, h, w), beads, self.L, None, want_roi=want_roi,
-                                    reuse_buffers=True, disks=True, time_major=True, pool_tag=self.pool_tag)
+        return hp.roi_gather_reduce(image.view(1, T, C, h, w), beads, self.L, None, want_roi=want_roi,
+                                    reuse_buffers=True, disks=True, time_major=True, pool_tag=tag)
 
     def __call__(self, stack, flatfield=1.0, darkfield=0.0, seed=0, want_roi=True):
         if self.n_streams > 1 and self.mode == "P":
@@ -200,11 +202,11 @@ class StackProcessor:
             if self.mode == "P" and len(self.search_channels) == 1 and self.batch >= self.n_assays:
                 out = self._detect_reduce_on_device(seed, want_roi)
                 return self._trial_roi_sets(out, want_roi, tries[1]) if tries else out
-            if tries:  # (no device-side ROI route to try from: the block chosen by its flat-field time stays)
-                self._trial_blocks = None
-                torch.cuda.empty_cache()
-                self.placement.update(image_block=int(np.argmin(self.placement["flatfield_ms"])))
             beads = self.detect(seed)
+            if tries:
+                out = self._trial_pairs(lambda img, tag: self.segment_reduce(beads, want_roi, img, tag), tries[1])
+                out["beads"] = beads
+                return out
         out = self.segment_reduce(beads, want_roi=want_roi)
         out["beads"] = beads
         return out
@@ -214,7 +216,7 @@ class StackProcessor:
     # 4.2 / 4.6 ms at 64 x 4 x 4096^2), decided by where the image block and the ROI output set landed in physical
     # memory (not translation, not virtual offsets; between BLOCKS of one process the same two levels
     # show, tools/placement_probe.py).  A process cannot choose where a block lands -- but it can ask for several and keep
-    # the best: at the FIRST call of a large mode-P processor the flat-field passes are timed into a few image blocks and
+    # the best: at the FIRST call of a large processor (either mode) the flat-field passes are timed into a few image blocks and
     # the ROI pass from every one of them into a few output sets; the fastest PAIR stays, the rest is freed before the
     # second call.  Transient memory: tries x the block; time: images x sets ROI passes, once.  MG_PLACEMENT_TRIES="images,sets" (0: off).
     def _placement_tries(self):
@@ -226,10 +228,11 @@ class StackProcessor:
         except ValueError:
             return None
         block = self.image.numel() * self.image.element_size()
-        if (n_img < 2 and n_set < 2) or self.mode != "P" or self.pool_tag or self.n_streams > 1 or block < (1 << 31):
+        if (n_img < 2 and n_set < 2) or self.pool_tag or self.n_streams > 1 or block < (1 << 31):
             return None  # (small stacks are bound by latencies; the streaming path alternates two sets of its own)
         free, _ = torch.cuda.mem_get_info(self.dev)
-        roi_set = self.n_assays * 2500 * self.L * self.L * (2 * self.C + 2)  # ~ markers x (pixels + masks)
+        planes = self.C if self.mode == "P" else self.C * self.T
+        roi_set = self.n_assays * 2500 * self.L * self.L * (2 * planes + 2)  # ~ markers x (pixels + masks)
         if free < (max(n_img, 1) + 1) * block + (max(n_set, 1) + 1) * roi_set:
             return None
         self.placement = {}
@@ -259,23 +262,30 @@ class StackProcessor:
         self.placement.update(flatfield_ms=[round(t, 3) for t in times])
 
     def _trial_roi_sets(self, out, want_roi, tries):
-        """The ROI pass of the call that has just run, repeated from every image block into ``tries`` output sets of
-        their own (the pass reads one and writes the other: its level belongs to the pair); the pair with the smallest
-        flat-field + ROI time is this processor's from now on, everything else is freed."""
-        blocks, self._trial_blocks = self._trial_blocks, None
-        flat_ms = self.placement["flatfield_ms"]
+        """_trial_pairs for the device-side route: the ROI pass of the call that has just run, from the bead tables where
+        the suppression left them."""
         tabs = out.get("device_tables")
         if tabs is None:
-            self.placement.update(image_block=int(np.argmin(flat_ms)))
-            del blocks
+            self._trial_blocks = None
             torch.cuda.empty_cache()
+            self.placement.update(image_block=int(np.argmin(self.placement["flatfield_ms"])))
             return out
         T, C, h, w = self.T, self.C, self.h, self.w
         counts = [len(b) for b in out["beads"]]
+        res = self._trial_pairs(lambda img, tag: hp.roi_gather_reduce(
+            img.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi, reuse_buffers=True, disks=True,
+            device_tables=(tabs[0], counts, self.max_r), pool_tag=tag), tries)
+        res["beads"] = out["beads"]
+        return res
+
+    def _trial_pairs(self, run, tries):
+        """``run(image block, pool tag)`` = the ROI pass: timed from every image block of the trial into ``tries`` output
+        sets of their own (the pass reads one and writes the other: its level belongs to the pair); the pair with the
+        smallest flat-field + ROI time is this processor's from now on, everything else goes back to the driver.
+        Returns the pass's result in the set that stays."""
+        blocks, self._trial_blocks = self._trial_blocks, None
+        flat_ms = self.placement["flatfield_ms"]
         tags = ["#place%d" % k for k in range(tries)]
-        run = lambda img, tag: hp.roi_gather_reduce(img.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi,  # noqa: E731
-                                                    reuse_buffers=True, disks=True, device_tables=(tabs[0], counts, self.max_r),
-                                                    pool_tag=tag)
         roi_ms = [[self._timed(lambda: run(img, tag)) for tag in tags] for img in blocks]
         total = np.asarray(roi_ms) + np.asarray(flat_ms)[:, None]
         bi, bj = (int(v) for v in np.unravel_index(int(np.argmin(total)), total.shape))
@@ -284,9 +294,7 @@ class StackProcessor:
         del blocks
         torch.cuda.empty_cache()  # the blocks not kept go back to the driver NOW (~0.4 s for 50 GB), not at the next graph capture
         self.placement.update(roi_ms=[[round(t, 3) for t in row] for row in roi_ms], image_block=bi, roi_set=bj)
-        res = run(self.image, self.pool_tag)  # the call's result, in the set that stays
-        res["beads"] = out["beads"]
-        return res
+        return run(self.image, self.pool_tag)
 
     def _detect_reduce_on_device(self, seed, want_roi):
         """One search channel, the whole stack in one batch: there is no cross-channel de-duplication

@@ -407,7 +407,8 @@ def test_save_and_spill_a_gpu_resident_result(mg, tmp_path):
 
 
 @pytest.mark.gpu
-def test_placement_trial_changes_nothing_but_the_blocks(mg, monkeypatch):
+@pytest.mark.parametrize("mode", ["P", "R"])
+def test_placement_trial_changes_nothing_but_the_blocks(mg, monkeypatch, mode):
     """The first call of a large mode-P processor times its passes into several image blocks / ROI output sets and keeps
     the fastest (StackProcessor._placement_tries): the results of that call and of the next are those of a processor
     that never tried (MG_PLACEMENT_TRIES=0), and the blocks not kept are gone."""
@@ -418,7 +419,7 @@ def test_placement_trial_changes_nothing_but_the_blocks(mg, monkeypatch):
 
     T, C, S = 17, 4, 4096  # 2.3 GB of image: above the trial's threshold
     stack, _ = synthetic_stack(T, C, S, S, seed=77)
-    kw = dict(num_iter=200_000, search_channels=(0,), mode="P")
+    kw = dict(num_iter=200_000, search_channels=(0,), mode=mode)  # (R: the host-table route of the ROI pass, one assay)
 
     def run(tries):
         monkeypatch.setenv("MG_PLACEMENT_TRIES", tries)

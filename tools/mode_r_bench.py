@@ -47,5 +47,5 @@ L = proc.L
 roi_bytes = m * T * L * L * (4 * C + 2)
 print(json.dumps({"mode": "R", "shape": [T, C, S, S], "ms_per_step": dt * 1e3, "MPs": T * C * S * S / dt / 1e6,
                   "markers_at_t0": m, "roi_windows": m * T, "roi_windows_per_s": m * T / dt,
-                  "roi_algorithmic_GB": roi_bytes / 1e9,
+                  "roi_algorithmic_GB": roi_bytes / 1e9, "placement": proc.placement,
                   "stages_ms": {k: round(v[0] / args.steps, 3) for k, v in sorted(timer.summary().items(), key=lambda kv: -kv[1][0])}}))
