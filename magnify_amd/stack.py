@@ -224,7 +224,7 @@ class StackProcessor:
             return None
         self._placed = True
         try:
-            n_img, n_set = (int(v) for v in os.environ.get("MG_PLACEMENT_TRIES", "4,3").split(","))
+            n_img, n_set = (int(v) for v in os.environ.get("MG_PLACEMENT_TRIES", "6,3").split(","))
         except ValueError:
             return None
         block = self.image.numel() * self.image.element_size()
