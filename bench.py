@@ -390,7 +390,10 @@ def main():
         n_all, n_s = T * C * S * S, search_planes * S * S
         # SURVEY.md 8d's count minus the label map this build no longer writes (4 B/px of the searched
         # planes) or reads (4 B per window pixel): masks come straight from the bead tables
-        stream_bytes = 6 * n_all + 8 * n_s + markers_local * proc.L**2 * (4 * C + 2)
+        # ... and minus the histogram pass's read of the blurred image (1 B/px) where the one-pass blur + histogram
+        # kernel ran (mg_to_uint8_blur_hist takes the magnitudes from registers): bytes saved are not bytes moved
+        one_pass_hist = "mg_to_uint8_blur_hist" in stages and "mg_scharr_hist" not in stages
+        stream_bytes = 6 * n_all + (7 if one_pass_hist else 8) * n_s + markers_local * proc.L**2 * (4 * C + 2)
         breakdown, roofline, streaming, total_ms = stage_report(stages, args.steps, p, pmc, stream_bytes)
         # the same stages against SURVEY 8d's own count, which includes the label map (4 B written per searched pixel,
         # 4 B read per window pixel) that this build never materialises: bytes saved, not bytes moved
