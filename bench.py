@@ -220,8 +220,8 @@ def per_assay_fg_sums(out, n_assays):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--timepoints", type=int, default=64, help="timepoints per GPU")
     ap.add_argument("--channels", type=int, default=4)
     ap.add_argument("--size", type=int, default=4096)

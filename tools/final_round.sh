@@ -6,7 +6,7 @@
 set -e
 TAG=${1:-r4}
 OUT=gpurun_out
-# (the driver's command of rounds 1-3; `python bench.py` alone runs 5 steps after 4 warm-up calls)
+# (the driver's command of rounds 1-3; `python bench.py` alone runs 10 steps after 6 warm-up calls)
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_final_bench.json 2> $OUT/${TAG}_final_bench.err || { tail -20 $OUT/${TAG}_final_bench.err; exit 1; }
 echo default done
 python bench.py --timepoints 8 --steps 40 --warmup 3 --no-cpu --no-isolated > $OUT/${TAG}_bench_8tp.json 2> $OUT/${TAG}_bench_8tp.err
