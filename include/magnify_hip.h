@@ -360,12 +360,13 @@ int mg_score_circles_keyed(const uint8_t* d_blur, const float* d_angle, const ui
  * Ring = 4-connected perimeter of radius min_dist (d_ring_rc, ring_len); indices wrap
  * modulo the claim grid extent like negative numba indices do. */
 /* max_alive (all suppression calls): an upper bound of d_num_alive known to the caller, used only to size the
- * launch grid (0 = unknown: a grid for circle_cap). */
+ * launch grid (0 = unknown: a grid for circle_cap).  d_skip (all three; may be NULL): int32[n_planes], planes with a
+ * non-zero entry are left alone -- they were decided by mg_nms_sparse. */
 int mg_nms_rounds(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
                   const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist,
                   const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
                   int32_t* d_undecided, int64_t undecided_stride, int n_rounds, int counters_clear,
-                  const uint32_t* d_tie_keys, int64_t max_alive, void* stream);
+                  const uint32_t* d_tie_keys, int64_t max_alive, const int32_t* d_skip, void* stream);
 
 /* Before the rounds (optional, exact): of the alive circles that share a centre only the first in suppression
  * order (score desc, tie key asc) stays undecided, the others are marked rejected -- they have the same ring and
@@ -373,14 +374,31 @@ int mg_nms_rounds(const int32_t* d_circles, int64_t circle_cap, const float* d_s
  * which is restored before returning; d_state as for mg_nms_rounds. */
 int mg_nms_same_centre(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
                        const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist, uint64_t* d_grid,
-                       int64_t grid_cap, uint8_t* d_state, const uint32_t* d_tie_keys, int64_t max_alive, void* stream);
+                       int64_t grid_cap, uint8_t* d_state, const uint32_t* d_tie_keys, int64_t max_alive,
+                       const int32_t* d_skip, void* stream);
 
 /* After the rounds have converged: restore the all-ones claim grid under the rings of all alive
  * circles, so that the grid needs its full initialisation only once. */
 int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
                    const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist,
                    const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
-                   int64_t max_alive, void* stream);
+                   int64_t max_alive, const int32_t* d_skip, void* stream);
+
+/* The same greedy suppression (utils.py:254-292) decided from the circles alone, one workgroup per plane: circle i is
+ * kept iff no circle j kept before it has a ring cell in common with it, i.e. iff c_i - c_j is in D = ring (-) ring for
+ * no such j.  d_dbits: the bitmap of D, bit (dr + 2 d)(4 d + 1) + dc + 2 d set iff two rings of radius d = min_dist
+ * whose centres differ by (dr, dc) share a cell (the caller builds it from the ring of mg_circle_points).  A plane's
+ * alive circles are bucketed in LDS, a circle looks at the buckets around it; d_state gets 1 (kept) / 2 (dropped) for
+ * every alive circle of a plane it decides and d_done[plane] = 1.  d_done[plane] = 0 -- the plane is left to
+ * mg_nms_same_centre / mg_nms_rounds, untouched -- when it holds more than 12 288 alive circles, spans more than 4 608
+ * buckets of 64 x 64, or a centre lies at row or col < -(min_dist + 1) (the reference's claim index would be negative
+ * and wrap); every plane when min_dist > mg_nms_sparse_max_dist().  d_skip of the three calls above = this d_done:
+ * they leave the planes alone that are decided (the cleanup only zeroes their circles' state bytes).  Needs no claim
+ * grid and does not look at d_state before writing it. */
+int mg_nms_sparse(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
+                  const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist, const uint32_t* d_dbits,
+                  uint8_t* d_state, const uint32_t* d_tie_keys, int32_t* d_done, void* stream);
+int mg_nms_sparse_max_dist(void);
 
 /* Gather the kept circles in priority order (utils.py:195-199 output order):
  * d_out[n_planes][out_cap][3] int32 (row, col, r), d_out_scores, d_num_out[n_planes].

@@ -63,11 +63,13 @@ PROTOTYPES = {
     "mg_score_pairs": [_i, _p, _i],
     "mg_score_circles_keyed": [_p, _p, _p, _p, _l, _i, _i, _i, _p, _l, _p, _p, _i, _i, _p, _p, _p, _i, _p, _f, _i,
                                _p, _p, _p, _p, _p, _p, _l, _p, _i, _p],
-    "mg_nms_rounds": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _l, _i, _i, _p, _l, _p],
-    "mg_nms_same_centre": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _l, _p, _p, _l, _p],
+    "mg_nms_rounds": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _l, _i, _i, _p, _l, _p, _p],
+    "mg_nms_same_centre": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _l, _p, _p, _l, _p, _p],
+    "mg_nms_sparse": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p],
+    "mg_nms_sparse_max_dist": [],
     "mg_collect_circles": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _i, _p],
     "mg_circle_labels": [_p, _l, _p, _i, _i, _i, _p, _i, _p, _i, _p],
-    "mg_nms_cleanup": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _l, _p],
+    "mg_nms_cleanup": [_p, _l, _p, _p, _p, _p, _i, _i, _p, _i, _p, _l, _p, _l, _p, _p],
     "mg_roi_gather_reduce": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mg_roi_gather_reduce_batched": [_p, _i, _l, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mg_counts_to_offsets": [_p, _i, _i, _p, _p],

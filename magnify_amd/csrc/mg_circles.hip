@@ -863,10 +863,19 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
                                             const int32_t* __restrict__ d_ring_rc, int ring_len,
                                             uint64_t* __restrict__ d_grid, int64_t grid_cap,
                                             uint8_t* __restrict__ d_state, int32_t* __restrict__ d_undecided,
-                                            const uint32_t* __restrict__ d_tie, int cpw) {
+                                            const uint32_t* __restrict__ d_tie, int cpw,
+                                            const int32_t* __restrict__ d_skip) {
   const int plane = blockIdx.y;
   const int n = d_num_alive[plane];
   if (n == 0) return;
+  if (d_skip && d_skip[plane]) {
+    // the plane was decided by mg_nms_sparse: no bids, nothing on the claim grid.  The cleanup only returns the
+    // state bytes of the alive circles to 0 (what it does for every circle whose ring it restores)
+    if (PHASE == 2)
+      for (int64_t a = (int64_t)blockIdx.x * NT + threadIdx.x; a < n; a += (int64_t)gridDim.x * NT)
+        d_state[(int64_t)plane * circle_cap + d_alive[(int64_t)plane * circle_cap + a]] = 0;
+    return;
+  }
   const uint32_t* tie = d_tie ? d_tie + (int64_t)plane * circle_cap : nullptr;
   const int pad = 2 * min_dist + 1;
   const int n_rows = d_max_rc[2 * plane] + 2 * pad, n_cols = d_max_rc[2 * plane + 1] + 2 * pad;
@@ -1006,6 +1015,168 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
     }
   }
   if (PHASE == 1 && any_undecided && lane == 0 && d_undecided[plane] == 0) d_undecided[plane] = 1;
+}
+
+// ---- K10s: the same greedy suppression, decided per plane in ONE workgroup from the circles alone ----------------
+// utils.py:254-292 keeps circle i iff no ring cell of i is claimed by a circle kept before it: iff no kept circle j
+// earlier in the order has ring(c_j) and ring(c_i) in common: iff c_i - c_j lies in D = ring (-) ring for no kept
+// earlier j.  So the grid is not needed -- only, for every alive circle, the alive circles around it.  The rounds above
+// reach that through 64 claim-grid cells per circle and round (memory-side atomics and scattered 8-byte loads over a
+// 137 MB grid per plane: 0.9 ms per step at C4 with its same-centre pass and the cleanup); here a plane's ~11 000
+// alive circles are sorted into 64 x 64 buckets in LDS, a circle looks at the 3 x 3 buckets around it, tests
+// c_i - c_j against the bitmap of D and compares keys: kept when every conflicting circle before it is rejected,
+// rejected when one of them is kept, undecided (another round of the in-kernel loop) otherwise -- the sequential
+// greedy choice, whatever the order the threads run in.  A plane the kernel cannot take (more than SP_CAP circles, more
+// buckets than SP_MAXB, a centre so far outside the image that the reference's negative index would WRAP, utils.py:271:
+// row or col < -(min_dist + 1)) is left to the rounds: d_done[plane] = 0.
+constexpr int SP_NT = 1024;
+constexpr int SP_CAP = 12288;           // alive circles of a plane held in LDS (SP_PER per thread)
+constexpr int SP_PER = SP_CAP / SP_NT;
+constexpr int SP_SHIFT = 6;             // log2 of the bucket edge
+constexpr int SP_BIAS = 64;             // added to coordinates: >= min_dist + 1, so stored coordinates are >= 0
+constexpr int SP_MAXB = 4608;           // buckets per plane
+constexpr int SP_MAXD = 15;             // min_dist up to this (the bitmap of D has (4 d + 1)^2 bits)
+constexpr int SP_DWORDS = ((4 * SP_MAXD + 1) * (4 * SP_MAXD + 1) + 31) / 32;
+constexpr size_t SP_LDS = (size_t)SP_CAP * (4 + 4 + 2 + 1) + (size_t)(SP_MAXB + 1) * 4 + SP_DWORDS * 4;
+
+__global__ __launch_bounds__(SP_NT) void k_nms_sparse(const int32_t* __restrict__ d_circles, int64_t circle_cap,
+                                                      const float* __restrict__ d_scores,
+                                                      const int32_t* __restrict__ d_alive,
+                                                      const int32_t* __restrict__ d_num_alive,
+                                                      const int32_t* __restrict__ d_max_rc, int min_dist,
+                                                      const uint32_t* __restrict__ d_dbits, uint8_t* __restrict__ d_state,
+                                                      const uint32_t* __restrict__ d_tie, int32_t* __restrict__ d_done) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t sp_lds[];
+  uint32_t* pos = reinterpret_cast<uint32_t*>(sp_lds);          // (row + bias) << 16 | (col + bias)
+  uint32_t* skey = pos + SP_CAP;                                // the score half of nms_key: smaller = earlier
+  int32_t* bstart = reinterpret_cast<int32_t*>(skey + SP_CAP);  // [nb + 1]
+  uint32_t* dbits = reinterpret_cast<uint32_t*>(bstart + SP_MAXB + 1);
+  uint16_t* sorted = reinterpret_cast<uint16_t*>(dbits + SP_DWORDS);
+  uint8_t* st = reinterpret_cast<uint8_t*>(sorted + SP_CAP);
+  __shared__ int s_bad;
+  const int plane = blockIdx.x;
+  const int n = d_num_alive[plane];
+  if (threadIdx.x == 0) s_bad = 0;
+  const int nbr = ((d_max_rc[2 * plane] + SP_BIAS) >> SP_SHIFT) + 1, nbc = ((d_max_rc[2 * plane + 1] + SP_BIAS) >> SP_SHIFT) + 1;
+  const int nb = nbr * nbc;
+  if (n <= 0 || n > SP_CAP || nb > SP_MAXB || nbr <= 0 || nbc <= 0) {  // block-uniform
+    if (threadIdx.x == 0) d_done[plane] = (n <= 0);  // (no alive circle: nothing for the rounds either)
+    return;
+  }
+  const int32_t* circles = d_circles + (int64_t)plane * circle_cap * 3;
+  const float* scores = d_scores + (int64_t)plane * circle_cap;
+  const int32_t* alive = d_alive + (int64_t)plane * circle_cap;
+  const uint32_t* tie = d_tie ? d_tie + (int64_t)plane * circle_cap : nullptr;
+  const int side = 4 * min_dist + 1, reach = 2 * min_dist;
+  for (int i = threadIdx.x; i < (side * side + 31) / 32; i += SP_NT) dbits[i] = d_dbits[i];
+  for (int i = threadIdx.x; i <= nb; i += SP_NT) bstart[i] = 0;
+  __syncthreads();
+  // ---- the circles, their buckets, their slots inside the buckets ----
+  int slot[SP_PER], bkt[SP_PER];
+  bool bad = false;
+#pragma unroll
+  for (int u = 0; u < SP_PER; ++u) {
+    const int a = threadIdx.x + u * SP_NT;
+    slot[u] = 0, bkt[u] = -1;
+    if (a < n) {
+      const int idx = alive[a];
+      const int row = circles[3 * (int64_t)idx], col = circles[3 * (int64_t)idx + 1];
+      if (row < -(min_dist + 1) || col < -(min_dist + 1) || row > d_max_rc[2 * plane] || col > d_max_rc[2 * plane + 1]) {
+        bad = true;
+      } else {
+        uint32_t b = __float_as_uint(scores[idx]);
+        b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+        pos[a] = ((uint32_t)(row + SP_BIAS) << 16) | (uint32_t)(col + SP_BIAS);
+        skey[a] = ~b;
+        st[a] = 0;
+        bkt[u] = ((row + SP_BIAS) >> SP_SHIFT) * nbc + ((col + SP_BIAS) >> SP_SHIFT);
+        slot[u] = atomicAdd(&bstart[bkt[u] + 1], 1);
+      }
+    }
+  }
+  if (bad) s_bad = 1;
+  __syncthreads();
+  if (s_bad) {  // block-uniform
+    if (threadIdx.x == 0) d_done[plane] = 0;
+    return;
+  }
+  // ---- bucket starts: every thread sums a run of buckets, one block-wide scan, the run's prefixes ----
+  {
+    const int per = (nb + SP_NT - 1) / SP_NT;
+    const int lo = min((int)threadIdx.x * per, nb), hi = min(lo + per, nb);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += bstart[i + 1];
+    int total;
+    int run = mg_block_exscan(sum, &total);
+    __syncthreads();
+    for (int i = lo; i < hi; ++i) {
+      const int c = bstart[i + 1];
+      bstart[i + 1] = run;  // (entry i + 1 holds bucket i's START until the shift below)
+      run += c;
+    }
+    __syncthreads();
+    // shift: bstart[i] = start of bucket i, bstart[nb] = n
+    int mine[8];
+    for (int k = 0, i = lo; i < hi && k < 8; ++i, ++k) mine[k] = bstart[i + 1];
+    __syncthreads();
+    for (int k = 0, i = lo; i < hi && k < 8; ++i, ++k) bstart[i] = mine[k];
+    if (threadIdx.x == 0) bstart[nb] = n;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < SP_PER; ++u)
+    if (bkt[u] >= 0) sorted[bstart[bkt[u]] + slot[u]] = (uint16_t)(threadIdx.x + u * SP_NT);
+  __syncthreads();
+  // ---- rounds ----
+  int again;
+  do {
+    int changed = 0;
+#pragma unroll 1
+    for (int a = threadIdx.x; a < n; a += SP_NT) {
+      if (st[a] != 0) continue;
+      const uint32_t pa = pos[a], ka = skey[a];
+      const int ra = (int)(pa >> 16), ca = (int)(pa & 0xFFFFu);
+      const int br = ra >> SP_SHIFT, bc = ca >> SP_SHIFT;
+      uint32_t ta = 0;
+      bool have_ta = false, rejected = false, blocked = false;
+      for (int dbr = -1; dbr <= 1 && !rejected; ++dbr) {
+        const int r2 = br + dbr;
+        if (r2 < 0 || r2 >= nbr) continue;
+        const int c_lo = max(bc - 1, 0), c_hi = min(bc + 1, nbc - 1);
+        const int k0 = bstart[r2 * nbc + c_lo], k1 = bstart[r2 * nbc + c_hi + 1];  // three buckets of a row are one run
+        for (int k = k0; k < k1; ++k) {
+          const int j = sorted[k];
+          if (j == a) continue;
+          const uint32_t pj = pos[j];
+          const int dr = ra - (int)(pj >> 16), dc = ca - (int)(pj & 0xFFFFu);
+          if (abs(dr) > reach || abs(dc) > reach) continue;
+          const int bit = (dr + reach) * side + dc + reach;
+          if (!((dbits[bit >> 5] >> (bit & 31)) & 1u)) continue;
+          // j's ring meets a's: is j before a?
+          const uint32_t kj = skey[j];
+          bool before = kj < ka;
+          if (kj == ka) {
+            if (!have_ta) ta = tie ? tie[alive[a]] : (uint32_t)alive[a], have_ta = true;
+            const uint32_t tj = tie ? tie[alive[j]] : (uint32_t)alive[j];
+            before = tj < ta;
+          }
+          if (!before) continue;
+          const uint8_t sj = st[j];
+          if (sj == 1) {
+            rejected = true;
+            break;
+          }
+          if (sj == 0) blocked = true;
+        }
+      }
+      if (rejected) st[a] = 2, changed = 1;
+      else if (!blocked) st[a] = 1, changed = 1;
+    }
+    again = __syncthreads_or(changed);
+  } while (again);
+  uint8_t* state = d_state + (int64_t)plane * circle_cap;
+  for (int a = threadIdx.x; a < n; a += SP_NT) state[alive[a]] = st[a];
+  if (threadIdx.x == 0) d_done[plane] = 1;
 }
 
 // ---- K11: collect kept circles in priority order -------------------------------------------------------
@@ -1292,7 +1463,8 @@ extern "C" int mg_nms_rounds(const int32_t* d_circles, int64_t circle_cap, const
                              const int32_t* d_alive, const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes,
                              int min_dist, const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap,
                              uint8_t* d_state, int32_t* d_undecided, int64_t undecided_stride, int n_rounds,
-                             int counters_clear, const uint32_t* d_tie_keys, int64_t max_alive, void* stream) {
+                             int counters_clear, const uint32_t* d_tie_keys, int64_t max_alive, const int32_t* d_skip,
+                             void* stream) {
   if (!d_circles || !d_scores || !d_alive || !d_num_alive || !d_max_rc || !d_ring_rc || !d_grid || !d_state ||
       !d_undecided)
     return MG_EINVAL;
@@ -1309,10 +1481,10 @@ extern "C" int mg_nms_rounds(const int32_t* d_circles, int64_t circle_cap, const
     int32_t* und = d_undecided + (int64_t)k * undecided_stride;
     if (!counters_clear && mg_zero_async(und, sizeof(int32_t) * n_planes, s) != hipSuccess) return MG_ELAUNCH;
     hipLaunchKernelGGL((k_nms<0>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                       min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, und, d_tie_keys, cpw);
+                       min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, und, d_tie_keys, cpw, d_skip);
     MG_CHECK_LAUNCH();
     hipLaunchKernelGGL((k_nms<1>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                       min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, und, d_tie_keys, cpw);
+                       min_dist, d_ring_rc, ring_len, d_grid, grid_cap, d_state, und, d_tie_keys, cpw, d_skip);
     MG_CHECK_LAUNCH();
   }
   return MG_OK;
@@ -1321,20 +1493,20 @@ extern "C" int mg_nms_rounds(const int32_t* d_circles, int64_t circle_cap, const
 extern "C" int mg_nms_same_centre(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
                                   const int32_t* d_alive, const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes,
                                   int min_dist, uint64_t* d_grid, int64_t grid_cap, uint8_t* d_state,
-                                  const uint32_t* d_tie_keys, int64_t max_alive, void* stream) {
+                                  const uint32_t* d_tie_keys, int64_t max_alive, const int32_t* d_skip, void* stream) {
   if (!d_circles || !d_scores || !d_alive || !d_num_alive || !d_max_rc || !d_grid || !d_state) return MG_EINVAL;
   if (n_planes < 0 || n_planes > 65535 || min_dist <= 0) return MG_EINVAL;
   if (n_planes == 0 || circle_cap == 0) return MG_OK;
   hipStream_t s = mg_stream(stream);
   const dim3 g(grid_x(max_alive > 0 ? std::min(max_alive, circle_cap) : circle_cap), n_planes);
   hipLaunchKernelGGL((k_nms<3>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys, 64);
+                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys, 64, d_skip);
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_nms<4>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys, 64);
+                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys, 64, d_skip);
   MG_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_nms<5>), g, dim3(NT), 0, s, d_circles, circle_cap, d_scores, d_alive, d_num_alive, d_max_rc,
-                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys, 64);
+                     min_dist, (const int32_t*)nullptr, 0, d_grid, grid_cap, d_state, (int32_t*)nullptr, d_tie_keys, 64, d_skip);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -1342,7 +1514,7 @@ extern "C" int mg_nms_same_centre(const int32_t* d_circles, int64_t circle_cap, 
 extern "C" int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
                               const int32_t* d_alive, const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes,
                               int min_dist, const int32_t* d_ring_rc, int ring_len, uint64_t* d_grid, int64_t grid_cap,
-                              uint8_t* d_state, int64_t max_alive, void* stream) {
+                              uint8_t* d_state, int64_t max_alive, const int32_t* d_skip, void* stream) {
   if (!d_circles || !d_scores || !d_alive || !d_num_alive || !d_max_rc || !d_ring_rc || !d_grid || !d_state)
     return MG_EINVAL;
   if (n_planes < 0 || n_planes > 65535 || min_dist <= 0 || ring_len <= 0) return MG_EINVAL;
@@ -1352,10 +1524,38 @@ extern "C" int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, cons
   hipLaunchKernelGGL((k_nms<2>), dim3(grid_x(bound * (64 / cpw)), n_planes),
                      dim3(NT), 0, mg_stream(stream), d_circles,
                      circle_cap, d_scores, d_alive, d_num_alive, d_max_rc, min_dist, d_ring_rc, ring_len, d_grid,
-                     grid_cap, d_state, (int32_t*)nullptr, (const uint32_t*)nullptr, cpw);
+                     grid_cap, d_state, (int32_t*)nullptr, (const uint32_t*)nullptr, cpw, d_skip);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
+
+extern "C" int mg_nms_sparse(const int32_t* d_circles, int64_t circle_cap, const float* d_scores, const int32_t* d_alive,
+                             const int32_t* d_num_alive, const int32_t* d_max_rc, int n_planes, int min_dist,
+                             const uint32_t* d_dbits, uint8_t* d_state, const uint32_t* d_tie_keys, int32_t* d_done,
+                             void* stream) {
+  if (!d_circles || !d_scores || !d_alive || !d_num_alive || !d_max_rc || !d_dbits || !d_state || !d_done) return MG_EINVAL;
+  if (n_planes < 0 || n_planes > 65535 || min_dist <= 0) return MG_EINVAL;
+  if (n_planes == 0) return MG_OK;
+  hipStream_t s = mg_stream(stream);
+  if (min_dist > SP_MAXD || circle_cap == 0) {  // nothing decided here: the rounds take every plane
+    if (mg_zero_async(d_done, sizeof(int32_t) * n_planes, s) != hipSuccess) return MG_ELAUNCH;
+    return MG_OK;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_nms_sparse), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)SP_LDS) != hipSuccess)
+      return MG_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_nms_sparse, dim3(n_planes), dim3(SP_NT), SP_LDS, s, d_circles, circle_cap, d_scores, d_alive,
+                     d_num_alive, d_max_rc, min_dist, d_dbits, d_state, d_tie_keys, d_done);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+/* Words of the bitmap of D = ring (-) ring that mg_nms_sparse reads: bit (dr + 2 d) (4 d + 1) + dc + 2 d. */
+extern "C" int mg_nms_sparse_max_dist(void) { return SP_MAXD; }
 
 extern "C" int mg_collect_circles(const int32_t* d_circles, int64_t circle_cap, const float* d_scores,
                                   const int32_t* d_alive, const int32_t* d_num_alive, const uint8_t* d_state,

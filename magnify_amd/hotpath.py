@@ -715,7 +715,11 @@ class CircleFinder:
             self.state.zero_()
             self._drop_graphs()
         if getattr(self, "_nms_dist", None) != min_dist:
-            self._nms_ring = torch.from_numpy(nat.circle_points(min_dist, True)).to(self.dev)
+            ring = nat.circle_points(min_dist, True)
+            self._nms_ring = torch.from_numpy(ring).to(self.dev)
+            self._nms_dbits = torch.from_numpy(_ring_difference_bits(ring, min_dist)).to(self.dev)
+            if getattr(self, "nms_done", None) is None:
+                self.nms_done = torch.zeros((self.P,), dtype=torch.int32, device=self.dev)
             self._nms_dist = min_dist
             self._drop_graphs()
 
@@ -724,22 +728,27 @@ class CircleFinder:
         the status block they are rows of has just been cleared).  ``first``: the same-centre pass (only the first
         circle of a centre enters the rounds: exact, three tiny launches)."""
         P, s, ring = self.P, _stream(), self._nms_ring
+        skip = self.nms_done.data_ptr() if _NMS_SPARSE else 0
         if first:
+            if _NMS_SPARSE:  # whole planes decided from the circles alone; the calls below leave those planes alone
+                _call("mg_nms_sparse", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
+                      self.num_alive.data_ptr(), self.max_rc.data_ptr(), P, min_dist, self._nms_dbits.data_ptr(),
+                      self.state.data_ptr(), _ptr(self._tie_keys), self.nms_done.data_ptr(), s, stage="mg_nms_rounds")
             _call("mg_nms_same_centre", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
                   self.num_alive.data_ptr(), self.max_rc.data_ptr(), P, min_dist, self.nms_grid.data_ptr(),
-                  self.nms_grid.shape[1], self.state.data_ptr(), _ptr(self._tie_keys), out_cap, s, stage="mg_nms_rounds")
+                  self.nms_grid.shape[1], self.state.data_ptr(), _ptr(self._tie_keys), out_cap, skip, s, stage="mg_nms_rounds")
         if count > 0:
             _call("mg_nms_rounds", self.circles.data_ptr(), self.cap, self.scores.data_ptr(),
                   self.alive.data_ptr(), self.num_alive.data_ptr(), self.max_rc.data_ptr(), P,
                   min_dist, ring.data_ptr(), ring.shape[0], self.nms_grid.data_ptr(),
                   self.nms_grid.shape[1], self.state.data_ptr(), self.undecided.data_ptr(), self.undecided.stride(0),
-                  int(count), int(cleared), _ptr(self._tie_keys), out_cap, s, stage="mg_nms_rounds")
+                  int(count), int(cleared), _ptr(self._tie_keys), out_cap, skip, s, stage="mg_nms_rounds")
 
     def _nms_cleanup(self, min_dist, out_cap):
         _call("mg_nms_cleanup", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
               self.num_alive.data_ptr(), self.max_rc.data_ptr(), self.P, min_dist, self._nms_ring.data_ptr(),
               self._nms_ring.shape[0], self.nms_grid.data_ptr(), self.nms_grid.shape[1], self.state.data_ptr(),
-              out_cap, _stream())
+              out_cap, self.nms_done.data_ptr() if _NMS_SPARSE else 0, _stream())
 
     def nms_stage(self, min_dist: int, optimistic=False, bufs=None, cleared=False):
         """Checked chain: the alive counts come to the host first (they size the output), the rounds are checked for
@@ -1131,6 +1140,21 @@ def _upload_i32(values, device):
     host = ring[0][ring[1]]
     host.numpy()[:] = values
     return host.to(device, non_blocking=True)
+
+
+_NMS_SPARSE = os.environ.get("MG_NMS_SPARSE", "1") != "0"
+
+
+def _ring_difference_bits(ring, d):
+    """Bitmap of D = ring (-) ring for mg_nms_sparse: bit (dr + 2 d)(4 d + 1) + dc + 2 d is set iff two rings of radius d
+    whose centres differ by (dr, dc) have a cell in common (utils.py:266-289 marks and tests exactly those cells)."""
+    ring = np.asarray(ring, dtype=np.int64)
+    side = 4 * d + 1
+    diff = (ring[:, None, :] - ring[None, :, :]).reshape(-1, 2) + 2 * d
+    flat = np.unique(diff[:, 0] * side + diff[:, 1])
+    bits = np.zeros(((side * side + 31) // 32,), dtype=np.uint32)
+    np.bitwise_or.at(bits, flat >> 5, np.uint32(1) << (flat & 31).astype(np.uint32))
+    return bits.view(np.int32)
 
 
 _ROI_ORDER = os.environ.get("MG_ROI_ORDER", "1") != "0"

@@ -536,6 +536,56 @@ def test_nms_golden_and_wrap(hp, golden):
         np.testing.assert_array_equal(out[0, :m].cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("min_dist", [3, 8, 15, 16])
+def test_nms_decided_from_the_circles_alone(hp, monkeypatch, min_dist):
+    """mg_nms_sparse (a plane's alive circles bucketed in LDS, ring conflicts from the bitmap of ring (-) ring) against the
+    oracle's filter_neighbors and against the claim-grid rounds: crowded planes with equal scores and shared centres, a
+    plane with a centre far outside the image (negative claim index: left to the rounds), an empty plane, a radius
+    beyond the kernel's bitmap (16: every plane left to the rounds)."""
+    rng = np.random.default_rng(100 + min_dist)
+    h, w, P = 700, 900, 4
+    sets = []
+    for plane in range(P):
+        n = [3000, 1200, 0, 2000][plane]
+        cl = rng.integers(0, 40, size=(60, 2)) * np.array([17, 22]) + 10  # clusters: many circles within reach of each other
+        c = cl[rng.integers(0, 60, n)] + rng.integers(-2 * min_dist, 2 * min_dist + 1, size=(n, 2))
+        c = np.column_stack([np.clip(c[:, 0], -min_dist - 1, h), np.clip(c[:, 1], -min_dist - 1, w), rng.integers(5, 20, n)])
+        if plane == 1 and n:
+            c[7, 0] = -min_dist - 2  # the reference's claim index goes negative: wraps
+            c[8] = [h + 20, 33, 9]
+        sc = np.round(rng.uniform(0.3, 1.0, n), 2).astype(np.float32)  # two decimals: many equal scores
+        if n > 50:
+            c[20:40, :2] = c[20, :2]  # one centre, twenty circles
+        sets.append((c.astype(np.int32), sc))
+    cap = 3200
+
+    def run(sparse):
+        monkeypatch.setattr(hp, "_NMS_SPARSE", sparse)
+        cf = hp.CircleFinder(P, h, w, 5, 25, cap)
+        for plane, (c, sc) in enumerate(sets):
+            n = len(c)
+            cf.circles[plane, :n] = dev(c)
+            cf.scores[plane, :n] = dev(sc)
+            cf.alive[plane, :n] = dev(rng.permutation(n).astype(np.int32))
+            cf.num_circles[plane] = n
+            cf.num_alive[plane] = n
+            cf.max_rc[plane] = dev(np.array([c[:, 0].max(), c[:, 1].max()] if n else [0, 0], dtype=np.int32))
+        out, out_scores, num_out = cf.nms_stage(min_dist)
+        done = cf.nms_done.cpu().numpy().copy() if sparse else None
+        assert not cf.state.any()  # the cleanup has returned every state byte to 0
+        return [out[k, : int(num_out[k])].cpu().numpy() for k in range(P)], done
+
+    got, done = run(True)
+    want, _ = run(False)
+    assert done.tolist() == ([0, 0, 0, 0] if min_dist > 15 else [1, 0, 1, 1])
+    for plane, (c, sc) in enumerate(sets):
+        np.testing.assert_array_equal(got[plane], want[plane], err_msg=f"plane {plane}")
+        if len(c):  # (the oracle wraps negative claim indices as numba does)
+            order = np.lexsort((np.arange(len(c)), -sc.astype(np.float64)))
+            keep = rn.filter_neighbors(c[order], min_dist)
+            np.testing.assert_array_equal(got[plane], c[order][keep], err_msg=f"plane {plane} vs oracle")
+
+
 def test_find_circles_empty(hp):
     planes = np.zeros((1, 128, 128), dtype=np.uint16)
     cf = hp.CircleFinder(1, 128, 128, 8, 12, 1000)
