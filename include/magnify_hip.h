@@ -390,8 +390,8 @@ int mg_nms_cleanup(const int32_t* d_circles, int64_t circle_cap, const float* d_
  * whose centres differ by (dr, dc) share a cell (the caller builds it from the ring of mg_circle_points).  A plane's
  * alive circles are bucketed in LDS, a circle looks at the buckets around it; d_state gets 1 (kept) / 2 (dropped) for
  * every alive circle of a plane it decides and d_done[plane] = 1.  d_done[plane] = 0 -- the plane is left to
- * mg_nms_same_centre / mg_nms_rounds, untouched -- when it holds more than 12 288 alive circles, spans more than 4 608
- * buckets of 64 x 64, or a centre lies at row or col < -(min_dist + 1) (the reference's claim index would be negative
+ * mg_nms_same_centre / mg_nms_rounds, untouched -- when it holds more than 12 288 alive circles, spans more than 9 216
+ * buckets of 32 x 64, or a centre lies at row or col < -(min_dist + 1) (the reference's claim index would be negative
  * and wrap); every plane when min_dist > mg_nms_sparse_max_dist().  d_skip of the three calls above = this d_done:
  * they leave the planes alone that are decided (the cleanup only zeroes their circles' state bytes).  Needs no claim
  * grid and does not look at d_state before writing it. */

@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
 // earlier j.  So the grid is not needed -- only, for every alive circle, the alive circles around it.  The rounds above
 // reach that through 64 claim-grid cells per circle and round (memory-side atomics and scattered 8-byte loads over a
 // 137 MB grid per plane: 0.9 ms per step at C4 with its same-centre pass and the cleanup); here a plane's ~11 000
-// alive circles are sorted into 64 x 64 buckets in LDS, a circle looks at the 3 x 3 buckets around it, tests
+// alive circles are sorted into buckets of 32 x 64 in LDS, a circle looks at the 3 x 3 buckets around it, tests
 // c_i - c_j against the bitmap of D and compares keys: kept when every conflicting circle before it is rejected,
 // rejected when one of them is kept, undecided (another round of the in-kernel loop) otherwise -- the sequential
 // greedy choice, whatever the order the threads run in.  A plane the kernel cannot take (more than SP_CAP circles, more
@@ -1032,12 +1032,14 @@ __global__ __launch_bounds__(NT) void k_nms(const int32_t* __restrict__ d_circle
 constexpr int SP_NT = 1024;
 constexpr int SP_CAP = 12288;           // alive circles of a plane held in LDS (SP_PER per thread)
 constexpr int SP_PER = SP_CAP / SP_NT;
-constexpr int SP_SHIFT = 6;             // log2 of the bucket edge
+constexpr int SP_SHIFT_R = 5, SP_SHIFT_C = 6;  // log2 of a bucket's rows / columns: both >= the reach 2 * min_dist
 constexpr int SP_BIAS = 64;             // added to coordinates: >= min_dist + 1, so stored coordinates are >= 0
-constexpr int SP_MAXB = 4608;           // buckets per plane
+constexpr int SP_MAXB = 9216;           // buckets per plane (16-bit starts: two per LDS word)
 constexpr int SP_MAXD = 15;             // min_dist up to this (the bitmap of D has (4 d + 1)^2 bits)
 constexpr int SP_DWORDS = ((4 * SP_MAXD + 1) * (4 * SP_MAXD + 1) + 31) / 32;
-constexpr size_t SP_LDS = (size_t)SP_CAP * (4 + 4 + 2 + 1) + (size_t)(SP_MAXB + 1) * 4 + SP_DWORDS * 4;
+constexpr int SP_BWORDS = (SP_MAXB + 2 + 1) / 2;
+constexpr size_t SP_LDS = (size_t)SP_CAP * (4 + 4 + 2 + 1) + (size_t)SP_BWORDS * 4 + SP_DWORDS * 4;
+static_assert(2 * SP_MAXD <= (1 << SP_SHIFT_R) && SP_CAP < 65536, "bucket edge / 16-bit starts");
 
 __global__ __launch_bounds__(SP_NT) void k_nms_sparse(const int32_t* __restrict__ d_circles, int64_t circle_cap,
                                                       const float* __restrict__ d_scores,
@@ -1049,15 +1051,16 @@ __global__ __launch_bounds__(SP_NT) void k_nms_sparse(const int32_t* __restrict_
   extern __shared__ __attribute__((aligned(16))) uint8_t sp_lds[];
   uint32_t* pos = reinterpret_cast<uint32_t*>(sp_lds);          // (row + bias) << 16 | (col + bias)
   uint32_t* skey = pos + SP_CAP;                                // the score half of nms_key: smaller = earlier
-  int32_t* bstart = reinterpret_cast<int32_t*>(skey + SP_CAP);  // [nb + 1]
-  uint32_t* dbits = reinterpret_cast<uint32_t*>(bstart + SP_MAXB + 1);
+  uint32_t* bwords = skey + SP_CAP;                             // [nb + 2] 16-bit entries, two per word
+  uint16_t* bstart = reinterpret_cast<uint16_t*>(bwords);
+  uint32_t* dbits = bwords + SP_BWORDS;
   uint16_t* sorted = reinterpret_cast<uint16_t*>(dbits + SP_DWORDS);
   uint8_t* st = reinterpret_cast<uint8_t*>(sorted + SP_CAP);
   __shared__ int s_bad;
   const int plane = blockIdx.x;
   const int n = d_num_alive[plane];
   if (threadIdx.x == 0) s_bad = 0;
-  const int nbr = ((d_max_rc[2 * plane] + SP_BIAS) >> SP_SHIFT) + 1, nbc = ((d_max_rc[2 * plane + 1] + SP_BIAS) >> SP_SHIFT) + 1;
+  const int nbr = ((d_max_rc[2 * plane] + SP_BIAS) >> SP_SHIFT_R) + 1, nbc = ((d_max_rc[2 * plane + 1] + SP_BIAS) >> SP_SHIFT_C) + 1;
   const int nb = nbr * nbc;
   if (n <= 0 || n > SP_CAP || nb > SP_MAXB || nbr <= 0 || nbc <= 0) {  // block-uniform
     if (threadIdx.x == 0) d_done[plane] = (n <= 0);  // (no alive circle: nothing for the rounds either)
@@ -1069,28 +1072,38 @@ __global__ __launch_bounds__(SP_NT) void k_nms_sparse(const int32_t* __restrict_
   const uint32_t* tie = d_tie ? d_tie + (int64_t)plane * circle_cap : nullptr;
   const int side = 4 * min_dist + 1, reach = 2 * min_dist;
   for (int i = threadIdx.x; i < (side * side + 31) / 32; i += SP_NT) dbits[i] = d_dbits[i];
-  for (int i = threadIdx.x; i <= nb; i += SP_NT) bstart[i] = 0;
+  for (int i = threadIdx.x; i < (nb + 3) / 2; i += SP_NT) bwords[i] = 0u;
   __syncthreads();
-  // ---- the circles, their buckets, their slots inside the buckets ----
-  int slot[SP_PER], bkt[SP_PER];
+  // ---- the circles, their buckets, their slots inside the buckets (the gathers of all of a thread's circles in flight
+  // together: index, then row / column / score, then the LDS work) ----
+  int slot[SP_PER], bkt[SP_PER], idx[SP_PER], row[SP_PER], col[SP_PER];
+  float sc[SP_PER];
   bool bad = false;
+#pragma unroll
+  for (int u = 0; u < SP_PER; ++u) idx[u] = alive[min((int)threadIdx.x + u * SP_NT, n - 1)];
+#pragma unroll
+  for (int u = 0; u < SP_PER; ++u) {
+    row[u] = circles[3 * (int64_t)idx[u]], col[u] = circles[3 * (int64_t)idx[u] + 1];
+    sc[u] = scores[idx[u]];
+  }
+  const int max_row = d_max_rc[2 * plane], max_col = d_max_rc[2 * plane + 1];
 #pragma unroll
   for (int u = 0; u < SP_PER; ++u) {
     const int a = threadIdx.x + u * SP_NT;
     slot[u] = 0, bkt[u] = -1;
     if (a < n) {
-      const int idx = alive[a];
-      const int row = circles[3 * (int64_t)idx], col = circles[3 * (int64_t)idx + 1];
-      if (row < -(min_dist + 1) || col < -(min_dist + 1) || row > d_max_rc[2 * plane] || col > d_max_rc[2 * plane + 1]) {
+      if (row[u] < -(min_dist + 1) || col[u] < -(min_dist + 1) || row[u] > max_row || col[u] > max_col) {
         bad = true;
       } else {
-        uint32_t b = __float_as_uint(scores[idx]);
+        uint32_t b = __float_as_uint(sc[u]);
         b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-        pos[a] = ((uint32_t)(row + SP_BIAS) << 16) | (uint32_t)(col + SP_BIAS);
+        pos[a] = ((uint32_t)(row[u] + SP_BIAS) << 16) | (uint32_t)(col[u] + SP_BIAS);
         skey[a] = ~b;
         st[a] = 0;
-        bkt[u] = ((row + SP_BIAS) >> SP_SHIFT) * nbc + ((col + SP_BIAS) >> SP_SHIFT);
-        slot[u] = atomicAdd(&bstart[bkt[u] + 1], 1);
+        bkt[u] = ((row[u] + SP_BIAS) >> SP_SHIFT_R) * nbc + ((col[u] + SP_BIAS) >> SP_SHIFT_C);
+        // entry bkt + 1 counts the bucket (16-bit halves of a word: a 32-bit atomic on the half's word; n < 65536: no carry)
+        const int e = bkt[u] + 1, sh = 16 * (e & 1);
+        slot[u] = (int)((atomicAdd(&bwords[e >> 1], 1u << sh) >> sh) & 0xFFFFu);
       }
     }
   }
@@ -1104,23 +1117,23 @@ __global__ __launch_bounds__(SP_NT) void k_nms_sparse(const int32_t* __restrict_
   {
     const int per = (nb + SP_NT - 1) / SP_NT;
     const int lo = min((int)threadIdx.x * per, nb), hi = min(lo + per, nb);
+    constexpr int MAXPER = (SP_MAXB + SP_NT - 1) / SP_NT;
+    int cnt[MAXPER];
     int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += bstart[i + 1];
+#pragma unroll
+    for (int k = 0; k < MAXPER; ++k) {
+      cnt[k] = lo + k < hi ? (int)bstart[lo + k + 1] : 0;
+      sum += cnt[k];
+    }
     int total;
     int run = mg_block_exscan(sum, &total);
-    __syncthreads();
-    for (int i = lo; i < hi; ++i) {
-      const int c = bstart[i + 1];
-      bstart[i + 1] = run;  // (entry i + 1 holds bucket i's START until the shift below)
-      run += c;
+    __syncthreads();  // every count has been read: the entries become starts (16-bit stores of neighbours share words)
+#pragma unroll
+    for (int k = 0; k < MAXPER; ++k) {
+      if (lo + k < hi) bstart[lo + k] = (uint16_t)run;
+      run += cnt[k];
     }
-    __syncthreads();
-    // shift: bstart[i] = start of bucket i, bstart[nb] = n
-    int mine[8];
-    for (int k = 0, i = lo; i < hi && k < 8; ++i, ++k) mine[k] = bstart[i + 1];
-    __syncthreads();
-    for (int k = 0, i = lo; i < hi && k < 8; ++i, ++k) bstart[i] = mine[k];
-    if (threadIdx.x == 0) bstart[nb] = n;
+    if (threadIdx.x == 0) bstart[nb] = (uint16_t)n;
   }
   __syncthreads();
 #pragma unroll
@@ -1128,49 +1141,66 @@ __global__ __launch_bounds__(SP_NT) void k_nms_sparse(const int32_t* __restrict_
     if (bkt[u] >= 0) sorted[bstart[bkt[u]] + slot[u]] = (uint16_t)(threadIdx.x + u * SP_NT);
   __syncthreads();
   // ---- rounds ----
+  // A circle that is blocked remembers ONE circle it waits for (the earliest undecided conflicting circle before it):
+  // while that one is undecided the circle stays blocked, when it is kept the circle is rejected -- no new scan of
+  // the neighbourhood in either case; only when it is rejected does the circle look around again.
+  auto scan = [&](int a, int& wait_for) -> int {  // 1 kept, 2 rejected, 0 blocked (wait_for = whom to watch)
+    const uint32_t pa = pos[a], ka = skey[a];
+    const int ra = (int)(pa >> 16), ca = (int)(pa & 0xFFFFu);
+    const int br = ra >> SP_SHIFT_R, bc = ca >> SP_SHIFT_C;
+    uint32_t ta = 0, best_k = 0xFFFFFFFFu, best_t = 0xFFFFFFFFu;
+    bool have_ta = false;
+    wait_for = -1;
+    for (int dbr = -1; dbr <= 1; ++dbr) {
+      const int r2 = br + dbr;
+      if (r2 < 0 || r2 >= nbr) continue;
+      const int c_lo = max(bc - 1, 0), c_hi = min(bc + 1, nbc - 1);
+      const int k0 = bstart[r2 * nbc + c_lo], k1 = bstart[r2 * nbc + c_hi + 1];  // three buckets of a row are one run
+      for (int k = k0; k < k1; ++k) {
+        const int j = sorted[k];
+        if (j == a) continue;
+        const uint32_t pj = pos[j];
+        const int dr = ra - (int)(pj >> 16), dc = ca - (int)(pj & 0xFFFFu);
+        if (abs(dr) > reach || abs(dc) > reach) continue;
+        const int bit = (dr + reach) * side + dc + reach;
+        if (!((dbits[bit >> 5] >> (bit & 31)) & 1u)) continue;
+        // j's ring meets a's: is j before a?
+        const uint32_t kj = skey[j];
+        bool before = kj < ka;
+        uint32_t tj = 0;
+        if (kj == ka) {
+          if (!have_ta) ta = tie ? tie[alive[a]] : (uint32_t)alive[a], have_ta = true;
+          tj = tie ? tie[alive[j]] : (uint32_t)alive[j];
+          before = tj < ta;
+        }
+        if (!before) continue;
+        const uint8_t sj = st[j];
+        if (sj == 1) return 2;
+        if (sj == 0 && (kj < best_k || (kj == best_k && tj < best_t))) best_k = kj, best_t = tj, wait_for = j;
+      }
+    }
+    return wait_for < 0 ? 1 : 0;
+  };
+  int wait_for[SP_PER];
+#pragma unroll
+  for (int u = 0; u < SP_PER; ++u) wait_for[u] = -1;
   int again;
   do {
     int changed = 0;
-#pragma unroll 1
-    for (int a = threadIdx.x; a < n; a += SP_NT) {
-      if (st[a] != 0) continue;
-      const uint32_t pa = pos[a], ka = skey[a];
-      const int ra = (int)(pa >> 16), ca = (int)(pa & 0xFFFFu);
-      const int br = ra >> SP_SHIFT, bc = ca >> SP_SHIFT;
-      uint32_t ta = 0;
-      bool have_ta = false, rejected = false, blocked = false;
-      for (int dbr = -1; dbr <= 1 && !rejected; ++dbr) {
-        const int r2 = br + dbr;
-        if (r2 < 0 || r2 >= nbr) continue;
-        const int c_lo = max(bc - 1, 0), c_hi = min(bc + 1, nbc - 1);
-        const int k0 = bstart[r2 * nbc + c_lo], k1 = bstart[r2 * nbc + c_hi + 1];  // three buckets of a row are one run
-        for (int k = k0; k < k1; ++k) {
-          const int j = sorted[k];
-          if (j == a) continue;
-          const uint32_t pj = pos[j];
-          const int dr = ra - (int)(pj >> 16), dc = ca - (int)(pj & 0xFFFFu);
-          if (abs(dr) > reach || abs(dc) > reach) continue;
-          const int bit = (dr + reach) * side + dc + reach;
-          if (!((dbits[bit >> 5] >> (bit & 31)) & 1u)) continue;
-          // j's ring meets a's: is j before a?
-          const uint32_t kj = skey[j];
-          bool before = kj < ka;
-          if (kj == ka) {
-            if (!have_ta) ta = tie ? tie[alive[a]] : (uint32_t)alive[a], have_ta = true;
-            const uint32_t tj = tie ? tie[alive[j]] : (uint32_t)alive[j];
-            before = tj < ta;
-          }
-          if (!before) continue;
-          const uint8_t sj = st[j];
-          if (sj == 1) {
-            rejected = true;
-            break;
-          }
-          if (sj == 0) blocked = true;
+#pragma unroll
+    for (int u = 0; u < SP_PER; ++u) {
+      const int a = threadIdx.x + u * SP_NT;
+      if (a >= n || st[a] != 0) continue;
+      if (wait_for[u] >= 0) {
+        const uint8_t sw = st[wait_for[u]];
+        if (sw == 0) continue;  // still blocked
+        if (sw == 1) {
+          st[a] = 2, changed = 1;
+          continue;
         }
       }
-      if (rejected) st[a] = 2, changed = 1;
-      else if (!blocked) st[a] = 1, changed = 1;
+      const int res = scan(a, wait_for[u]);
+      if (res) st[a] = (uint8_t)res, changed = 1;
     }
     again = __syncthreads_or(changed);
   } while (again);
