@@ -204,7 +204,8 @@ class StackProcessor:
                 return self._trial_roi_sets(out, want_roi, tries[1]) if tries else out
             beads = self.detect(seed)
             if tries:
-                out = self._trial_pairs(lambda img, tag: self.segment_reduce(beads, want_roi, img, tag), tries[1])
+                out = self._trial_pairs(lambda img, tag: self.segment_reduce(beads, want_roi, img, tag), tries[1],
+                                        markers=sum(len(b) for b in beads))
                 out["beads"] = beads
                 return out
         out = self.segment_reduce(beads, want_roi=want_roi)
@@ -254,7 +255,11 @@ class StackProcessor:
         tried from them too (_trial_roi_sets; each holds the corrected stack); the fastest is self.image meanwhile."""
         blocks, times = [], []
         for k in range(tries):
-            self.image = self.image if k == 0 else torch.empty_like(self.image)
+            if k:
+                try:
+                    self.image = torch.empty_like(self.image)
+                except torch.OutOfMemoryError:  # (less free memory than the estimate said: as many blocks as there are)
+                    break
             blocks.append(self.image)
             times.append(self._timed(lambda: self.flatfield(stack, flatfield, darkfield)))
         self.image = blocks[int(np.argmin(times))]
@@ -274,22 +279,43 @@ class StackProcessor:
         counts = [len(b) for b in out["beads"]]
         res = self._trial_pairs(lambda img, tag: hp.roi_gather_reduce(
             img.view(T, C, 1, h, w), None, self.L, None, want_roi=want_roi, reuse_buffers=True, disks=True,
-            device_tables=(tabs[0], counts, self.max_r), pool_tag=tag), tries)
+            device_tables=(tabs[0], counts, self.max_r), pool_tag=tag), tries, markers=int(sum(counts)))
         res["beads"] = out["beads"]
         return res
 
-    def _trial_pairs(self, run, tries):
+    def _trial_pairs(self, run, tries, markers=None):
         """``run(image block, pool tag)`` = the ROI pass: timed from every image block of the trial into ``tries`` output
         sets of their own (the pass reads one and writes the other: its level belongs to the pair); the pair with the
         smallest flat-field + ROI time is this processor's from now on, everything else goes back to the driver.
-        Returns the pass's result in the set that stays."""
+        Returns the pass's result in the set that stays.  The sets are as large as the markers make them (a noiseless
+        stack has several times the markers of a noisy one): as many are tried as fit the free memory -- fewer than two:
+        the image block with the fastest flat-field passes stays and the pass runs once more into the untagged set."""
         blocks, self._trial_blocks = self._trial_blocks, None
         flat_ms = self.placement["flatfield_ms"]
+        hp.drop_pool_tags([""])  # (the call's own result is made again below)
+        torch.cuda.empty_cache()
+        if markers is not None:
+            planes = self.C if self.mode == "P" else self.C * self.T
+            set_bytes = int(1.3 * markers * self.L * self.L * (2 * planes + 2)) + (64 << 20)
+            free, _ = torch.cuda.mem_get_info(self.dev)
+            tries = int(min(tries, max(0, free - (8 << 30)) // set_bytes))
         tags = ["#place%d" % k for k in range(tries)]
-        roi_ms = [[self._timed(lambda: run(img, tag)) for tag in tags] for img in blocks]
+        roi_ms = None
+        if tries >= 2:
+            try:
+                roi_ms = [[self._timed(lambda: run(img, tag)) for tag in tags] for img in blocks]
+            except torch.OutOfMemoryError:  # (the estimate was too low: no set trial)
+                roi_ms = None
+        if roi_ms is None:
+            hp.drop_pool_tags(tags)
+            self.image = blocks[int(np.argmin(flat_ms))]
+            del blocks
+            torch.cuda.empty_cache()
+            self.placement.update(image_block=int(np.argmin(flat_ms)), roi_ms=None, roi_set=None)
+            return run(self.image, self.pool_tag)
         total = np.asarray(roi_ms) + np.asarray(flat_ms)[:, None]
         bi, bj = (int(v) for v in np.unravel_index(int(np.argmin(total)), total.shape))
-        hp.drop_pool_tags([""] + [t for k, t in enumerate(tags) if k != bj])
+        hp.drop_pool_tags([t for k, t in enumerate(tags) if k != bj])
         self.image, self.pool_tag = blocks[bi], tags[bj]
         del blocks
         torch.cuda.empty_cache()  # the blocks not kept go back to the driver NOW (~0.4 s for 50 GB), not at the next graph capture
