@@ -911,10 +911,17 @@ class CircleFinder:
             graph = torch.cuda.CUDAGraph()
             self._cap_stream.wait_stream(main)
             _CAPTURING = True
-            # (thread-local: what other host threads do on their streams meanwhile does not concern this capture)
-            with torch.cuda.graph(graph, stream=self._cap_stream, capture_error_mode="thread_local"):
-                _, rounds = self._launch_chain(planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, False, False,
-                                               passthrough_u8, bufs=bufs)
+            # (thread-local: what other host threads do on their streams meanwhile does not concern this capture.
+            # capture_begin / capture_end directly, not torch.cuda.graph: that context manager starts with
+            # torch.cuda.empty_cache(), which hands every cached block back to the driver -- 0.4 s when a few tens of
+            # gigabytes of grown-out-of output sets sit in the cache, inside whatever region the capture falls into)
+            with torch.cuda.stream(self._cap_stream):
+                graph.capture_begin(capture_error_mode="thread_local")
+                try:
+                    _, rounds = self._launch_chain(planes, minmax, low_q, high_q, min_roundness, min_dist, seeds, False,
+                                                   False, passthrough_u8, bufs=bufs)
+                finally:
+                    graph.capture_end()
             main.wait_stream(self._cap_stream)
         except Exception as exc:  # noqa: BLE001  (whatever the runtime refuses: fall back in-process)
             self._graphs = None
