@@ -92,8 +92,14 @@ struct Pairs {
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 // Sum of the bounds over the perimeter of the circle whose centre byte sits at lds[vaddr + BIAS].
+// `need`: what the sum has to reach (wave-uniform: a wave's circles share the radius).  A bound is at most 64 per
+// point, so after k of n pairs a circle with sum + 128 (n - k) < need cannot reach it whatever the rest holds; when
+// that is true of ALL 64 circles of the wave -- four checks in the last quarter of the walk: a wave of noise circles
+// (81 % of the waves hold no survivor) is out at ~85 % of its perimeter -- the rest is not read.  The sums returned
+// then are below `need` like the full ones would be: the same circles are dropped.
 template <int R>
-__device__ __forceinline__ int score_r(const uint8_t* lds, int vaddr, const uint2* __restrict__ tabs) {
+__device__ __forceinline__ int score_r(const uint8_t* lds, int vaddr, const uint2* __restrict__ tabs, int need = -(1 << 30),
+                                       bool valid = true) {
   constexpr Pairs<R> P{};
   static_assert(P.n <= MAXP, "perimeter too long");
   int sum = 0;
@@ -106,6 +112,10 @@ __device__ __forceinline__ int score_r(const uint8_t* lds, int vaddr, const uint
     s.y = lds[vaddr + (BIAS - off)];
     const uint32_t q = __builtin_amdgcn_perm(t.y, t.x, __builtin_bit_cast(uint32_t, s));  // bytes 0 and 2: the two bounds
     sum = __builtin_amdgcn_sdot4((int)q, 0x00010001, sum, false);
+    const int done = k + 1;
+    if (P.n >= 16 && done < P.n && (done == (P.n * 12) / 16 || done == (P.n * 13) / 16 || done == (P.n * 14) / 16 || done == (P.n * 15) / 16)) {
+      if (__ballot(valid && sum + 128 * (P.n - done) >= need) == 0) return sum;
+    }
   }
   return sum;
 }
@@ -267,8 +277,9 @@ __global__ __launch_bounds__(NP) void k_prefilter(const uint32_t* __restrict__ d
       const int wrow = (s / SUBX) * TS + (int)((key >> 6) & 63u) + max_r, wcol = (s % SUBX) * TS + (int)(key & 63u) + max_r;
       const int vaddr = WBASE + wrow * WSTR + wcol - BIAS;
       int sum = 0;
+      const int need_rho = need[rho];
       switch (rho + min_r) {
-#define MG_CASE(R) case R: sum = score_r<R>(lds, vaddr, d_tabs); break;
+#define MG_CASE(R) case R: sum = score_r<R>(lds, vaddr, d_tabs, need_rho, valid); break;
           MG_CASE(2) MG_CASE(3) MG_CASE(4) MG_CASE(5) MG_CASE(6) MG_CASE(7) MG_CASE(8) MG_CASE(9) MG_CASE(10)
           MG_CASE(11) MG_CASE(12) MG_CASE(13) MG_CASE(14) MG_CASE(15) MG_CASE(16) MG_CASE(17) MG_CASE(18)
           MG_CASE(19) MG_CASE(20) MG_CASE(21) MG_CASE(22) MG_CASE(23) MG_CASE(24) MG_CASE(25) MG_CASE(26)
