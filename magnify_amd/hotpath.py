@@ -723,14 +723,21 @@ class CircleFinder:
             self._nms_dist = min_dist
             self._drop_graphs()
 
+    def _sparse_nms(self):
+        """mg_nms_sparse ahead of the claim-grid rounds: from four planes of 512^2 on.  It runs a plane in ONE workgroup
+        (~60 us of latencies whatever the plane holds) and the rounds' launches still go out, to find the planes done:
+        a single plane (C1, C2, a one-timepoint shard) or hundreds of chamber windows with a few circles each (C3) are
+        quicker through the rounds alone (C1: 0.87 against 0.96 ms)."""
+        return _NMS_SPARSE and self.P >= 4 and self.h * self.w >= (1 << 18)
+
     def _nms_rounds(self, min_dist, first, count, out_cap, cleared=False):
         """Suppression rounds; round k of this group counts what it left undecided in self.undecided[k] (``cleared``:
         the status block they are rows of has just been cleared).  ``first``: the same-centre pass (only the first
         circle of a centre enters the rounds: exact, three tiny launches)."""
         P, s, ring = self.P, _stream(), self._nms_ring
-        skip = self.nms_done.data_ptr() if _NMS_SPARSE else 0
+        skip = self.nms_done.data_ptr() if self._sparse_nms() else 0
         if first:
-            if _NMS_SPARSE:  # whole planes decided from the circles alone; the calls below leave those planes alone
+            if skip:  # whole planes decided from the circles alone; the calls below leave those planes alone
                 _call("mg_nms_sparse", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
                       self.num_alive.data_ptr(), self.max_rc.data_ptr(), P, min_dist, self._nms_dbits.data_ptr(),
                       self.state.data_ptr(), _ptr(self._tie_keys), self.nms_done.data_ptr(), s, stage="mg_nms_rounds")
@@ -748,7 +755,7 @@ class CircleFinder:
         _call("mg_nms_cleanup", self.circles.data_ptr(), self.cap, self.scores.data_ptr(), self.alive.data_ptr(),
               self.num_alive.data_ptr(), self.max_rc.data_ptr(), self.P, min_dist, self._nms_ring.data_ptr(),
               self._nms_ring.shape[0], self.nms_grid.data_ptr(), self.nms_grid.shape[1], self.state.data_ptr(),
-              out_cap, self.nms_done.data_ptr() if _NMS_SPARSE else 0, _stream())
+              out_cap, self.nms_done.data_ptr() if self._sparse_nms() else 0, _stream())
 
     def nms_stage(self, min_dist: int, optimistic=False, bufs=None, cleared=False):
         """Checked chain: the alive counts come to the host first (they size the output), the rounds are checked for
