@@ -1274,62 +1274,83 @@ __global__ __launch_bounds__(NT) void k_cell_fill(const uint32_t* __restrict__ d
 // bits at once, a segmented wave scan over the rows of a cell gives each row its output position,
 // and a lane then writes only its own row's few coordinates -- a short store run instead of a
 // thread walking a whole cell (grid rows of dependent loads and ~70 stores).  grid <= 64.
+// bits_at without its branch around the second word (the bitmaps carry a spare word): a load behind a lane-level branch
+// ends with a wait, and the loads of a wave's groups are meant to be in flight together
+__device__ __forceinline__ uint32_t bits_at_nb(const uint32_t* __restrict__ bits, int64_t bit0, int n) {
+  const int64_t wi = bit0 >> 5;
+  const int sh = (int)(bit0 & 31);
+  const uint64_t two = (uint64_t)bits[wi] | ((uint64_t)bits[wi + 1] << 32);
+  const uint32_t v = (uint32_t)(two >> sh);
+  return n >= 32 ? v : (v & ((1u << n) - 1u));
+}
+
+constexpr int FILL_TRIPS = 4;  // groups of cells per wave: the bit rows and starts of all of them are requested before
+                               // the first is worked on (a wave per group sat out two global round trips for ~200
+                               // entries: 0.69 ms at C4; 3 / 4 / 6 / 8 groups: 0.58 / 0.57 / 0.67 / 0.76)
+
 __global__ __launch_bounds__(NT) void k_cell_fill_rows(const uint32_t* __restrict__ d_bits, int64_t words_per_plane,
                                                        int h, int w, int grid, int gc, int n_cells,
                                                        const int32_t* __restrict__ d_starts,
                                                        int32_t* __restrict__ d_coords, int64_t coord_cap) {
   const int plane = blockIdx.y;
-  const int cpw = 64 / grid;  // cells per wave
+  const int cpw = 64 / grid;  // cells per group (a wave's lanes: one per cell row)
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6;
   const int ci = lane / grid, r = lane - ci * grid;
-  const int64_t cell = wave * cpw + ci;
   const uint32_t* bits = d_bits + plane * words_per_plane;
-  uint64_t rowbits = 0;
-  int y = 0, x0 = 0;
-  int64_t pos = 0;
-  if (ci < cpw && cell < n_cells) {
-    const int cr = (int)(cell / gc), cc = (int)(cell - (int64_t)cr * gc);
-    y = cr * grid + r;
-    x0 = cc * grid;
-    const int cw = min(grid, w - x0);
-    if (y < h) {
-      const int64_t b0 = (int64_t)y * w + x0;
-      rowbits = bits_at(bits, b0, min(32, cw));
-      if (cw > 32) rowbits |= (uint64_t)bits_at(bits, b0 + 32, cw - 32) << 32;
+  uint64_t rowbits[FILL_TRIPS];
+  int y[FILL_TRIPS], x0[FILL_TRIPS];
+  int64_t pos[FILL_TRIPS];
+#pragma unroll
+  for (int q = 0; q < FILL_TRIPS; ++q) {
+    const int64_t cell = (wave * FILL_TRIPS + q) * cpw + ci;
+    rowbits[q] = 0, y[q] = 0, x0[q] = 0, pos[q] = 0;
+    if (ci < cpw && cell < n_cells) {
+      const int cr = (int)(cell / gc), cc = (int)(cell - (int64_t)cr * gc);
+      y[q] = cr * grid + r;
+      x0[q] = cc * grid;
+      const int cw = min(grid, w - x0[q]);
+      if (y[q] < h) {
+        const int64_t b0 = (int64_t)y[q] * w + x0[q];
+        rowbits[q] = bits_at_nb(bits, b0, min(32, cw));
+        if (cw > 32) rowbits[q] |= (uint64_t)bits_at_nb(bits, b0 + 32, cw - 32) << 32;
+      }
+      pos[q] = d_starts[(int64_t)plane * n_cells + cell];
     }
-    pos = d_starts[(int64_t)plane * n_cells + cell];
   }
-  // The wave's cells are consecutive, so are their runs in the list: ONE contiguous run per wave, starting at the
+  // A group's cells are consecutive, so are their runs in the list: ONE contiguous run per group, starting at the
   // first cell's start.  A lane puts its row's coordinates at their places in an LDS copy of that run (wave-wide
   // exclusive scan of the row counts), then the wave stores the run with whole 512-byte instructions (before: every
   // lane stored its own few entries one after the other -- ~10 partly filled store instructions per wave).
-  constexpr int CH = 512;  // entries staged per trip (a wave of 17 % edge density has ~200; all pixels edges: 1200)
+  constexpr int CH = 512;  // entries staged per trip (a group of 17 % edge density has ~200; all pixels edges: 1200)
   __shared__ int2 s_stage[NT / 64][CH];
   int2* stage = s_stage[threadIdx.x >> 6];
-  const int cnt = __popcll(rowbits);
-  const int incl = mg_wave_scan_incl_i32(cnt);
-  const int total = __shfl(incl, 63);
-  const int lpos = incl - cnt;
-  const int64_t base = __shfl(pos, 0);  // (lane 0: cell wave * cpw, row 0 -- the start of the wave's first cell)
-  const bool any_cell = wave * cpw < n_cells;
   int2* out = reinterpret_cast<int2*>(d_coords + (int64_t)plane * coord_cap * 2);
-  for (int c0 = 0; c0 < total; c0 += CH) {  // wave-uniform
-    uint64_t rb = rowbits;
-    int li = lpos - c0;
-    while (rb) {
-      const int b = __ffsll((unsigned long long)rb) - 1;
-      rb &= rb - 1;
-      if (li >= 0 && li < CH) stage[li] = make_int2(y, x0 + b);
-      ++li;
+#pragma unroll
+  for (int q = 0; q < FILL_TRIPS; ++q) {
+    const int cnt = __popcll(rowbits[q]);
+    const int incl = mg_wave_scan_incl_i32(cnt);
+    const int total = __shfl(incl, 63);
+    const int lpos = incl - cnt;
+    const int64_t base = __shfl(pos[q], 0);  // (lane 0: the group's first cell, row 0 -- the start of that cell)
+    const bool any_cell = (wave * FILL_TRIPS + q) * cpw < n_cells;
+    for (int c0 = 0; c0 < total; c0 += CH) {  // wave-uniform
+      uint64_t rb = rowbits[q];
+      int li = lpos - c0;
+      while (rb) {
+        const int b = __ffsll((unsigned long long)rb) - 1;
+        rb &= rb - 1;
+        if (li >= 0 && li < CH) stage[li] = make_int2(y[q], x0[q] + b);
+        ++li;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (LDS operations of a wave complete in order)
+      const int n = min(total - c0, CH);
+      for (int i = lane; i < n; i += 64) {
+        const int64_t p = base + c0 + i;
+        if (any_cell && p < coord_cap) out[p] = stage[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (LDS operations of a wave complete in order)
-    const int n = min(total - c0, CH);
-    for (int i = lane; i < n; i += 64) {
-      const int64_t p = base + c0 + i;
-      if (any_cell && p < coord_cap) out[p] = stage[i];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
 }
 
@@ -1598,7 +1619,8 @@ extern "C" int mg_edge_grid(const uint32_t* d_edge_bits, int64_t words_per_plane
   }
   if ((phases & 2) && n_cells > 0) {  // ordered fill (entries beyond coord_cap are dropped; d_num_edges tells)
     if (grid <= 64) {
-      const int64_t waves = (n_cells + 64 / grid - 1) / (64 / grid);
+      const int64_t groups = (n_cells + 64 / grid - 1) / (64 / grid);
+      const int64_t waves = (groups + FILL_TRIPS - 1) / FILL_TRIPS;
       hipLaunchKernelGGL(k_cell_fill_rows, dim3((unsigned)((waves + NT / 64 - 1) / (NT / 64)), n_planes), dim3(NT), 0, s,
                          d_edge_bits, words_per_plane, h, w, grid, gc, n_cells, d_cell_starts, d_coords, coord_cap);
     } else {
