@@ -450,8 +450,11 @@ __global__ __launch_bounds__(NT) void k_tile_dedup(const uint32_t* __restrict__ 
   for (int wd = w0; wd < w1; ++wd) {
     uint32_t bits = lbits[wd];
     if (!bits) continue;
-    const int t = wd / words;  // tile of the group; (wd - t * words) * 32 + bit = the key's low 17 bits
-    const uint32_t hi = ((uint32_t)(tile0 + t) << 17) | ((uint32_t)(wd - t * words) << 5);
+    int t = 0, rem = wd;  // tile of the group; rem * 32 + bit = the key's low 17 bits  (TX - 1 compares, not a division)
+#pragma unroll
+    for (int k = 1; k < TX; ++k)
+      if (rem >= words) rem -= words, ++t;
+    const uint32_t hi = ((uint32_t)(tile0 + t) << 17) | ((uint32_t)rem << 5);
     while (bits) {
       const int b = __ffs(bits) - 1;
       bits &= bits - 1;
