@@ -1030,13 +1030,42 @@ __global__ __launch_bounds__(NT) void k_hysteresis(const uint32_t* __restrict__ 
   const uint32_t* weak = d_weak + plane * words_per_plane;
   uint32_t* strong = d_strong + plane * words_per_plane;
   int pending = 0;
-  for (int i = threadIdx.x; i < (HTH + 2) * (HW + 2); i += NT) {
-    const int r = i / (HW + 2), kk = i - r * (HW + 2);
-    const uint32_t sv = row_word(strong, h, w, ty0 - 1 + r, tx0 - 32 + 32 * kk);
-    const uint32_t wv = row_word(weak, h, w, ty0 - 1 + r, tx0 - 32 + 32 * kk);
-    st[r][kk] = sv;
-    wk[r][kk] = wv;
-    if (r >= 1 && r <= HTH && kk >= 1 && kk <= HW) pending |= (wv & ~sv) != 0;
+  if ((w & 31) == 0) {
+    // rows of whole words (tiles start on word boundaries): a thread's ~10 words of each map are requested together,
+    // then stored -- through row_word every one of them was two loads behind branches, i.e. a chain of round trips
+    // (the seven sweeps at 64 planes of 4096^2: 0.86 -> 0.73 ms)
+    constexpr int TOTAL = (HTH + 2) * (HW + 2), ITER = (TOTAL + NT - 1) / NT;
+    uint32_t sv[ITER], wv[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int i = min((int)threadIdx.x + it * NT, TOTAL - 1);
+      const int r = i / (HW + 2), kk = i - r * (HW + 2);
+      const int y = ty0 - 1 + r, x = tx0 - 32 + 32 * kk;
+      const bool in = y >= 0 && y < h && x >= 0 && x < w;
+      const int64_t wi = in ? ((int64_t)y * w + x) >> 5 : 0;
+      sv[it] = strong[wi];
+      wv[it] = weak[wi];
+      if (!in) sv[it] = 0u, wv[it] = 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int i = threadIdx.x + it * NT;
+      if (i < TOTAL) {
+        const int r = i / (HW + 2), kk = i - r * (HW + 2);
+        st[r][kk] = sv[it];
+        wk[r][kk] = wv[it];
+        if (r >= 1 && r <= HTH && kk >= 1 && kk <= HW) pending |= (wv[it] & ~sv[it]) != 0;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < (HTH + 2) * (HW + 2); i += NT) {
+      const int r = i / (HW + 2), kk = i - r * (HW + 2);
+      const uint32_t sv = row_word(strong, h, w, ty0 - 1 + r, tx0 - 32 + 32 * kk);
+      const uint32_t wv = row_word(weak, h, w, ty0 - 1 + r, tx0 - 32 + 32 * kk);
+      st[r][kk] = sv;
+      wk[r][kk] = wv;
+      if (r >= 1 && r <= HTH && kk >= 1 && kk <= HW) pending |= (wv & ~sv) != 0;
+    }
   }
   if (threadIdx.x == 0) s_mark = 0u;
   if (!__syncthreads_or(pending)) return;
@@ -1132,6 +1161,16 @@ __global__ __launch_bounds__(NT) void k_unpack_bits(const uint32_t* __restrict__
     d_out[plane * npix + i] = (bits[i >> 5] >> (i & 31)) & 1u;
 }
 
+// bits_at without its branch around the second word (the bitmaps carry a spare word): a load behind a lane-level branch
+// ends with a wait, and the loads of a wave's groups are meant to be in flight together
+__device__ __forceinline__ uint32_t bits_at_nb(const uint32_t* __restrict__ bits, int64_t bit0, int n) {
+  const int64_t wi = bit0 >> 5;
+  const int sh = (int)(bit0 & 31);
+  const uint64_t two = (uint64_t)bits[wi] | ((uint64_t)bits[wi + 1] << 32);
+  const uint32_t v = (uint32_t)(two >> sh);
+  return n >= 32 ? v : (v & ((1u << n) - 1u));
+}
+
 // ---- K5: grid_array from the bitmap: per-cell counts, scan, ordered coordinate fill -------------
 __global__ __launch_bounds__(NT) void k_cell_count(const uint32_t* __restrict__ d_bits, int64_t words_per_plane, int h,
                                                    int w, int grid, int gc, int n_cells,
@@ -1147,9 +1186,10 @@ __global__ __launch_bounds__(NT) void k_cell_count(const uint32_t* __restrict__ 
   const int y0 = cr * grid, x0 = cc * grid;
   const int ch = min(grid, h - y0), cw = min(grid, w - x0);
   int cnt = 0;
-  for (int r = 0; r < ch; ++r)
+#pragma unroll 5
+  for (int r = 0; r < ch; ++r)  // (branch-free loads, five rows a trip: in flight together)
     for (int c0 = 0; c0 < cw; c0 += 32)
-      cnt += __popc(bits_at(bits, (int64_t)(y0 + r) * w + x0 + c0, min(32, cw - c0)));
+      cnt += __popc(bits_at_nb(bits, (int64_t)(y0 + r) * w + x0 + c0, min(32, cw - c0)));
   d_counts[(int64_t)plane * n_cells + cell] = cnt;
 }
 
@@ -1274,16 +1314,6 @@ __global__ __launch_bounds__(NT) void k_cell_fill(const uint32_t* __restrict__ d
 // bits at once, a segmented wave scan over the rows of a cell gives each row its output position,
 // and a lane then writes only its own row's few coordinates -- a short store run instead of a
 // thread walking a whole cell (grid rows of dependent loads and ~70 stores).  grid <= 64.
-// bits_at without its branch around the second word (the bitmaps carry a spare word): a load behind a lane-level branch
-// ends with a wait, and the loads of a wave's groups are meant to be in flight together
-__device__ __forceinline__ uint32_t bits_at_nb(const uint32_t* __restrict__ bits, int64_t bit0, int n) {
-  const int64_t wi = bit0 >> 5;
-  const int sh = (int)(bit0 & 31);
-  const uint64_t two = (uint64_t)bits[wi] | ((uint64_t)bits[wi + 1] << 32);
-  const uint32_t v = (uint32_t)(two >> sh);
-  return n >= 32 ? v : (v & ((1u << n) - 1u));
-}
-
 constexpr int FILL_TRIPS = 4;  // groups of cells per wave: the bit rows and starts of all of them are requested before
                                // the first is worked on (a wave per group sat out two global round trips for ~200
                                // entries: 0.69 ms at C4; 3 / 4 / 6 / 8 groups: 0.58 / 0.57 / 0.67 / 0.76)
